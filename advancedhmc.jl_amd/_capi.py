@@ -1,0 +1,203 @@
+"""ctypes bindings for the C ABI declared in include/ahmc_hip.h.
+
+`CLib(path)` binds every entry point of the header on one shared library.  The product
+library is advancedhmc.jl_amd/csrc/libahmc_hip.so (HIP, gfx950) and is the ONLY library this
+package ever opens by itself: `load_hip_library()` raises if it has not been built — there is
+no CPU fallback.  (tests/ bind the same `CLib` class onto oracle/libahmc_oracle.so to obtain the
+checker; that path is never taken from inside the package.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+# --- enums (mirror include/ahmc_hip.h) --------------------------------------------------------
+AHMC_ABI_VERSION = 1
+OK, ERR_ARGUMENT, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_STATE = 0, 1, 2, 3, 4
+F32, F64 = 0, 1
+METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
+(TARGET_ISO_GAUSS, TARGET_DIAG_GAUSS, TARGET_FUNNEL, TARGET_HIER_GAUSS, TARGET_DENSE_GAUSS,
+ TARGET_EXTERNAL) = range(6)
+INTEGRATOR_LEAPFROG, INTEGRATOR_JITTERED, INTEGRATOR_TEMPERED = 0, 1, 2
+TS_ENDPOINT, TS_MULTINOMIAL, TS_SLICE = 0, 1, 2
+TC_CLASSIC, TC_GENERALISED, TC_STRICT = 0, 1, 2
+ADAPT_NONE, ADAPT_STEPSIZE, ADAPT_MASSMATRIX, ADAPT_NAIVE, ADAPT_STAN = range(5)
+
+# stat fields: name -> (id, is_int)
+STAT_FIELDS = {
+    "n_steps": (0, True),
+    "is_accept": (1, True),
+    "acceptance_rate": (2, False),
+    "log_density": (3, False),
+    "hamiltonian_energy": (4, False),
+    "hamiltonian_energy_error": (5, False),
+    "max_hamiltonian_energy_error": (6, False),
+    "tree_depth": (7, True),
+    "numerical_error": (8, True),
+    "step_size": (9, False),
+    "nom_step_size": (10, False),
+}
+
+
+class KernelCfg(C.Structure):
+    """ahmc_kernel_cfg"""
+    _fields_ = [
+        ("nuts", C.c_int32),
+        ("sampler", C.c_int32),
+        ("criterion", C.c_int32),
+        ("max_depth", C.c_int32),
+        ("delta_max", C.c_double),
+        ("L", C.c_int64),
+        ("lambda_", C.c_double),
+        ("refresh_alpha", C.c_double),
+    ]
+
+
+class AHMCError(RuntimeError):
+    """A non-zero status from the C ABI.  `ArgumentError` mirrors Julia's exception of the
+    same name (src/hamiltonian.jl:55-57, src/abstractmcmc.jl:64-70)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[ahmc status {code}] {msg}")
+        self.code = code
+
+
+class ArgumentError(AHMCError, ValueError):
+    pass
+
+
+class UnsupportedError(AHMCError, NotImplementedError):
+    pass
+
+
+_vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+
+# name -> (restype, argtypes); the complete symbol list of include/ahmc_hip.h
+SIGNATURES = {
+    "ahmc_create": (_i32, [_i32, _i32, _i64, _i64, _vp, C.POINTER(_vp)]),
+    "ahmc_destroy": (_i32, [_vp]),
+    "ahmc_last_error": (C.c_char_p, [_vp]),
+    "ahmc_abi_version": (_i32, []),
+    "ahmc_backend": (C.c_char_p, []),
+    "ahmc_sync": (_i32, [_vp]),
+    "ahmc_stream": (_vp, [_vp]),
+    "ahmc_set_target": (_i32, [_vp, _i32, _vp, _i64]),
+    "ahmc_set_metric": (_i32, [_vp, _i32, _vp, _i64]),
+    "ahmc_get_metric": (_i32, [_vp, _vp, _i64]),
+    "ahmc_set_stepsize": (_i32, [_vp, _vp, _i64]),
+    "ahmc_get_stepsize": (_i32, [_vp, _vp]),
+    "ahmc_set_integrator": (_i32, [_vp, _i32, _f64]),
+    "ahmc_seed": (_i32, [_vp, _u64, _u64, _u64, _u64]),
+    "ahmc_set_position": (_i32, [_vp, _vp, _vp]),
+    "ahmc_set_phasepoint": (_i32, [_vp, _vp, _vp, _vp, _vp]),
+    "ahmc_get_phasepoint": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ahmc_refresh_momentum": (_i32, [_vp, _f64]),
+    "ahmc_leapfrog": (_i32, [_vp, _i64]),
+    "ahmc_lf_pre": (_i32, [_vp, _i32, _i64, _i64]),
+    "ahmc_lf_post": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
+    "ahmc_theta_ptr": (_vp, [_vp]),
+    "ahmc_hmc_transition": (_i32, [_vp, _i64, _f64, _i32]),
+    "ahmc_nuts_transition": (_i32, [_vp, _i32, _f64, _i32, _i32]),
+    "ahmc_get_stat": (_i32, [_vp, _i32, _vp]),
+    "ahmc_find_good_stepsize": (_i32, [_vp, _f64, _i32]),
+    "ahmc_adaptor_init": (_i32, [_vp, _i32, _f64, _i32, _i32, _i32]),
+    "ahmc_adapt": (_i32, [_vp, _i64, _i64]),
+    "ahmc_stan_windows": (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i64), C.POINTER(_i64),
+                                 C.POINTER(_i64), _i32, C.POINTER(_i32)]),
+    "ahmc_sample": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i32, _vp]),
+    "ahmc_get_accum": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
+    "ahmc_reset_accum": (_i32, [_vp]),
+}
+
+
+class CLib:
+    """One loaded implementation of the ABI."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = os.path.abspath(path)
+        self.dll = C.CDLL(self.path, mode=C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0)
+        missing = []
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(self.dll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        if missing:
+            raise ImportError(f"{self.path} does not export: {', '.join(missing)}")
+        v = self.dll.ahmc_abi_version()
+        if v != AHMC_ABI_VERSION:
+            raise ImportError(f"{self.path}: ABI version {v}, expected {AHMC_ABI_VERSION}")
+        self.backend = self.dll.ahmc_backend().decode()
+
+    def check(self, code: int, ctx=None):
+        if code == OK:
+            return
+        msg = self.dll.ahmc_last_error(ctx)
+        msg = msg.decode("utf-8", "replace") if msg else ""
+        if code == ERR_ARGUMENT:
+            raise ArgumentError(code, msg)
+        if code == ERR_UNSUPPORTED:
+            raise UnsupportedError(code, msg)
+        raise AHMCError(code, msg)
+
+
+_HIP_LIB = None
+
+
+def hip_library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libahmc_hip.so")
+
+
+def load_hip_library() -> CLib:
+    """Open the HIP engine.  Fails loudly when it has not been built (no fallback)."""
+    global _HIP_LIB
+    if _HIP_LIB is None:
+        path = hip_library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+                "This package has no CPU fallback.")
+        # libtorch's bundled libamdhip64 must be the HIP runtime of the process if torch is used
+        # at all (bench.py uses torch.distributed/RCCL): import torch first so that our library's
+        # NEEDED libamdhip64.so.7 resolves to the copy already mapped.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for single-process use
+            pass
+        _HIP_LIB = CLib(path)
+        if not _HIP_LIB.backend.startswith("hip"):
+            raise ImportError(f"{path} reports backend {_HIP_LIB.backend!r}, expected the HIP engine")
+    return _HIP_LIB
+
+
+def np_dtype(dtype_code: int):
+    return np.float32 if dtype_code == F32 else np.float64
+
+
+def dtype_code(dtype) -> int:
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return F32
+    if dt == np.float64:
+        return F64
+    raise ArgumentError(ERR_ARGUMENT, f"element type must be float32 or float64, got {dt}")
+
+
+def as_ptr(a) -> C.c_void_p:
+    """host numpy array, torch tensor (host or device) or raw int address -> void*"""
+    if a is None:
+        return C.c_void_p(None)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(f"cannot take the address of {type(a)}")

@@ -1,0 +1,688 @@
+"""Host-side mirror of AdvancedHMC.jl's operator interface for the sampler-vec path.
+
+Julia is absent from the build image, so the host side above the C ABI is written in Python
+with the reference's names, argument meaning and error behaviour (so the parity tests read like
+test/sampler-vec.jl, test/integrator.jl, test/trajectory.jl).  The Julia package extension that
+binds the same ABI with `ccall` is julia/AdvancedHMCMI355XExt.jl.
+
+Every class cites the reference definition it mirrors (paths under the AdvancedHMC.jl checkout).
+Arrays are (D, N) column-major like a Julia Matrix: numpy arrays are converted with
+`np.asfortranarray`, results come back as F-ordered (D, N) arrays (or (D,) for a single chain).
+All compute happens in the C library the `Engine` is bound to — the HIP engine unless a test
+injects another `CLib`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import ArgumentError
+
+
+# ------------------------------------------------------------------------------------------------
+# RNG handle (replaces `rng::AbstractRNG`)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PhiloxRNG:
+    """Counter-based Philox4x32-10 stream family.  `chain_offset` is the global index of the
+    first local chain (multi-GPU shards), `iteration` the transition counter."""
+    seed: int = 0
+    chain_offset: int = 0
+    iteration: int = 0
+
+
+def _rng_spec(rng, n_chains):
+    """int | PhiloxRNG | sequence of PhiloxRNG (one per chain, src/utilities.jl:12-23)."""
+    if rng is None:
+        return PhiloxRNG(0), 1
+    if isinstance(rng, (int, np.integer)):
+        return PhiloxRNG(int(rng)), 1
+    if isinstance(rng, PhiloxRNG):
+        return rng, 1
+    rngs = list(rng)
+    if len(rngs) != n_chains:  # @argcheck length(rngs) == n_chains
+        raise ArgumentError(capi.ERR_ARGUMENT, f"length(rngs) == n_chains must hold, got {len(rngs)} != {n_chains}")
+    first = rngs[0]
+    if all(r.seed == first.seed and r.chain_offset == first.chain_offset for r in rngs):
+        return first, 0  # identically seeded RNG vector: every chain sees the same variates
+    if all(r.seed == first.seed and r.chain_offset == first.chain_offset + k for k, r in enumerate(rngs)):
+        return first, 1
+    raise ArgumentError(capi.ERR_ARGUMENT, "a vector of RNGs must share one seed (same or consecutive streams)")
+
+
+# ------------------------------------------------------------------------------------------------
+# metrics (src/metric.jl:17-120)
+# ------------------------------------------------------------------------------------------------
+def _size_tuple(sz):
+    if isinstance(sz, (int, np.integer)):
+        return (int(sz),)
+    return tuple(int(s) for s in sz)
+
+
+class AbstractMetric:
+    kind = None
+
+    @property
+    def D(self):
+        return self.size[0]
+
+
+class UnitEuclideanMetric(AbstractMetric):
+    """src/metric.jl:17-35.  UnitEuclideanMetric([T,] sz)"""
+    kind = capi.METRIC_UNIT
+
+    def __init__(self, *args):
+        if len(args) == 2:
+            self.eltype, sz = np.dtype(args[0]), args[1]
+        else:
+            self.eltype, sz = np.dtype(np.float64), args[0]
+        self.size = _size_tuple(sz)
+        self.Minv = None
+
+    def __repr__(self):
+        return f"UnitEuclideanMetric({self.eltype}, {self.size})"
+
+
+class DiagEuclideanMetric(AbstractMetric):
+    """src/metric.jl:52-72.  DiagEuclideanMetric(M⁻¹) | DiagEuclideanMetric([T,] sz)"""
+    kind = capi.METRIC_DIAG
+
+    def __init__(self, *args):
+        if len(args) == 2:
+            T, sz = np.dtype(args[0]), _size_tuple(args[1])
+            Minv = np.ones(sz, dtype=T, order="F")
+        elif isinstance(args[0], np.ndarray):
+            Minv = np.asfortranarray(args[0])
+            if Minv.dtype not in (np.float32, np.float64):
+                Minv = Minv.astype(np.float64)
+        else:
+            Minv = np.ones(_size_tuple(args[0]), dtype=np.float64, order="F")
+        self.Minv = Minv
+        self.eltype = Minv.dtype
+        self.size = Minv.shape
+
+    @property
+    def sqrtMinv(self):
+        return np.sqrt(self.Minv)
+
+    def __repr__(self):
+        return f"DiagEuclideanMetric({np.array2string(self.Minv.ravel(order='F')[:6], precision=3)} ...)"
+
+
+class DenseEuclideanMetric(AbstractMetric):
+    """src/metric.jl:89-120.  One (D, D) M⁻¹ shared by all chains (the reference has no batched
+    dense metric, :103; sharing it is this engine's extension)."""
+    kind = capi.METRIC_DENSE
+
+    def __init__(self, *args):
+        if len(args) == 2:
+            T, D = np.dtype(args[0]), _size_tuple(args[1])[0]
+            Minv = np.eye(D, dtype=T, order="F")
+        elif isinstance(args[0], np.ndarray):
+            Minv = np.asfortranarray(args[0])
+        else:
+            Minv = np.eye(_size_tuple(args[0])[0], dtype=np.float64, order="F")
+        if Minv.ndim != 2 or Minv.shape[0] != Minv.shape[1]:
+            raise ArgumentError(capi.ERR_ARGUMENT, "DenseEuclideanMetric needs a square M⁻¹")
+        self.Minv = Minv
+        self.eltype = Minv.dtype
+        self.size = (Minv.shape[0],)
+
+
+def renew(metric, Minv):
+    """src/metric.jl:31,69,117"""
+    if isinstance(metric, UnitEuclideanMetric):
+        return metric
+    return type(metric)(np.asarray(Minv))
+
+
+# ------------------------------------------------------------------------------------------------
+# targets: the (ℓπ, ∂ℓπ∂θ) pair of Hamiltonian (src/hamiltonian.jl:1-20) as built-in families
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Target:
+    kind: int
+    D: int
+    params: Optional[np.ndarray] = None
+
+
+def IsoGaussian(D):
+    """ℓπ of test/common.jl:76-77 (`Gaussian(zeros(D), ones(D))`)"""
+    return Target(capi.TARGET_ISO_GAUSS, int(D))
+
+
+def DiagGaussian(m, s):
+    """test/common.jl:35-77 `Gaussian(m, s)` with the exact gradient (m-x)/s²"""
+    m = np.asarray(m, dtype=np.float64).ravel()
+    s = np.asarray(s, dtype=np.float64).ravel()
+    if m.shape != s.shape:
+        raise ArgumentError(capi.ERR_ARGUMENT, "DiagGaussian: m and s must have the same length")
+    return Target(capi.TARGET_DIAG_GAUSS, m.size, np.concatenate([m, s]))
+
+
+def Funnel(D):
+    """Neal's funnel as defined in research/notebooks/geweke_test.ipynb cell 4"""
+    return Target(capi.TARGET_FUNNEL, int(D))
+
+
+def HierGaussian(D):
+    """θ = (μ, log τ, x₁..x_{D-2}) hierarchical Gaussian"""
+    return Target(capi.TARGET_HIER_GAUSS, int(D))
+
+
+def DenseGaussian(P):
+    """ℓπ = -½ θᵀPθ with P the (D, D) precision matrix"""
+    P = np.asfortranarray(np.asarray(P, dtype=np.float64))
+    return Target(capi.TARGET_DENSE_GAUSS, P.shape[0], P.ravel(order="F"))
+
+
+@dataclass
+class ExternalTarget:
+    """User log-density evaluated by the caller: `fn(θ (D,N)) -> (ℓπ (N,), ∇ℓπ (D,N))`, the
+    signature of `∂ℓπ∂θ` at test/common.jl:64-74.  Leapfrog runs through the split-step pair
+    ahmc_lf_pre / ahmc_lf_post around this callback."""
+    D: int
+    fn: object
+    kind: int = capi.TARGET_EXTERNAL
+    params: Optional[np.ndarray] = None
+
+
+@dataclass
+class Hamiltonian:
+    """src/hamiltonian.jl:1-20 (GaussianKinetic only, :18-20)"""
+    metric: AbstractMetric
+    target: object
+
+    def __post_init__(self):
+        if self.metric.size[0] != self.target.D:
+            raise ArgumentError(capi.ERR_ARGUMENT, f"metric dimension {self.metric.size[0]} != target dimension {self.target.D}")
+
+
+# ------------------------------------------------------------------------------------------------
+# integrators (src/integrator.jl:71-209)
+# ------------------------------------------------------------------------------------------------
+class AbstractLeapfrog:
+    kind = capi.INTEGRATOR_LEAPFROG
+    param = 0.0
+
+    def nom_step_size(self):
+        return self.eps
+
+
+class Leapfrog(AbstractLeapfrog):
+    """src/integrator.jl:71-74; ϵ scalar or per-chain vector"""
+
+    def __init__(self, eps):
+        self.eps = np.asarray(eps, dtype=np.float64) if np.ndim(eps) else float(eps)
+
+
+class JitteredLeapfrog(AbstractLeapfrog):
+    """src/integrator.jl:112-156"""
+    kind = capi.INTEGRATOR_JITTERED
+
+    def __init__(self, eps0, jitter):
+        self.eps = np.asarray(eps0, dtype=np.float64) if np.ndim(eps0) else float(eps0)
+        self.param = float(jitter)
+
+
+class TemperedLeapfrog(AbstractLeapfrog):
+    """src/integrator.jl:174-209"""
+    kind = capi.INTEGRATOR_TEMPERED
+
+    def __init__(self, eps, alpha):
+        self.eps = np.asarray(eps, dtype=np.float64) if np.ndim(eps) else float(eps)
+        self.param = float(alpha)
+
+
+# ------------------------------------------------------------------------------------------------
+# trajectories / kernels (src/trajectory.jl:62-254, :414-449)
+# ------------------------------------------------------------------------------------------------
+class EndPointTS:
+    code = capi.TS_ENDPOINT
+
+
+class MultinomialTS:
+    code = capi.TS_MULTINOMIAL
+
+
+class SliceTS:
+    code = capi.TS_SLICE
+
+
+@dataclass
+class FixedNSteps:
+    L: int
+
+
+@dataclass
+class FixedIntegrationTime:
+    lam: float
+
+
+@dataclass
+class ClassicNoUTurn:
+    max_depth: int = 10
+    delta_max: float = 1000.0
+    code = capi.TC_CLASSIC
+
+
+@dataclass
+class GeneralisedNoUTurn:
+    max_depth: int = 10
+    delta_max: float = 1000.0
+    code = capi.TC_GENERALISED
+
+
+@dataclass
+class StrictGeneralisedNoUTurn:
+    max_depth: int = 10
+    delta_max: float = 1000.0
+    code = capi.TC_STRICT
+
+
+_DYNAMIC = (ClassicNoUTurn, GeneralisedNoUTurn, StrictGeneralisedNoUTurn)
+
+
+@dataclass
+class Trajectory:
+    """`Trajectory{TS}(integrator, termination_criterion)` (src/trajectory.jl:213-224)"""
+    TS: type
+    integrator: AbstractLeapfrog
+    termination_criterion: object
+
+
+class FullMomentumRefreshment:
+    alpha = 0.0
+
+
+@dataclass
+class PartialMomentumRefreshment:
+    alpha: float
+
+
+class HMCKernel:
+    """src/trajectory.jl:249-254"""
+
+    def __init__(self, *args):
+        if len(args) == 1:
+            self.refreshment, self.tau = FullMomentumRefreshment(), args[0]
+        else:
+            self.refreshment, self.tau = args
+
+    def cfg(self) -> capi.KernelCfg:
+        tc = self.tau.termination_criterion
+        k = capi.KernelCfg()
+        k.sampler = self.tau.TS.code
+        k.refresh_alpha = float(self.refreshment.alpha)
+        if isinstance(tc, _DYNAMIC):
+            k.nuts, k.criterion, k.max_depth, k.delta_max = 1, tc.code, tc.max_depth, tc.delta_max
+        elif isinstance(tc, FixedNSteps):
+            k.nuts, k.L, k.lambda_ = 0, tc.L, 0.0
+        elif isinstance(tc, FixedIntegrationTime):
+            k.nuts, k.L, k.lambda_ = 0, 0, tc.lam
+        else:
+            raise ArgumentError(capi.ERR_ARGUMENT, f"unknown termination criterion {tc!r}")
+        return k
+
+
+# ------------------------------------------------------------------------------------------------
+# adaptors (src/adaptation/*.jl)
+# ------------------------------------------------------------------------------------------------
+class NoAdaptation:
+    code = capi.ADAPT_NONE
+    delta = 0.8
+
+
+@dataclass
+class StepSizeAdaptor:
+    """StepSizeAdaptor(δ, integrator | ϵ) → NesterovDualAveraging (src/AdvancedHMC.jl:105-110)"""
+    delta: float
+    integrator: object = None
+    code = capi.ADAPT_STEPSIZE
+
+
+@dataclass
+class MassMatrixAdaptor:
+    """MassMatrixAdaptor(metric) → UnitMassMatrix / WelfordVar (src/AdvancedHMC.jl:112-118)"""
+    metric: AbstractMetric
+    code = capi.ADAPT_MASSMATRIX
+    delta = 0.8
+
+
+@dataclass
+class NaiveHMCAdaptor:
+    """src/adaptation/Adaptation.jl:41-64"""
+    pc: MassMatrixAdaptor
+    ssa: StepSizeAdaptor
+    code = capi.ADAPT_NAIVE
+
+    @property
+    def delta(self):
+        return self.ssa.delta
+
+
+@dataclass
+class StanHMCAdaptor:
+    """src/adaptation/stan_adaptor.jl:52-103"""
+    pc: MassMatrixAdaptor
+    ssa: StepSizeAdaptor
+    init_buffer: int = 75
+    term_buffer: int = 50
+    window_size: int = 25
+    code = capi.ADAPT_STAN
+
+    @property
+    def delta(self):
+        return self.ssa.delta
+
+
+def stan_windows(n_adapts, init_buffer=75, term_buffer=50, window_size=25, lib: Optional[capi.CLib] = None):
+    """initialize!(::StanHMCAdaptorState, ...) (src/adaptation/stan_adaptor.jl:13-50).
+    Returns (window_start, window_end, window_splits)."""
+    lib = lib or capi.load_hip_library()
+    ws, we, ns = C.c_int64(), C.c_int64(), C.c_int32()
+    splits = (C.c_int64 * 64)()
+    lib.check(lib.dll.ahmc_stan_windows(init_buffer, term_buffer, window_size, n_adapts, C.byref(ws), C.byref(we),
+                                        splits, 64, C.byref(ns)))
+    return ws.value, we.value, [splits[i] for i in range(ns.value)]
+
+
+# ------------------------------------------------------------------------------------------------
+# phase point / transition carriers (src/hamiltonian.jl:88-107, src/trajectory.jl:18-23)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class DualValue:
+    value: np.ndarray
+    gradient: np.ndarray
+
+
+@dataclass
+class PhasePoint:
+    theta: np.ndarray
+    r: np.ndarray
+    lp: DualValue  # ℓπ: value = log density, gradient = -∇ℓπ (src/hamiltonian.jl:45-48)
+    lk: DualValue  # ℓκ: value = -K(r); gradient (∂H∂r) is recomputed on demand
+
+
+@dataclass
+class Transition:
+    z: PhasePoint
+    stat: dict = field(default_factory=dict)
+
+
+def neg_energy(z: PhasePoint):
+    return z.lp.value + z.lk.value
+
+
+def energy(z: PhasePoint):
+    return -neg_energy(z)
+
+
+# ------------------------------------------------------------------------------------------------
+# Engine: one C context
+# ------------------------------------------------------------------------------------------------
+class Engine:
+    """Binds a Hamiltonian and N chains to one `ahmc_ctx`.
+
+    `lib=None` opens the HIP engine (and fails if it is not built).  `stream` is an optional
+    hipStream_t (e.g. `torch.cuda.Stream().cuda_stream`) for HIP-event timing."""
+
+    def __init__(self, h: Hamiltonian, n_chains: int, dtype=np.float64, rng=0, lib: Optional[capi.CLib] = None,
+                 device: int = 0, stream: int = 0):
+        self.lib = lib or capi.load_hip_library()
+        self.h = h
+        self.D, self.N = int(h.target.D), int(n_chains)
+        self.dtype = np.dtype(dtype)
+        self._ctx = C.c_void_p()
+        self.lib.check(self.lib.dll.ahmc_create(device, capi.dtype_code(self.dtype), self.D, self.N,
+                                                C.c_void_p(stream or None), C.byref(self._ctx)))
+        self._external = isinstance(h.target, ExternalTarget)
+        self.set_target(h.target)
+        self.set_metric(h.metric)
+        self.seed(rng)
+
+    # -- plumbing --
+    def _call(self, name, *args):
+        self.lib.check(getattr(self.lib.dll, name)(self._ctx, *args), self._ctx)
+
+    def close(self):
+        if self._ctx:
+            self.lib.dll.ahmc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _mat(self, a, name):
+        a = np.asarray(a)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        if a.shape != (self.D, self.N):
+            raise ArgumentError(capi.ERR_ARGUMENT, f"{name} has size {a.shape}, expected {(self.D, self.N)}")
+        return np.asfortranarray(a, dtype=self.dtype)
+
+    def _out(self, vec=False):
+        return np.empty((self.N,) if vec else (self.D, self.N), dtype=self.dtype, order="F")
+
+    def _shape_out(self, a):
+        return a[:, 0].copy() if (self.N == 1 and getattr(self, "_vector_mode", False)) else a
+
+    # -- configuration --
+    def set_target(self, target):
+        p = None if target.params is None else np.ascontiguousarray(target.params, dtype=self.dtype)
+        self._call("ahmc_set_target", target.kind, capi.as_ptr(p), 0 if p is None else p.size)
+
+    def set_metric(self, metric):
+        if metric.kind == capi.METRIC_UNIT:
+            self._call("ahmc_set_metric", metric.kind, None, 0)
+        else:
+            M = np.asfortranarray(metric.Minv, dtype=self.dtype)
+            if metric.kind == capi.METRIC_DIAG and M.shape[0] != self.D:
+                raise ArgumentError(capi.ERR_ARGUMENT, f"AxesMismatch: M⁻¹ has size {M.shape} but r has first axis {self.D}")
+            self._call("ahmc_set_metric", metric.kind, capi.as_ptr(M), M.size)
+        self.metric_kind = metric.kind
+
+    def get_metric(self):
+        if self.metric_kind == capi.METRIC_UNIT:
+            return None
+        # size is whatever was set last (D, D*N or D*D): probe via a D*N then D buffer
+        for shape in ((self.D, self.N), (self.D,), (self.D, self.D)):
+            out = np.empty(shape, dtype=self.dtype, order="F")
+            code = self.lib.dll.ahmc_get_metric(self._ctx, capi.as_ptr(out), out.size)
+            if code == capi.OK:
+                return out
+        self.lib.check(code, self._ctx)
+
+    def set_integrator(self, lf: AbstractLeapfrog):
+        eps = np.atleast_1d(np.asarray(lf.eps, dtype=self.dtype))
+        if eps.size not in (1, self.N):
+            raise ArgumentError(capi.ERR_ARGUMENT, f"step size vector has length {eps.size}, expected 1 or {self.N}")
+        self._call("ahmc_set_stepsize", capi.as_ptr(eps), eps.size)
+        self._call("ahmc_set_integrator", lf.kind, float(lf.param))
+
+    def get_stepsize(self):
+        out = self._out(vec=True)
+        self._call("ahmc_get_stepsize", capi.as_ptr(out))
+        return out
+
+    def seed(self, rng, iteration=None):
+        spec, stride = _rng_spec(rng, self.N)
+        self._call("ahmc_seed", spec.seed, spec.chain_offset, stride, spec.iteration if iteration is None else iteration)
+
+    # -- phase point --
+    def set_position(self, theta, r=None):
+        """phasepoint(h, θ, r) (src/hamiltonian.jl:115-119)"""
+        self._vector_mode = np.ndim(theta) == 1
+        th = self._mat(theta, "θ")
+        if self._external:
+            lp, grad = self.h.target.fn(th)
+            rr = self._mat(r, "r") if r is not None else np.zeros_like(th)
+            self._call("ahmc_set_phasepoint", capi.as_ptr(th), capi.as_ptr(rr),
+                       capi.as_ptr(np.ascontiguousarray(lp, dtype=self.dtype)),
+                       capi.as_ptr(np.asfortranarray(-np.asarray(grad), dtype=self.dtype)))
+            return
+        rr = None if r is None else self._mat(r, "r")
+        self._call("ahmc_set_position", capi.as_ptr(th), capi.as_ptr(rr))
+
+    def phasepoint(self) -> PhasePoint:
+        th, r, g = self._out(), self._out(), self._out()
+        lp, lk = self._out(True), self._out(True)
+        self._call("ahmc_get_phasepoint", capi.as_ptr(th), capi.as_ptr(r), capi.as_ptr(lp), capi.as_ptr(g), capi.as_ptr(lk))
+        if self.N == 1 and getattr(self, "_vector_mode", False):
+            return PhasePoint(th[:, 0], r[:, 0], DualValue(lp[0], g[:, 0]), DualValue(lk[0], None))
+        return PhasePoint(th, r, DualValue(lp, g), DualValue(lk, None))
+
+    def theta(self):
+        th = self._out()
+        self._call("ahmc_get_phasepoint", capi.as_ptr(th), None, None, None, None)
+        return self._shape_out(th)
+
+    def refresh(self, refreshment=None):
+        """refresh(rng, refreshment, h, z) (src/hamiltonian.jl:213-254)"""
+        self._call("ahmc_refresh_momentum", float(getattr(refreshment, "alpha", 0.0)))
+
+    def step(self, n_steps=1):
+        """step(lf, h, z, n_steps) (src/integrator.jl:216-265)"""
+        if self._external:
+            n = abs(int(n_steps))
+            fwd = 1 if n_steps > 0 else 0
+            theta_view = self._out()
+            for i in range(1, n + 1):
+                self._call("ahmc_lf_pre", fwd, i, n)
+                self._call("ahmc_get_phasepoint", capi.as_ptr(theta_view), None, None, None, None)
+                lp, grad = self.h.target.fn(theta_view)
+                self._call("ahmc_lf_post", fwd, i, n, capi.as_ptr(np.ascontiguousarray(lp, dtype=self.dtype)),
+                           capi.as_ptr(np.asfortranarray(-np.asarray(grad), dtype=self.dtype)))
+            return
+        self._call("ahmc_leapfrog", int(n_steps))
+
+    # -- transitions --
+    def transition(self, kernel: HMCKernel):
+        """transition(rng, h, κ, z) (src/sampler.jl:48-58)"""
+        k = kernel.cfg()
+        if k.refresh_alpha != 0.0:
+            raise capi.UnsupportedError(capi.ERR_UNSUPPORTED, "PartialMomentumRefreshment runs through Engine.sample")
+        if k.nuts:
+            self._call("ahmc_nuts_transition", k.max_depth, k.delta_max, k.criterion, k.sampler)
+        else:
+            self._call("ahmc_hmc_transition", k.L, k.lambda_, k.sampler)
+
+    def stats(self, fields: Optional[Sequence[str]] = None) -> dict:
+        out = {}
+        for name in fields or capi.STAT_FIELDS:
+            fid, is_int = capi.STAT_FIELDS[name]
+            buf = np.empty(self.N, dtype=np.int32 if is_int else self.dtype)
+            self._call("ahmc_get_stat", fid, capi.as_ptr(buf))
+            out[name] = buf
+        for b in ("is_accept", "numerical_error"):
+            if b in out:
+                out[b] = out[b].astype(bool)
+        return out
+
+    def find_good_stepsize(self, initial_step_size=0.1, max_n_iters=100):
+        """find_good_stepsize(rng, h, θ) per chain (src/trajectory.jl:768-837)"""
+        self._call("ahmc_find_good_stepsize", float(initial_step_size), int(max_n_iters))
+        return self.get_stepsize()
+
+    # -- adaptation --
+    def adaptor_init(self, adaptor):
+        ib, tb, ws = (getattr(adaptor, "init_buffer", 75), getattr(adaptor, "term_buffer", 50),
+                      getattr(adaptor, "window_size", 25))
+        self._call("ahmc_adaptor_init", adaptor.code, float(adaptor.delta), ib, tb, ws)
+
+    def adapt(self, i, n_adapts):
+        self._call("ahmc_adapt", int(i), int(n_adapts))
+
+    # -- bulk driver --
+    def run(self, kernel: HMCKernel, n_samples, n_adapts=0, drop_warmup=False, samples_out=None):
+        """The whole `sample` loop enqueued by one C call (no host synchronisation inside)."""
+        k = kernel.cfg()
+        self._call("ahmc_sample", C.byref(k), int(n_samples), int(n_adapts), 1 if drop_warmup else 0,
+                   capi.as_ptr(samples_out))
+
+    def sync(self):
+        self._call("ahmc_sync")
+
+    @property
+    def stream(self):
+        return self.lib.dll.ahmc_stream(self._ctx)
+
+    def accum(self, moments=True):
+        tot, ntr, ndiv = C.c_int64(), C.c_int64(), C.c_int64()
+        s1 = self._out() if moments else None
+        s2 = self._out() if moments else None
+        self._call("ahmc_get_accum", C.byref(tot), C.byref(ntr), C.byref(ndiv), capi.as_ptr(s1), capi.as_ptr(s2))
+        return {"total_n_steps": tot.value, "n_transitions": ntr.value, "n_divergent": ndiv.value,
+                "sum_theta": s1, "sumsq_theta": s2}
+
+    def reset_accum(self):
+        self._call("ahmc_reset_accum")
+
+
+# ------------------------------------------------------------------------------------------------
+# free functions with the reference's names
+# ------------------------------------------------------------------------------------------------
+def find_good_stepsize(rng, h: Hamiltonian, theta, initial_step_size=0.1, max_n_iters=100, dtype=np.float64,
+                       lib=None):
+    """src/trajectory.jl:768-852.  θ (D,) → scalar ϵ; θ (D,N) → per-chain ϵ (N,)"""
+    theta = np.asarray(theta)
+    N = 1 if theta.ndim == 1 else theta.shape[1]
+    eng = Engine(h, N, dtype=dtype, rng=rng, lib=lib)
+    try:
+        eng.set_position(theta)
+        eps = eng.find_good_stepsize(initial_step_size, max_n_iters)
+    finally:
+        eng.close()
+    return float(eps[0]) if theta.ndim == 1 else eps
+
+
+def sample(rng, h: Hamiltonian, kernel: HMCKernel, theta, n_samples: int, adaptor=None, n_adapts: Optional[int] = None,
+           drop_warmup=False, verbose=False, progress=False, dtype=None, lib=None, device=0):
+    """sample(rng, h, κ, θ, n_samples, adaptor, n_adapts; drop_warmup) (src/sampler.jl:159-248).
+
+    Returns `(θs, stats)`: a list of (D, N) arrays (or (D,) for vector θ) and a list of stat
+    dicts with the reference's field names plus `is_adapt` (:193).  One transition + adapt! per
+    iteration is issued through the C ABI, exactly the loop of :182-228."""
+    adaptor = adaptor if adaptor is not None else NoAdaptation()
+    if n_adapts is None:
+        n_adapts = min(n_samples // 10, 1000)
+    if drop_warmup and isinstance(adaptor, NoAdaptation):
+        raise AssertionError("Cannot drop warmup samples if there is no adaptation phase.")  # :172
+    theta = np.asarray(theta)
+    dtype = dtype or (theta.dtype if theta.dtype in (np.float32, np.float64) else np.float64)
+    N = 1 if theta.ndim == 1 else theta.shape[1]
+    eng = Engine(h, N, dtype=dtype, rng=rng, lib=lib, device=device)
+    try:
+        eng.set_integrator(kernel.tau.integrator)
+        eng.set_position(theta)  # sample_init (:36-46)
+        eng.adaptor_init(adaptor)
+        k = kernel.cfg()
+        thetas, stats = [], []
+        one = capi.KernelCfg.from_buffer_copy(k)
+        for i in range(1, n_samples + 1):
+            eng._call("ahmc_sample", C.byref(one), 1, 0, 0, None)  # transition(rng, h, κ, t.z) (:184)
+            st = eng.stats()
+            isadapted = i <= n_adapts and not isinstance(adaptor, NoAdaptation)
+            eng.adapt(i, n_adapts)
+            st["is_adapt"] = isadapted
+            if not drop_warmup or i > n_adapts:
+                thetas.append(eng.theta())
+                stats.append(st)
+        return thetas, stats
+    finally:
+        eng.close()
+
+
+def EBFMI(energies):
+    """src/diagnosis.jl:1-3; energies: sequence over iterations of scalars or (N,) arrays"""
+    E = np.asarray(energies, dtype=np.float64)
+    num = np.mean(np.diff(E, axis=0) ** 2, axis=0)
+    return num / np.var(E, axis=0, ddof=1)

@@ -1,0 +1,253 @@
+/*
+ * ahmc_hip.h — C ABI of the MI355X-native chain-batched HMC/NUTS trajectory engine.
+ *
+ * This header is the drop-in boundary.  The reference (AdvancedHMC.jl) has no
+ * FFI: its boundary is Julia multiple dispatch.  Every entry point below therefore names the
+ * reference method it stands in for (path:line under the AdvancedHMC.jl checkout); the Julia
+ * package extension that `ccall`s them is julia/AdvancedHMCMI355XExt.jl.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns an
+ *     int32 status (AHMC_OK == 0); the message for the last failure on a context is
+ *     ahmc_last_error(ctx) (ahmc_last_error(NULL) for a failed ahmc_create).  Nothing throws
+ *     or aborts across the ABI.  Numerical trouble is never an error: as in the reference it
+ *     becomes -Inf energies, a rejection and a stat flag (src/hamiltonian.jl:95-104).
+ *   - Arrays are column-major (D, N) exactly as a Julia Matrix{T} holds them: chain c owns the
+ *     contiguous slice [c*D, (c+1)*D)  (src/integrator.jl:226-227, test/sampler-vec.jl:11).
+ *     Per-chain scalars are length-N vectors.  The element type T is fixed at ahmc_create.
+ *   - A `const void*`/`void*` array argument may be a host pointer or a device pointer of the
+ *     context's device (unified addressing decides the copy direction).  The caller owns every
+ *     pointer it passes; the library owns the context, its device state and its scratch.
+ *   - A context is bound to one device and one stream and is not thread-safe; calls are
+ *     asynchronous on the stream until ahmc_sync / any get_* (which synchronise).
+ *   - Sign convention of the cached gradient follows the reference: `grad` holds
+ *     -∇ℓπ(θ) = ∂H/∂θ  (src/hamiltonian.jl:45-48).  `lk` holds ℓκ = -K(r).
+ *
+ * The same ABI is implemented twice: advancedhmc.jl_amd/csrc (HIP, gfx950 — the product) and
+ * oracle/ (scalar CPU restatement of the reference — test infrastructure only).
+ */
+#ifndef AHMC_HIP_H
+#define AHMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AHMC_ABI_VERSION 1
+
+typedef struct ahmc_ctx ahmc_ctx;
+
+/* status codes */
+enum {
+  AHMC_OK = 0,
+  AHMC_ERR_ARGUMENT = 1,    /* Julia ArgumentError / @argcheck  (src/hamiltonian.jl:55-57,94) */
+  AHMC_ERR_UNSUPPORTED = 2, /* combination the engine has no kernel for                      */
+  AHMC_ERR_RUNTIME = 3,     /* HIP runtime failure (message carries hipGetErrorString)        */
+  AHMC_ERR_STATE = 4        /* call order violated (e.g. transition before set_position)      */
+};
+
+/* element type: Float32 / Float64 (src/AdvancedHMC.jl:37 default Float64) */
+enum { AHMC_F32 = 0, AHMC_F64 = 1 };
+
+/* metric: src/metric.jl:17-35 (Unit), :52-72 (Diag), :89-120 (Dense) */
+enum { AHMC_METRIC_UNIT = 0, AHMC_METRIC_DIAG = 1, AHMC_METRIC_DENSE = 2 };
+
+/* built-in log-density families evaluated inside the kernels (SURVEY.md §8d synthetic inputs);
+ * AHMC_TARGET_EXTERNAL = caller computes (ℓπ, ∇ℓπ) between ahmc_lf_pre and ahmc_lf_post, i.e.
+ * the `h.∂ℓπ∂θ(θ)` callback of src/hamiltonian.jl:45-48 stays on the Julia side.             */
+enum {
+  AHMC_TARGET_ISO_GAUSS = 0,  /* ℓπ = Σ -(log2π + θ²)/2           test/common.jl:40-44, m=0,s=1 */
+  AHMC_TARGET_DIAG_GAUSS = 1, /* params: m[D], s[D]                test/common.jl:35-77           */
+  AHMC_TARGET_FUNNEL = 2,     /* θ1~N(0,3²), θi~N(0,e^{θ1})        research/notebooks/geweke_test.ipynb cell 4 */
+  AHMC_TARGET_HIER_GAUSS = 3, /* θ=(μ,logτ,x..): μ~N(0,1), logτ~N(0,1), xi~N(μ,τ²)  SURVEY §8d cfg5 */
+  AHMC_TARGET_DENSE_GAUSS = 4,/* ℓπ = -½ θᵀPθ, params: P (D,D) column-major precision  SURVEY §8d cfg4 */
+  AHMC_TARGET_EXTERNAL = 5
+};
+
+/* integrator: src/integrator.jl:71-74 (Leapfrog), :112-156 (Jittered), :174-209 (Tempered) */
+enum { AHMC_INTEGRATOR_LEAPFROG = 0, AHMC_INTEGRATOR_JITTERED = 1, AHMC_INTEGRATOR_TEMPERED = 2 };
+
+/* trajectory sampler: src/trajectory.jl:90 (EndPointTS), :102-119 (SliceTS), :129-136 (MultinomialTS) */
+enum { AHMC_TS_ENDPOINT = 0, AHMC_TS_MULTINOMIAL = 1, AHMC_TS_SLICE = 2 };
+
+/* dynamic termination criterion: src/trajectory.jl:414-449 */
+enum { AHMC_TC_CLASSIC = 0, AHMC_TC_GENERALISED = 1, AHMC_TC_STRICT = 2 };
+
+/* per-chain statistics of the last transition; names follow the reference's stat NamedTuple
+ * (static: src/trajectory.jl:286-298; NUTS: :726-739; integrator: src/integrator.jl:58).
+ * T-typed fields come back as T[N], integer fields as int32[N].                             */
+enum {
+  AHMC_STAT_N_STEPS = 0,                      /* int32 */
+  AHMC_STAT_IS_ACCEPT = 1,                    /* int32 (0/1) */
+  AHMC_STAT_ACCEPTANCE_RATE = 2,              /* T */
+  AHMC_STAT_LOG_DENSITY = 3,                  /* T */
+  AHMC_STAT_HAMILTONIAN_ENERGY = 4,           /* T */
+  AHMC_STAT_HAMILTONIAN_ENERGY_ERROR = 5,     /* T */
+  AHMC_STAT_MAX_HAMILTONIAN_ENERGY_ERROR = 6, /* T  (NUTS only) */
+  AHMC_STAT_TREE_DEPTH = 7,                   /* int32 (NUTS only) */
+  AHMC_STAT_NUMERICAL_ERROR = 8,              /* int32 (0/1) */
+  AHMC_STAT_STEP_SIZE = 9,                    /* T */
+  AHMC_STAT_NOM_STEP_SIZE = 10,               /* T */
+  AHMC_STAT__COUNT = 11
+};
+
+/* adaptor kinds: src/adaptation/Adaptation.jl:41-64 (Naive), stan_adaptor.jl (Stan),
+ * stepsize.jl (StepSizeAdaptor = NesterovDualAveraging), massmatrix.jl (WelfordVar)         */
+enum {
+  AHMC_ADAPT_NONE = 0,
+  AHMC_ADAPT_STEPSIZE = 1,   /* StepSizeAdaptor(δ, integrator)                          */
+  AHMC_ADAPT_MASSMATRIX = 2, /* MassMatrixAdaptor(metric) → WelfordVar, updated every step */
+  AHMC_ADAPT_NAIVE = 3,      /* NaiveHMCAdaptor(pc, ssa)                                */
+  AHMC_ADAPT_STAN = 4        /* StanHMCAdaptor(pc, ssa; 75/50/25)                       */
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* lifetime                                                                                   */
+
+/* Allocate a context for N chains of dimension D on `device`.  `stream` is a hipStream_t to
+ * enqueue on (NULL → the library creates its own).  Replaces the implicit allocation done by
+ * sample_init / resize (src/sampler.jl:25-46).                                               */
+int32_t ahmc_create(int32_t device, int32_t dtype, int64_t D, int64_t N, void* stream,
+                    ahmc_ctx** out);
+int32_t ahmc_destroy(ahmc_ctx* ctx);
+const char* ahmc_last_error(const ahmc_ctx* ctx);
+int32_t ahmc_abi_version(void);
+/* "hip:gfx950" for the product library, "cpu-oracle" for oracle/ */
+const char* ahmc_backend(void);
+int32_t ahmc_sync(ahmc_ctx* ctx);
+/* the hipStream_t the context enqueues on (for HIP-event timing by the caller) */
+void* ahmc_stream(ahmc_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------ */
+/* configuration (the fields of Hamiltonian / metric / integrator structs)                    */
+
+/* Hamiltonian.ℓπ/∂ℓπ∂θ (src/hamiltonian.jl:1-20): choose a built-in family.  `params` holds
+ * n_params elements of T (layout per family above) or NULL.                                  */
+int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params);
+
+/* metric constructors + renew (src/metric.jl:31,61-69,104-117).  Unit: Minv ignored.
+ * Diag: n == D (one M⁻¹ shared by all chains) or n == D*N (per-chain (D,N), F5 in SURVEY).
+ * Dense: n == D*D (shared).  sqrt / Cholesky factors are recomputed here, as `renew` does.   */
+int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n);
+int32_t ahmc_get_metric(ahmc_ctx* ctx, void* Minv_out, int64_t n);
+
+/* Leapfrog(ϵ) with scalar (n==1) or per-chain (n==N) nominal step size
+ * (src/integrator.jl:71-74, update_nom_step_size :60).                                       */
+int32_t ahmc_set_stepsize(ahmc_ctx* ctx, const void* eps, int64_t n);
+int32_t ahmc_get_stepsize(ahmc_ctx* ctx, void* eps_out /* T[N] */);
+/* JitteredLeapfrog(ϵ0, jitter) / TemperedLeapfrog(ϵ, α): param = jitter or α               */
+int32_t ahmc_set_integrator(ahmc_ctx* ctx, int32_t kind, double param);
+
+/* Counter-based RNG (Philox4x32-10): key = seed, stream of local chain c =
+ * chain_offset + chain_stride*c, per-transition counter = `iteration` (advanced by every
+ * *_transition call).  Replaces the `rng` argument threaded through src/sampler.jl:159 etc.;
+ * "identical seeds" (north_star) is defined on this stream, which the oracle shares
+ * (SURVEY.md §8c(1)).  chain_stride = 1: independent chains (one shared `rng`, or a shard of a
+ * multi-GPU run with chain_offset = first global chain).  chain_stride = 0: every chain draws
+ * the same variates — the "vector of identically seeded RNGs" case of
+ * test/sampler-vec.jl:69-80 and src/utilities.jl:12-23.                                      */
+int32_t ahmc_seed(ahmc_ctx* ctx, uint64_t seed, uint64_t chain_offset, uint64_t chain_stride,
+                  uint64_t iteration);
+
+/* ------------------------------------------------------------------------------------------ */
+/* phase point (src/hamiltonian.jl:88-139)                                                    */
+
+/* phasepoint(h, θ, r): set θ (and r if non-NULL, else r = 0) and fill the caches ℓπ, -∇ℓπ, ℓκ
+ * with the built-in target; non-finite ℓπ/ℓκ values become -Inf (:95-104).                  */
+int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r);
+/* PhasePoint(θ, r, ℓπ, ℓκ) with caller-supplied caches (external target): lp T[N], grad (D,N)
+ * holds -∇ℓπ.                                                                                */
+int32_t ahmc_set_phasepoint(ahmc_ctx* ctx, const void* theta, const void* r, const void* lp,
+                            const void* grad);
+/* any output may be NULL.  theta,r,grad: (D,N); lp,lk: T[N]                                  */
+int32_t ahmc_get_phasepoint(ahmc_ctx* ctx, void* theta, void* r, void* lp, void* grad, void* lk);
+
+/* refresh(rng, FullMomentumRefreshment(), h, z) (src/hamiltonian.jl:213-220) with
+ * rand_momentum (src/metric.jl:290-320); alpha in (0,1) selects PartialMomentumRefreshment(α)
+ * (:243-254); alpha == 0 → full.  Uses and does NOT advance the iteration counter.           */
+int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha);
+
+/* step(lf, h, z, n_steps; fwd = n_steps > 0) (src/integrator.jl:216-265) with the built-in
+ * target, all steps fused in one launch; each chain stops at its own first non-finite point.  */
+int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps);
+
+/* external-gradient split step (the two halves of src/integrator.jl:237-243 around the
+ * ∂H∂θ(h, θ) callback at :241).  lf_pre: temper, r -= ϵ/2·g, θ += ϵ·M⁻¹r.  The caller then
+ * evaluates (ℓπ, ∇ℓπ) at ahmc_theta_ptr() and hands them to lf_post: r -= ϵ/2·g, temper,
+ * ℓκ, non-finite → -Inf.  `fwd` = 0 integrates backwards.                                    */
+int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps);
+int32_t ahmc_lf_post(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps, const void* lp,
+                     const void* grad_neg /* -∇ℓπ (D,N) */);
+/* device pointer of the context's θ (D,N) for zero-copy gradient evaluation by the caller    */
+void* ahmc_theta_ptr(ahmc_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------ */
+/* transitions (src/sampler.jl:48-58 = jitter → refresh → trajectory transition)             */
+
+/* Static HMC: transition(rng, h, HMCKernel(Trajectory{TS}(lf, FixedNSteps(L))), z)
+ * (src/trajectory.jl:271-300, sample_phasepoint :336-390, mh_accept_ratio :855-880,
+ * accept_phasepoint! :303-332).  TS ∈ {ENDPOINT, MULTINOMIAL}.  lambda > 0 selects
+ * FixedIntegrationTime(λ): L = max(1, floor(λ/ϵ_nominal)) (:240-243; needs scalar ϵ).       */
+int32_t ahmc_hmc_transition(ahmc_ctx* ctx, int64_t L, double lambda, int32_t sampler);
+
+/* NUTS: transition(rng, h, HMCKernel(Trajectory{TS}(lf, TC(max_depth, Δ_max))), z) per chain
+ * (src/trajectory.jl:677-742, build_tree :626-675), run for all N chains at once.            */
+int32_t ahmc_nuts_transition(ahmc_ctx* ctx, int32_t max_depth, double delta_max,
+                             int32_t criterion, int32_t sampler);
+
+/* statistics of the last transition; `out` has N elements of the field's type               */
+int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out);
+
+/* find_good_stepsize(rng, h, θ) (src/trajectory.jl:768-837) for every chain independently;
+ * result becomes the per-chain nominal step size.                                            */
+int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters);
+
+/* ------------------------------------------------------------------------------------------ */
+/* adaptation (src/adaptation/{stepsize,massmatrix,stan_adaptor}.jl, glue src/sampler.jl:3-22,72-90)                           */
+
+/* construct the adaptor: kind above; δ target acceptance; (init_buffer, term_buffer,
+ * window_size) = (75, 50, 25) for Stan (stan_adaptor.jl:94-103).                             */
+int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t init_buffer,
+                          int32_t term_buffer, int32_t window_size);
+/* adapt!(h, κ, adaptor, i, n_adapts, z, α) (src/sampler.jl:72-90): uses the last transition's
+ * acceptance_rate and position; updates metric and nominal step size in place.               */
+int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts);
+/* Stan window schedule for n_adapts (stan_adaptor.jl:13-50): writes up to cap split points,
+ * returns their count in *n_splits and the window start/end.  Pure host logic.               */
+int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size,
+                          int64_t n_adapts, int64_t* window_start, int64_t* window_end,
+                          int64_t* splits, int32_t cap, int32_t* n_splits);
+
+/* ------------------------------------------------------------------------------------------ */
+/* driver: sample(rng, h, κ, θ, n_samples, adaptor, n_adapts) (src/sampler.jl:159-248)        */
+
+typedef struct {
+  int32_t nuts;          /* 1: NUTS, 0: static HMC                                        */
+  int32_t sampler;       /* AHMC_TS_*                                                      */
+  int32_t criterion;     /* AHMC_TC_* (NUTS)                                               */
+  int32_t max_depth;     /* NUTS (default 10)                                              */
+  double delta_max;      /* NUTS (default 1000)                                            */
+  int64_t L;             /* static HMC                                                     */
+  double lambda;         /* static HMC FixedIntegrationTime, 0 = unused                    */
+  double refresh_alpha;  /* 0 = FullMomentumRefreshment                                    */
+} ahmc_kernel_cfg;
+
+/* Runs n_samples transitions (+ adapt! for i <= n_adapts) without host synchronisation.
+ * samples_out: NULL, or device/host buffer of (D, N, n_keep) receiving θ after each kept
+ * transition (n_keep = n_samples - (drop_warmup ? n_adapts : 0)).
+ * Accumulators (see ahmc_get_accum) are reset at the first kept transition.                  */
+int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples,
+                    int64_t n_adapts, int32_t drop_warmup, void* samples_out);
+
+/* running accumulators over kept transitions: Σ n_steps (all chains), number of kept
+ * transitions, number of divergent transitions, per-chain Σθ and Σθ² (D,N) (may be NULL)     */
+int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transitions,
+                       int64_t* n_divergent, void* sum_theta, void* sumsq_theta);
+int32_t ahmc_reset_accum(ahmc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AHMC_HIP_H */

@@ -1,0 +1,1595 @@
+// ahmc_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// A scalar, per-chain restatement of the hot path of AdvancedHMC.jl v0.8.6 (the reference,
+// pure Julia).  It implements the C ABI of include/ahmc_hip.h so the same host code can drive
+// either this checker or the HIP engine.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load it; the product package never does.
+//
+// PINNING.  Julia is absent from the build image, so the reference cannot be executed and no
+// reference-generated numeric vectors exist ("parity unpinned" at the random-variate level:
+// Julia's Xoshiro/ziggurat streams are replaced by the Philox4x32-10 streams defined below).
+// What IS pinned: every known-answer / identity test the reference's own suite holds for this
+// path is replayed against this file in tests/test_oracle_golden.py (fixtures in tests/golden/):
+// window schedule (test/adaptation.jl:148-151), temper schedule (test/integrator.jl:89-106),
+// BinaryTree combine (test/trajectory.jl:231-246), Termination table (:199-229), sampler
+// combine (:143-177), energy identities (test/hamiltonian.jl:54-79), U-turn equivalences
+// (test/trajectory.jl:249-325), step-loop ≡ step(n) (test/integrator.jl:17-32), the harmonic
+// oscillator bound (:108-153), seed self-consistency (test/sampler-vec.jl:69-80) and the
+// statistical checks (test/sampler-vec.jl:43,66).  A second, independent literal restatement in
+// Python (oracle/ahmc_ref.py) must agree with this file to 1e-12 (tests/test_oracle_cross.py).
+//
+// Each function cites the reference lines it follows (paths relative to the AdvancedHMC.jl
+// checkout).  Batch semantics: every chain is run through the reference's *scalar* (vector θ)
+// code path independently; where the reference's matrix mode couples chains (Q1: whole-batch
+// early exit, src/integrator.jl:252-258) the coupled behaviour is available via
+// ahmco_set_ref_compat(ctx, 1) for documentation tests and is off by default.
+
+#include "../include/ahmc_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// RNG specification shared with the HIP engine: Philox4x32-10 (Salmon et al., SC'11).
+// counter = (chain, iteration, purpose, slot), key = (seed_lo, seed_hi).
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { RNG_MOMENTUM = 0, RNG_TRANSITION = 1, RNG_JITTER = 2, RNG_FINDEPS = 3 };
+constexpr uint32_t COUPLED_CHAIN = 0xFFFFFFFFu;
+
+struct Philox4 {
+  uint32_t v[4];
+};
+
+inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                             uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  for (int round = 0; round < 10; ++round) {
+    uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+
+// 53-bit uniform in the open interval (0,1)
+inline double u53(uint32_t hi, uint32_t lo) {
+  uint64_t bits = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
+  return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+struct Rng {
+  uint32_t k0, k1, chain, iter;
+  Philox4 raw(uint32_t purpose, uint32_t slot) const {
+    return philox4x32_10(chain, iter, purpose, slot, k0, k1);
+  }
+  double uniform(uint32_t purpose, uint32_t slot) const {
+    Philox4 p = raw(purpose, slot);
+    return u53(p.v[0], p.v[1]);
+  }
+  bool boolean(uint32_t purpose, uint32_t slot) const { return (raw(purpose, slot).v[0] >> 31) != 0; }
+  double randexp(uint32_t purpose, uint32_t slot) const { return -std::log(uniform(purpose, slot)); }
+  // standard normal for element d: Box–Muller on pair d/2
+  double normal(uint32_t purpose, uint32_t d) const {
+    Philox4 p = raw(purpose, d >> 1);
+    double u1 = u53(p.v[0], p.v[1]), u2 = u53(p.v[2], p.v[3]);
+    double rad = std::sqrt(-2.0 * std::log(u1));
+    double ang = 6.283185307179586476925286766559 * u2;
+    return (d & 1) ? rad * std::sin(ang) : rad * std::cos(ang);
+  }
+};
+
+// Julia's min/max propagate NaN (Base.min(::Float64, ::Float64)); std::fmin does not.
+template <class T>
+inline T jl_min(T a, T b) {
+  if (std::isnan(a) || std::isnan(b)) return std::numeric_limits<T>::quiet_NaN();
+  return a < b ? a : b;
+}
+template <class T>
+inline T jl_max(T a, T b) {
+  if (std::isnan(a) || std::isnan(b)) return std::numeric_limits<T>::quiet_NaN();
+  return a > b ? a : b;
+}
+
+// LogExpFunctions.logaddexp (dependency, compat "0.3, 1", not vendored):
+//   Δ = x == y ? 0 : |x − y| ; max(x, y) + log1pexp(−Δ);  log1pexp(t) = log1p(exp(t)).
+// Used at src/trajectory.jl:192,198.  Pinned by test/trajectory.jl:170 (log 100 ⊕ log 150 = log 250).
+template <class T>
+inline T logaddexp(T x, T y) {
+  T d = (x == y) ? T(0) : std::abs(x - y);
+  return jl_max(x, y) + std::log1p(std::exp(-d));
+}
+
+template <class T>
+inline T neg_inf() {
+  return -std::numeric_limits<T>::infinity();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hamiltonian pieces for ONE chain
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Target {
+  int kind = AHMC_TARGET_ISO_GAUSS;
+  std::vector<T> params;
+};
+
+// (ℓπ(θ), ∇ℓπ(θ)) — the user callback `h.∂ℓπ∂θ(θ)` of src/hamiltonian.jl:46.  `g` receives +∇ℓπ.
+template <class T>
+T logdensity_and_gradient(const Target<T>& tg, int64_t D, const T* th, T* g) {
+  const T log2pi = T(1.8378770664093454835606594728112);
+  switch (tg.kind) {
+    case AHMC_TARGET_ISO_GAUSS: {
+      // test/common.jl:40-44 with m = 0, s = 1: Σ -(log 2π + θ²)/2 ; gradient m .- x (:52-56)
+      T v = 0;
+      for (int64_t d = 0; d < D; ++d) {
+        v += -(log2pi + th[d] * th[d]) / 2;
+        g[d] = -th[d];
+      }
+      return v;
+    }
+    case AHMC_TARGET_DIAG_GAUSS: {
+      // test/common.jl:40-44: -(log 2π + 2 log s + (m-x)²/s²)/2 ; exact gradient (m-x)/s²
+      // (the test fixture's own gradient `m .- x` is only right for s = 1: SURVEY §4)
+      const T* m = tg.params.data();
+      const T* s = m + D;
+      T v = 0;
+      for (int64_t d = 0; d < D; ++d) {
+        T diff = m[d] - th[d];
+        v += -(log2pi + 2 * std::log(s[d]) + diff * diff / (s[d] * s[d])) / 2;
+        g[d] = diff / (s[d] * s[d]);
+      }
+      return v;
+    }
+    case AHMC_TARGET_FUNNEL: {
+      // Neal's funnel, research/notebooks/geweke_test.ipynb cell 4:
+      //   θ1 ~ N(0, 3²);  θi ~ N(0, e^{θ1}) (variance e^{θ1}, i.e. std e^{θ1/2}), i = 2..D
+      T y = th[0];
+      T ss = 0;
+      for (int64_t d = 1; d < D; ++d) ss += th[d] * th[d];
+      T ey = std::exp(-y);  // 1/variance
+      T nm1 = T(D - 1);
+      T v = -(log2pi + 2 * std::log(T(3)) + y * y / 9) / 2 - nm1 * (log2pi + y) / 2 - ss * ey / 2;
+      g[0] = -y / 9 - nm1 / 2 + ss * ey / 2;
+      for (int64_t d = 1; d < D; ++d) g[d] = -th[d] * ey;
+      return v;
+    }
+    case AHMC_TARGET_HIER_GAUSS: {
+      // θ = (μ, log τ, x1..x_{D-2}); μ~N(0,1), logτ~N(0,1), xi~N(μ, τ²)
+      T mu = th[0], lt = th[1];
+      T itau2 = std::exp(-2 * lt);
+      T s1 = 0, s2 = 0;
+      for (int64_t d = 2; d < D; ++d) {
+        T df = th[d] - mu;
+        s1 += df;
+        s2 += df * df;
+      }
+      T n = T(D - 2);
+      T v = -(log2pi + mu * mu) / 2 - (log2pi + lt * lt) / 2 - n * (log2pi + 2 * lt) / 2 -
+            s2 * itau2 / 2;
+      g[0] = -mu + s1 * itau2;
+      g[1] = -lt - n + s2 * itau2;
+      for (int64_t d = 2; d < D; ++d) g[d] = -(th[d] - mu) * itau2;
+      return v;
+    }
+    case AHMC_TARGET_DENSE_GAUSS: {
+      // ℓπ = -½ θᵀPθ, ∇ = -Pθ, P (D,D) column-major symmetric precision
+      const T* P = tg.params.data();
+      T v = 0;
+      for (int64_t i = 0; i < D; ++i) g[i] = 0;
+      for (int64_t j = 0; j < D; ++j) {
+        T tj = th[j];
+        const T* col = P + j * D;
+        for (int64_t i = 0; i < D; ++i) g[i] -= col[i] * tj;
+      }
+      for (int64_t i = 0; i < D; ++i) v += th[i] * g[i];
+      return v / 2;
+    }
+    default:
+      for (int64_t d = 0; d < D; ++d) g[d] = std::numeric_limits<T>::quiet_NaN();
+      return std::numeric_limits<T>::quiet_NaN();
+  }
+}
+
+// One chain's view of the metric (src/metric.jl:17-120).  Diag: minv/sqrt_minv point at this
+// chain's D entries ((D,) shared or column c of (D,N)).  Dense: minv (D,D) col-major, chol = U
+// with UᵀU = M⁻¹ (cholesky(Symmetric(M⁻¹)).U, :108).
+template <class T>
+struct MetricView {
+  int kind;
+  int64_t D;
+  const T* minv;
+  const T* sqrt_minv;
+  const T* chol;
+};
+
+// ∂H∂r (src/hamiltonian.jl:50-68): Unit copy(r); Diag M⁻¹ .* r; Dense M⁻¹ * r
+template <class T>
+void dHdr(const MetricView<T>& m, const T* r, T* out) {
+  const int64_t D = m.D;
+  if (m.kind == AHMC_METRIC_UNIT) {
+    for (int64_t d = 0; d < D; ++d) out[d] = r[d];
+  } else if (m.kind == AHMC_METRIC_DIAG) {
+    for (int64_t d = 0; d < D; ++d) out[d] = m.minv[d] * r[d];
+  } else {
+    for (int64_t i = 0; i < D; ++i) out[i] = 0;
+    for (int64_t j = 0; j < D; ++j) {
+      const T* col = m.minv + j * D;
+      for (int64_t i = 0; i < D; ++i) out[i] += col[i] * r[j];
+    }
+  }
+}
+
+// neg_energy(h, r, θ) = ℓκ = -K(r) (src/hamiltonian.jl:155-184)
+template <class T>
+T neg_kinetic(const MetricView<T>& m, const T* r) {
+  const int64_t D = m.D;
+  T s = 0;
+  if (m.kind == AHMC_METRIC_UNIT) {
+    for (int64_t d = 0; d < D; ++d) s += r[d] * r[d];  // -sum(abs2, r)/2
+  } else if (m.kind == AHMC_METRIC_DIAG) {
+    for (int64_t d = 0; d < D; ++d) s += (r[d] * r[d]) * m.minv[d];  // -sum(abs2.(r) .* M⁻¹)/2
+  } else {
+    std::vector<T> tmp(D);
+    dHdr(m, r, tmp.data());  // mul!(_temp, M⁻¹, r); -dot(r, _temp)/2
+    for (int64_t d = 0; d < D; ++d) s += r[d] * tmp[d];
+  }
+  return -s / 2;
+}
+
+// PhasePoint (src/hamiltonian.jl:88-107).  `g` is ℓπ.gradient = -∇ℓπ (:45-48).  ℓκ.gradient
+// (∂H∂r) is never read after construction except by isfinite, so it is recomputed on demand.
+template <class T>
+struct PhasePoint {
+  std::vector<T> th, r, g;
+  T lp = 0, lk = 0;
+};
+
+// the value sanitation of the PhasePoint constructor (:95-104): non-finite values → -Inf
+template <class T>
+inline T sanitize(T v) {
+  return std::isfinite(v) ? v : neg_inf<T>();
+}
+
+// isfinite(z) (src/hamiltonian.jl:141-142): values AND gradients of ℓπ and ℓκ all finite
+template <class T>
+bool phasepoint_isfinite(const MetricView<T>& m, const PhasePoint<T>& z) {
+  if (!std::isfinite(z.lp) || !std::isfinite(z.lk)) return false;
+  for (T v : z.g)
+    if (!std::isfinite(v)) return false;
+  std::vector<T> kr(m.D);
+  dHdr(m, z.r.data(), kr.data());
+  for (T v : kr)
+    if (!std::isfinite(v)) return false;
+  return true;
+}
+
+template <class T>
+inline T energy(const PhasePoint<T>& z) {  // H = -(ℓπ + ℓκ)  (src/hamiltonian.jl:149,194)
+  return -(z.lp + z.lk);
+}
+
+// phasepoint(h, θ, r) (src/hamiltonian.jl:115-119): evaluates ∂H∂θ and the kinetic cache
+template <class T>
+PhasePoint<T> make_phasepoint(const Target<T>& tg, const MetricView<T>& m, const T* th, const T* r) {
+  PhasePoint<T> z;
+  z.th.assign(th, th + m.D);
+  z.r.assign(r, r + m.D);
+  z.g.resize(m.D);
+  T v = logdensity_and_gradient(tg, m.D, th, z.g.data());
+  for (auto& x : z.g) x = -x;  // DualValue(res[1], -res[2])
+  z.lp = sanitize(v);
+  z.lk = sanitize(neg_kinetic(m, r));
+  return z;
+}
+
+// integrator parameters of one chain (src/integrator.jl:71-74, :112-123, :174-179)
+template <class T>
+struct LeapfrogCfg {
+  int kind = AHMC_INTEGRATOR_LEAPFROG;
+  T eps = T(0.1);   // current (possibly jittered) step size
+  T alpha = T(1);   // TemperedLeapfrog temperature
+};
+
+// temper (src/integrator.jl:198-209); identity for the other integrators (:52-56)
+template <class T>
+inline void temper(const LeapfrogCfg<T>& lf, std::vector<T>& r, int64_t i, bool is_half, int64_t n_steps) {
+  if (lf.kind != AHMC_INTEGRATOR_TEMPERED) return;
+  int64_t i_temper = 2 * (i - 1) + 1 + (is_half ? 0 : 1);
+  T s = std::sqrt(lf.alpha);
+  if (i_temper <= n_steps)
+    for (auto& x : r) x = x * s;
+  else
+    for (auto& x : r) x = x / s;
+}
+
+// step(lf, h, z, n_steps; fwd, full_trajectory) (src/integrator.jl:216-265), scalar chain.
+// Returns the last point; if `traj` is non-null every intermediate point is appended to it.
+template <class T>
+PhasePoint<T> leapfrog_step(const LeapfrogCfg<T>& lf, const Target<T>& tg, const MetricView<T>& m,
+                            const PhasePoint<T>& z0, int64_t n_steps_signed, bool fwd,
+                            std::vector<PhasePoint<T>>* traj = nullptr, int64_t i0 = 0,
+                            int64_t n_total = -1) {
+  const int64_t D = m.D;
+  int64_t n_steps = n_steps_signed < 0 ? -n_steps_signed : n_steps_signed;  // :220
+  T eps = fwd ? lf.eps : -lf.eps;                                           // :222
+  PhasePoint<T> z = z0;
+  std::vector<T> th = z0.th, r = z0.r, g = z0.g, kr(D);
+  T value = z0.lp;
+  // (i0, n_total) let a caller run one step of a longer tempered trajectory (ref_compat mode)
+  const int64_t n_temper = n_total < 0 ? n_steps : n_total;
+  for (int64_t i = 1; i <= n_steps; ++i) {
+    temper(lf, r, i0 + i, true, n_temper);                         // :231
+    for (int64_t d = 0; d < D; ++d) r[d] = r[d] - eps / 2 * g[d];  // :233
+    dHdr(m, r.data(), kr.data());                                  // :235
+    for (int64_t d = 0; d < D; ++d) th[d] = th[d] + eps * kr[d];   // :236
+    value = logdensity_and_gradient(tg, D, th.data(), g.data());   // :238 ∂H∂θ
+    for (int64_t d = 0; d < D; ++d) g[d] = -g[d];
+    for (int64_t d = 0; d < D; ++d) r[d] = r[d] - eps / 2 * g[d];  // :239
+    temper(lf, r, i0 + i, false, n_temper);                        // :241
+    z.th = th; z.r = r; z.g = g;                                   // :243 phasepoint(h, θ, r; ℓπ)
+    z.lp = sanitize(value);
+    z.lk = sanitize(neg_kinetic(m, r.data()));
+    if (traj) traj->push_back(z);
+    if (!phasepoint_isfinite(m, z)) break;                         // :248-255
+  }
+  return z;
+}
+
+// rand_momentum (src/metric.jl:290-320) for one chain: z ~ N(0, I); Diag z ./ sqrtM⁻¹;
+// Dense cholM⁻¹ \ z (upper-triangular back substitution)
+template <class T>
+void rand_momentum(const Rng& rng, uint32_t purpose, const MetricView<T>& m, T* r) {
+  const int64_t D = m.D;
+  for (int64_t d = 0; d < D; ++d) r[d] = (T)rng.normal(purpose, (uint32_t)d);
+  if (m.kind == AHMC_METRIC_DIAG) {
+    for (int64_t d = 0; d < D; ++d) r[d] = r[d] / m.sqrt_minv[d];
+  } else if (m.kind == AHMC_METRIC_DENSE) {
+    for (int64_t i = D - 1; i >= 0; --i) {
+      T s = r[i];
+      for (int64_t j = i + 1; j < D; ++j) s -= m.chol[i + j * D] * r[j];
+      r[i] = s / m.chol[i + i * D];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NUTS (src/trajectory.jl:454-742), literal recursive form
+// ---------------------------------------------------------------------------------------------
+struct Termination {  // :480-507
+  bool dynamic = false, numerical = false;
+};
+inline Termination operator*(Termination a, Termination b) {
+  return Termination{a.dynamic || b.dynamic, a.numerical || b.numerical};
+}
+inline bool isterminated(Termination t) { return t.dynamic || t.numerical; }
+
+template <class T>
+inline T maxabs(T a, T b) {  // :526
+  return std::abs(a) > std::abs(b) ? a : b;
+}
+
+template <class T>
+struct BinaryTree {  // :512-520
+  PhasePoint<T> zleft, zright;
+  std::vector<T> rho;  // TurnStatistic (:454-467); unused (empty) for ClassicNoUTurn
+  T sum_alpha = 0;
+  int64_t n_alpha = 0;
+  T dH_max = 0;
+};
+
+template <class T>
+BinaryTree<T> combine(const BinaryTree<T>& l, const BinaryTree<T>& r) {  // :533-542
+  BinaryTree<T> t;
+  t.zleft = l.zleft;
+  t.zright = r.zright;
+  t.rho.resize(l.rho.size());
+  for (size_t d = 0; d < l.rho.size(); ++d) t.rho[d] = l.rho[d] + r.rho[d];  // :467
+  t.sum_alpha = l.sum_alpha + r.sum_alpha;
+  t.n_alpha = l.n_alpha + r.n_alpha;
+  t.dH_max = maxabs(l.dH_max, r.dH_max);
+  return t;
+}
+
+// tree sampler state: SliceTS (ℓu, n) / MultinomialTS (ℓw)  (:102-136)
+template <class T>
+struct Sampler {
+  PhasePoint<T> zcand;
+  T lw = 0;      // Multinomial: log total weight
+  T lu = 0;      // Slice: log slice variable
+  int64_t n = 0; // Slice: number of acceptable candidates
+};
+
+template <class T>
+struct NutsCfg {
+  int sampler = AHMC_TS_MULTINOMIAL;
+  int criterion = AHMC_TC_GENERALISED;
+  int max_depth = 10;
+  T delta_max = T(1000);
+};
+
+template <class T>
+struct NutsEnv {
+  const LeapfrogCfg<T>* lf;
+  const Target<T>* tg;
+  const MetricView<T>* m;
+  const NutsCfg<T>* cfg;
+  const Rng* rng;
+  uint32_t draw = 0;  // sequential index of the scalar draws of this transition
+};
+
+template <class T>
+inline T dot(const std::vector<T>& a, const std::vector<T>& b) {
+  T s = 0;
+  for (size_t d = 0; d < a.size(); ++d) s += a[d] * b[d];
+  return s;
+}
+
+template <class T>
+inline bool generalised_uturn_criterion(const std::vector<T>& rho, const std::vector<T>& pm,
+                                        const std::vector<T>& pp) {  // :619-621
+  return (dot(rho, pm) <= 0) || (dot(rho, pp) <= 0);
+}
+
+template <class T>
+std::vector<T> dHdr_vec(const MetricView<T>& m, const std::vector<T>& r) {
+  std::vector<T> o(r.size());
+  dHdr(m, r.data(), o.data());
+  return o;
+}
+
+// isterminated(tc, h, t, tleft, tright) for the three criteria (:551-623)
+template <class T>
+Termination uturn(const NutsEnv<T>& e, const BinaryTree<T>& t, const BinaryTree<T>& tl,
+                  const BinaryTree<T>& tr) {
+  const MetricView<T>& m = *e.m;
+  if (e.cfg->criterion == AHMC_TC_CLASSIC) {  // :551-557
+    const int64_t D = m.D;
+    std::vector<T> dth(D), ndth(D), nr0(D);
+    for (int64_t d = 0; d < D; ++d) {
+      dth[d] = t.zright.th[d] - t.zleft.th[d];
+      ndth[d] = -dth[d];
+      nr0[d] = -t.zleft.r[d];
+    }
+    bool s = (dot(dth, dHdr_vec(m, nr0)) >= 0) || (dot(ndth, dHdr_vec(m, t.zright.r)) >= 0);
+    return Termination{s, false};
+  }
+  bool s1 = generalised_uturn_criterion(t.rho, dHdr_vec(m, t.zleft.r), dHdr_vec(m, t.zright.r));  // :566-570
+  if (e.cfg->criterion == AHMC_TC_GENERALISED) return Termination{s1, false};
+  // Strict (:579-617)
+  std::vector<T> rho2(m.D), rho3(m.D);
+  for (int64_t d = 0; d < m.D; ++d) {
+    rho2[d] = tl.rho[d] + tr.zleft.r[d];   // check_left_subtree :597-601
+    rho3[d] = tl.zright.r[d] + tr.rho[d];  // check_right_subtree :609-615
+  }
+  bool s2 = generalised_uturn_criterion(rho2, dHdr_vec(m, t.zleft.r), dHdr_vec(m, tr.zleft.r));
+  bool s3 = generalised_uturn_criterion(rho3, dHdr_vec(m, tl.zright.r), dHdr_vec(m, t.zright.r));
+  return Termination{s1, false} * Termination{s2, false} * Termination{s3, false};
+}
+
+// sampler for a single-leaf tree (:163-176)
+template <class T>
+Sampler<T> leaf_sampler(const NutsEnv<T>& e, const Sampler<T>& s, T H0, const PhasePoint<T>& z) {
+  Sampler<T> o;
+  o.zcand = z;
+  if (e.cfg->sampler == AHMC_TS_SLICE) {
+    o.lu = s.lu;
+    o.n = (s.lu <= -energy(z)) ? 1 : 0;  // Int(s.ℓu <= neg_energy(zcand))
+  } else {
+    o.lw = H0 + (-energy(z));  // H0 + neg_energy(zcand)
+  }
+  return o;
+}
+
+// combine(rng, s1, s2): uniform progressive sampling inside a subtree (:178-195)
+template <class T>
+Sampler<T> combine_rng(NutsEnv<T>& e, const Sampler<T>& s1, const Sampler<T>& s2) {
+  Sampler<T> o;
+  if (e.cfg->sampler == AHMC_TS_SLICE) {
+    o.n = s1.n + s2.n;
+    o.lu = s1.lu;
+    T u = (T)e.rng->uniform(RNG_TRANSITION, e.draw++);
+    o.zcand = (T(o.n) * u < T(s1.n)) ? s1.zcand : s2.zcand;
+  } else {
+    o.lw = logaddexp(s1.lw, s2.lw);
+    T ex = (T)e.rng->randexp(RNG_TRANSITION, e.draw++);
+    o.zcand = (o.lw < s1.lw + ex) ? s1.zcand : s2.zcand;
+  }
+  return o;
+}
+
+// Termination(sampler, nt, H0, H′): divergence test (:500-507)
+template <class T>
+Termination leaf_termination(const NutsEnv<T>& e, const Sampler<T>& s, T H0, T Hp) {
+  if (e.cfg->sampler == AHMC_TS_SLICE) return Termination{false, !(s.lu < e.cfg->delta_max + -Hp)};
+  return Termination{false, !(-H0 < e.cfg->delta_max + -Hp)};
+}
+
+template <class T>
+struct BuildResult {
+  BinaryTree<T> tree;
+  Sampler<T> sampler;
+  Termination term;
+};
+
+// build_tree (:626-675)
+template <class T>
+BuildResult<T> build_tree(NutsEnv<T>& e, const PhasePoint<T>& z, const Sampler<T>& sampler, int v,
+                          int j, T H0) {
+  if (j == 0) {
+    // base case: one leapfrog step in direction v (:638-647)
+    PhasePoint<T> zp = leapfrog_step(*e.lf, *e.tg, *e.m, z, v, v > 0);
+    T Hp = energy(zp);
+    T dH = Hp - H0;
+    T alpha = std::exp(jl_min(T(0), -dH));
+    BuildResult<T> out;
+    out.sampler = leaf_sampler(e, sampler, H0, zp);
+    out.tree.zleft = zp;
+    out.tree.zright = zp;
+    if (e.cfg->criterion != AHMC_TC_CLASSIC) out.tree.rho = zp.r;  // TurnStatistic(tc, z′)
+    out.tree.sum_alpha = alpha;
+    out.tree.n_alpha = 1;
+    out.tree.dH_max = dH;
+    out.term = leaf_termination(e, out.sampler, H0, Hp);
+    return out;
+  }
+  BuildResult<T> first = build_tree(e, z, sampler, v, j - 1, H0);  // :650
+  if (!isterminated(first.term)) {
+    BuildResult<T> second;
+    const BinaryTree<T>*tl, *tr;
+    if (v == -1) {
+      second = build_tree(e, first.tree.zleft, sampler, v, j - 1, H0);  // :655-658
+      tl = &second.tree;
+      tr = &first.tree;
+    } else {
+      second = build_tree(e, first.tree.zright, sampler, v, j - 1, H0);  // :661-664
+      tl = &first.tree;
+      tr = &second.tree;
+    }
+    BuildResult<T> out;
+    out.tree = combine(*tl, *tr);                                  // :666
+    out.sampler = combine_rng(e, first.sampler, second.sampler);   // :667
+    out.term = first.term * second.term * uturn(e, out.tree, *tl, *tr);  // :668-671
+    return out;
+  }
+  return first;
+}
+
+// per-chain transition statistics (src/trajectory.jl:286-298, :726-739)
+template <class T>
+struct TStat {
+  int32_t n_steps = 0, is_accept = 0, tree_depth = 0, numerical_error = 0;
+  T acceptance_rate = 0, log_density = 0, hamiltonian_energy = 0, hamiltonian_energy_error = 0,
+    max_hamiltonian_energy_error = 0;
+};
+
+// dynamic transition (:677-742)
+template <class T>
+PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0, TStat<T>& st) {
+  T H0 = energy(z0);
+  BinaryTree<T> tree;
+  tree.zleft = z0;
+  tree.zright = z0;
+  if (e.cfg->criterion != AHMC_TC_CLASSIC) tree.rho = z0.r;
+  tree.sum_alpha = 0;
+  tree.n_alpha = 0;
+  tree.dH_max = 0;
+  Sampler<T> sampler;  // TS(rng, z0) (:144-155)
+  sampler.zcand = z0;
+  if (e.cfg->sampler == AHMC_TS_SLICE) {
+    sampler.lu = -energy(z0) - (T)e.rng->randexp(RNG_TRANSITION, e.draw++);
+    sampler.n = 1;
+  } else {
+    sampler.lw = 0;
+  }
+  Termination term;
+  PhasePoint<T> zcand = z0;
+  int j = 0;
+  while (!isterminated(term) && j < e.cfg->max_depth) {
+    bool vleft = e.rng->boolean(RNG_TRANSITION, e.draw++);  // :693
+    BuildResult<T> sub;
+    BinaryTree<T> tl, tr;
+    if (vleft) {
+      sub = build_tree(e, tree.zleft, sampler, -1, j, H0);
+      tl = sub.tree;
+      tr = tree;
+    } else {
+      sub = build_tree(e, tree.zright, sampler, 1, j, H0);
+      tl = tree;
+      tr = sub.tree;
+    }
+    if (!isterminated(sub.term)) {  // :708-713
+      j = j + 1;
+      bool acc;
+      if (e.cfg->sampler == AHMC_TS_SLICE) {
+        T u = (T)e.rng->uniform(RNG_TRANSITION, e.draw++);
+        acc = T(sampler.n) * u < T(sub.sampler.n);  // :202
+      } else {
+        T ex = (T)e.rng->randexp(RNG_TRANSITION, e.draw++);
+        acc = sampler.lw < sub.sampler.lw + ex;  // :203-206
+      }
+      if (acc) zcand = sub.sampler.zcand;
+    }
+    tree = combine(tl, tr);  // :715
+    // combine(zcand, sampler, sampler′) (:183-187, :197-200)
+    if (e.cfg->sampler == AHMC_TS_SLICE)
+      sampler.n = sampler.n + sub.sampler.n;
+    else
+      sampler.lw = logaddexp(sampler.lw, sub.sampler.lw);
+    sampler.zcand = zcand;
+    term = term * sub.term * uturn(e, tree, tl, tr);  // :719-722
+  }
+  T H = energy(zcand);
+  st.n_steps = (int32_t)tree.n_alpha;
+  st.is_accept = 1;
+  st.acceptance_rate = tree.sum_alpha / T(tree.n_alpha);
+  st.log_density = zcand.lp;
+  st.hamiltonian_energy = H;
+  st.hamiltonian_energy_error = H - H0;
+  st.max_hamiltonian_energy_error = tree.dH_max;
+  st.tree_depth = j;
+  st.numerical_error = term.numerical ? 1 : 0;
+  return zcand;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stan window schedule (src/adaptation/stan_adaptor.jl:13-50)
+// ---------------------------------------------------------------------------------------------
+struct StanWindows {
+  int64_t window_start = 0, window_end = 0;
+  std::vector<int64_t> splits;
+};
+
+StanWindows stan_windows(int64_t init_buffer, int64_t term_buffer, int64_t window_size, int64_t n_adapts) {
+  StanWindows w;
+  w.window_start = init_buffer + 1;
+  w.window_end = n_adapts - term_buffer;
+  int64_t next_window = init_buffer + window_size;
+  while (next_window <= w.window_end) {
+    int64_t next_window_boundary = next_window + 2 * window_size;
+    if (next_window_boundary > w.window_end) next_window = w.window_end;
+    w.splits.push_back(next_window);
+    window_size *= 2;
+    next_window += window_size;
+  }
+  if (!w.splits.empty() && w.splits.back() == n_adapts) w.splits.pop_back();
+  return w;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct CtxBase {
+  virtual ~CtxBase() {}
+  std::string err;
+  int dtype = AHMC_F64;
+};
+
+static thread_local std::string g_create_err;
+
+namespace {
+
+template <class T>
+struct Ctx : CtxBase {
+  int64_t D = 0, N = 0;
+  // phase point of every chain, (D,N) column-major
+  std::vector<T> th, r, g, lp, lk;
+  bool have_point = false;
+  // Hamiltonian
+  Target<T> target;
+  int metric_kind = AHMC_METRIC_UNIT;
+  bool metric_per_chain = false;
+  std::vector<T> minv, sqrt_minv, chol;
+  // integrator
+  int integ_kind = AHMC_INTEGRATOR_LEAPFROG;
+  T integ_param = 0;
+  std::vector<T> eps_nom, eps_cur;  // (N,)
+  bool eps_scalar = true;
+  // rng
+  uint64_t seed = 0, chain_offset = 0, chain_stride = 1, iteration = 0;
+  // stats of the last transition
+  std::vector<TStat<T>> stat;
+  // adaptation
+  int adapt_kind = AHMC_ADAPT_NONE;
+  T da_delta = T(0.8), da_gamma = T(0.05), da_t0 = T(10), da_kappa = T(0.75);
+  std::vector<int32_t> da_m;
+  std::vector<T> da_eps, da_mu, da_xbar, da_Hbar;
+  int64_t wv_n = 0, wv_nmin = 10;
+  std::vector<T> wv_mu, wv_M, wv_var;
+  int stan_init = 75, stan_term = 50, stan_window = 25;
+  int64_t stan_i = 0;
+  StanWindows windows;
+  // accumulators
+  int64_t acc_nsteps = 0, acc_ntrans = 0, acc_ndiv = 0;
+  std::vector<T> acc_sum, acc_sumsq;
+  bool ref_compat = false;
+
+  MetricView<T> metric_view(int64_t c) const {
+    MetricView<T> m;
+    m.kind = metric_kind;
+    m.D = D;
+    m.minv = nullptr;
+    m.sqrt_minv = nullptr;
+    m.chol = nullptr;
+    if (metric_kind == AHMC_METRIC_DIAG) {
+      int64_t off = metric_per_chain ? c * D : 0;
+      m.minv = minv.data() + off;
+      m.sqrt_minv = sqrt_minv.data() + off;
+    } else if (metric_kind == AHMC_METRIC_DENSE) {
+      m.minv = minv.data();
+      m.chol = chol.data();
+    }
+    return m;
+  }
+  Rng rng(int64_t c, uint64_t iter) const {
+    Rng g;
+    g.k0 = (uint32_t)seed;
+    g.k1 = (uint32_t)(seed >> 32);
+    g.chain = (uint32_t)(chain_offset + chain_stride * (uint64_t)c);
+    g.iter = (uint32_t)iter;
+    return g;
+  }
+  PhasePoint<T> load(int64_t c) const {
+    PhasePoint<T> z;
+    z.th.assign(th.begin() + c * D, th.begin() + (c + 1) * D);
+    z.r.assign(r.begin() + c * D, r.begin() + (c + 1) * D);
+    z.g.assign(g.begin() + c * D, g.begin() + (c + 1) * D);
+    z.lp = lp[c];
+    z.lk = lk[c];
+    return z;
+  }
+  void store(int64_t c, const PhasePoint<T>& z) {
+    std::copy(z.th.begin(), z.th.end(), th.begin() + c * D);
+    std::copy(z.r.begin(), z.r.end(), r.begin() + c * D);
+    std::copy(z.g.begin(), z.g.end(), g.begin() + c * D);
+    lp[c] = z.lp;
+    lk[c] = z.lk;
+  }
+  LeapfrogCfg<T> lfcfg(int64_t c) const {
+    LeapfrogCfg<T> lf;
+    lf.kind = integ_kind;
+    lf.eps = eps_cur[c];
+    lf.alpha = integ_kind == AHMC_INTEGRATOR_TEMPERED ? integ_param : T(1);
+    return lf;
+  }
+};
+
+template <class T>
+int fail(Ctx<T>* c, int code, const std::string& msg) {
+  c->err = msg;
+  return code;
+}
+
+// renew(metric, M⁻¹) (src/metric.jl:61-63 sqrt.; :104-109 cholesky upper)
+template <class T>
+int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
+  const int64_t D = c->D, N = c->N;
+  if (kind == AHMC_METRIC_UNIT) {
+    c->metric_kind = kind;
+    c->minv.clear(); c->sqrt_minv.clear(); c->chol.clear();
+    return AHMC_OK;
+  }
+  if (!minv) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: M⁻¹ pointer is NULL");
+  if (kind == AHMC_METRIC_DIAG) {
+    if (n != D && n != D * N)
+      return fail(c, AHMC_ERR_ARGUMENT, "AxesMismatch: diagonal M⁻¹ must have D or D*N elements");
+    c->metric_kind = kind;
+    c->metric_per_chain = (n == D * N) && !(N == 1);
+    c->minv.assign(minv, minv + n);
+    c->sqrt_minv.resize(n);
+    for (int64_t i = 0; i < n; ++i) c->sqrt_minv[i] = std::sqrt(c->minv[i]);
+    return AHMC_OK;
+  }
+  if (kind == AHMC_METRIC_DENSE) {
+    if (n != D * D) return fail(c, AHMC_ERR_ARGUMENT, "AxesMismatch: dense M⁻¹ must have D*D elements");
+    c->metric_kind = kind;
+    c->metric_per_chain = false;
+    c->minv.assign(minv, minv + n);
+    // upper Cholesky factor U, UᵀU = M⁻¹
+    std::vector<T>& U = c->chol;
+    U.assign(D * D, T(0));
+    for (int64_t j = 0; j < D; ++j) {
+      for (int64_t i = 0; i <= j; ++i) {
+        T s = c->minv[i + j * D];
+        for (int64_t k = 0; k < i; ++k) s -= U[k + i * D] * U[k + j * D];
+        if (i == j) {
+          if (!(s > 0)) return fail(c, AHMC_ERR_ARGUMENT, "PosDefException: M⁻¹ is not positive definite");
+          U[i + j * D] = std::sqrt(s);
+        } else {
+          U[i + j * D] = s / U[i + i * D];
+        }
+      }
+    }
+    return AHMC_OK;
+  }
+  return fail(c, AHMC_ERR_ARGUMENT, "set_metric: unknown metric kind");
+}
+
+// jitter(rng, lf) (src/integrator.jl:140-156): ϵ = ϵ0 (1 + jitter (2u − 1)), per chain
+template <class T>
+void apply_jitter(Ctx<T>* c) {
+  for (int64_t i = 0; i < c->N; ++i) {
+    if (c->integ_kind == AHMC_INTEGRATOR_JITTERED) {
+      T u = (T)c->rng(i, c->iteration).uniform(RNG_JITTER, 0);
+      c->eps_cur[i] = c->eps_nom[i] * (1 + c->integ_param * (2 * u - 1));
+    } else {
+      c->eps_cur[i] = c->eps_nom[i];
+    }
+  }
+}
+
+// refresh (src/hamiltonian.jl:213-220 full; :243-254 partial) for one chain
+template <class T>
+PhasePoint<T> refresh(Ctx<T>* c, int64_t i, const PhasePoint<T>& z, T alpha) {
+  MetricView<T> m = c->metric_view(i);
+  std::vector<T> rn(c->D);
+  rand_momentum(c->rng(i, c->iteration), RNG_MOMENTUM, m, rn.data());
+  if (alpha != 0) {
+    T s = std::sqrt(1 - alpha * alpha);
+    for (int64_t d = 0; d < c->D; ++d) rn[d] = alpha * z.r[d] + s * rn[d];
+  }
+  return make_phasepoint(c->target, m, z.th.data(), rn.data());  // recomputes ℓπ, ∇ℓπ at θ
+}
+
+// mh_accept_ratio (src/trajectory.jl:855-880)
+template <class T>
+inline void mh_accept_ratio(const Rng& rng, uint32_t draw, T H, T Hp, bool& accept, T& alpha) {
+  accept = Hp < H + (T)rng.randexp(RNG_TRANSITION, draw);
+  alpha = jl_min(T(1), std::exp(H - Hp));
+}
+
+// static transition for one chain (src/trajectory.jl:271-300), EndPointTS (:336-340) or
+// MultinomialTS (:369-390 with the coupled n_steps_fwd of Q4)
+template <class T>
+void hmc_transition_chain(Ctx<T>* c, int64_t i, int64_t L, int sampler, int64_t n_fwd_coupled, T refresh_alpha,
+                          int64_t stop_at /* ref_compat Q1: max steps, <0 = none */) {
+  MetricView<T> m = c->metric_view(i);
+  LeapfrogCfg<T> lf = c->lfcfg(i);
+  Rng rng = c->rng(i, c->iteration);
+  PhasePoint<T> z = refresh(c, i, c->load(i), refresh_alpha);
+  T H0 = energy(z);
+  PhasePoint<T> zp;
+  bool is_accept;
+  T alpha;
+  TStat<T>& st = c->stat[i];
+  if (sampler == AHMC_TS_ENDPOINT) {
+    int64_t nst = (stop_at >= 0 && stop_at < L) ? stop_at : L;
+    zp = leapfrog_step(lf, c->target, m, z, nst, true);
+    mh_accept_ratio(rng, 0, energy(z), energy(zp), is_accept, alpha);
+  } else {
+    std::vector<PhasePoint<T>> fwd, bwd;
+    leapfrog_step(lf, c->target, m, z, n_fwd_coupled, true, &fwd);
+    leapfrog_step(lf, c->target, m, z, L - n_fwd_coupled, false, &bwd);
+    std::vector<const PhasePoint<T>*> zs;  // vcat(reverse(zs_bwd)..., z, zs_fwd...)
+    for (auto it = bwd.rbegin(); it != bwd.rend(); ++it) zs.push_back(&*it);
+    zs.push_back(&z);
+    for (auto& p : fwd) zs.push_back(&p);
+    // randcat(rng, zs, unnorm_ℓp) (:344-352, src/utilities.jl:51-59 scalar form)
+    std::vector<T> lw(zs.size());
+    T mx = neg_inf<T>();
+    for (size_t k = 0; k < zs.size(); ++k) {
+      lw[k] = -energy(*zs[k]);
+      mx = jl_max(mx, lw[k]);
+    }
+    T se = 0;  // logsumexp
+    for (T v : lw) se += std::exp(v - mx);
+    T lse = mx + std::log(se);
+    T u = (T)rng.uniform(RNG_TRANSITION, 0);
+    T cum = 0;
+    size_t idx = 0;
+    while (cum < u && idx < zs.size()) cum += std::exp(lw[idx++] - lse);
+    if (idx < 1) idx = 1;
+    zp = *zs[idx - 1];
+    is_accept = true;
+    T sa = 0;
+    for (T v : lw) sa += std::exp(jl_min(T(0), -((-v) - energy(z))));  // α = exp(min(0, -ΔH))
+    alpha = sa / T(lw.size());
+  }
+  // accept_phasepoint! (:303-332) then momentum flip (:283)
+  PhasePoint<T> zn = is_accept ? zp : z;
+  for (auto& x : zn.r) x = -x;
+  T H = energy(zn), Hp = energy(zp);
+  st.n_steps = (int32_t)L;
+  st.is_accept = is_accept ? 1 : 0;
+  st.acceptance_rate = alpha;
+  st.log_density = zn.lp;
+  st.hamiltonian_energy = H;
+  st.hamiltonian_energy_error = H - H0;
+  st.max_hamiltonian_energy_error = 0;
+  st.tree_depth = 0;
+  st.numerical_error = std::isfinite(Hp) ? 0 : 1;  // scalar-chain form of :295
+  c->store(i, zn);
+}
+
+template <class T>
+int64_t resolve_L(Ctx<T>* c, int64_t L, double lambda) {
+  if (lambda > 0) {  // nsteps for FixedIntegrationTime (src/trajectory.jl:241-243)
+    double e = (double)c->eps_nom[0];
+    int64_t n = (int64_t)std::floor(lambda / e);
+    return n < 1 ? 1 : n;
+  }
+  return L;
+}
+
+template <class T>
+void accumulate(Ctx<T>* c) {
+  if (c->acc_sum.empty()) {
+    c->acc_sum.assign(c->D * c->N, T(0));
+    c->acc_sumsq.assign(c->D * c->N, T(0));
+  }
+  c->acc_ntrans += 1;
+  for (int64_t i = 0; i < c->N; ++i) {
+    c->acc_nsteps += c->stat[i].n_steps;
+    c->acc_ndiv += c->stat[i].numerical_error;
+  }
+  for (int64_t k = 0; k < c->D * c->N; ++k) {
+    c->acc_sum[k] += c->th[k];
+    c->acc_sumsq[k] += c->th[k] * c->th[k];
+  }
+}
+
+template <class T>
+int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, T refresh_alpha) {
+  if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
+  if (sampler != AHMC_TS_ENDPOINT && sampler != AHMC_TS_MULTINOMIAL)
+    return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
+  if (lambda > 0 && !c->eps_scalar)
+    return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
+  L = resolve_L(c, L, lambda);
+  if (L < 0) L = -L;
+  apply_jitter(c);
+  int64_t n_fwd = 0;
+  if (sampler == AHMC_TS_MULTINOMIAL) {
+    // rand_coupled(rng, 0:n_steps) (src/trajectory.jl:373, src/utilities.jl:39-47): ONE draw
+    Rng shared = c->rng(0, c->iteration);
+    shared.chain = COUPLED_CHAIN;
+    double u = shared.uniform(RNG_TRANSITION, 0);
+    n_fwd = (int64_t)std::floor(u * (double)(L + 1));
+    if (n_fwd > L) n_fwd = L;
+  }
+  int64_t stop_at = -1;
+  if (c->ref_compat && sampler == AHMC_TS_ENDPOINT) {
+    // Q1 (src/integrator.jl:252-258): in matrix mode the step loop breaks for ALL chains at the
+    // first step where any chain is non-finite.  Dry-run to find that step.
+    for (int64_t i = 0; i < c->N; ++i) {
+      MetricView<T> m = c->metric_view(i);
+      PhasePoint<T> z = refresh(c, i, c->load(i), refresh_alpha);
+      std::vector<PhasePoint<T>> tr;
+      leapfrog_step(c->lfcfg(i), c->target, m, z, L, true, &tr);
+      if (!tr.empty() && !phasepoint_isfinite(m, tr.back())) {
+        int64_t bs = (int64_t)tr.size();
+        if (stop_at < 0 || bs < stop_at) stop_at = bs;
+      }
+    }
+  }
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t i = 0; i < c->N; ++i) hmc_transition_chain(c, i, L, sampler, n_fwd, refresh_alpha, stop_at);
+  c->iteration += 1;
+  return AHMC_OK;
+}
+
+template <class T>
+int nuts_transition_all(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, T refresh_alpha) {
+  if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
+  if (sampler != AHMC_TS_MULTINOMIAL && sampler != AHMC_TS_SLICE)
+    return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
+  if (criterion < AHMC_TC_CLASSIC || criterion > AHMC_TC_STRICT)
+    return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
+  apply_jitter(c);
+  NutsCfg<T> cfg;
+  cfg.sampler = sampler;
+  cfg.criterion = criterion;
+  cfg.max_depth = max_depth;
+  cfg.delta_max = (T)delta_max;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t i = 0; i < c->N; ++i) {
+    MetricView<T> m = c->metric_view(i);
+    LeapfrogCfg<T> lf = c->lfcfg(i);
+    Rng rng = c->rng(i, c->iteration);
+    PhasePoint<T> z = refresh(c, i, c->load(i), refresh_alpha);
+    NutsEnv<T> e{&lf, &c->target, &m, &cfg, &rng, 0};
+    PhasePoint<T> zc = nuts_transition(e, z, c->stat[i]);
+    c->store(i, zc);
+  }
+  c->iteration += 1;
+  return AHMC_OK;
+}
+
+// A(h, z, ϵ) + find_good_stepsize for one chain (src/trajectory.jl:753-837), incl. quirk Q3
+template <class T>
+T find_good_stepsize_chain(Ctx<T>* c, int64_t i, T init, int max_n_iters) {
+  MetricView<T> m = c->metric_view(i);
+  T eps = init, epsp = init;
+  const T log_a_min = 2 * std::log(T(0.5)), log_a_cross = std::log(T(0.5)), log_a_max = std::log(T(0.75));
+  const T d = 2, invd = T(1) / d;
+  std::vector<T> r(c->D);
+  rand_momentum(c->rng(i, c->iteration), RNG_FINDEPS, m, r.data());
+  PhasePoint<T> z = make_phasepoint(c->target, m, c->th.data() + i * c->D, r.data());
+  T H = energy(z);
+  auto A = [&](T e) {
+    LeapfrogCfg<T> lf;
+    lf.kind = AHMC_INTEGRATOR_LEAPFROG;
+    lf.eps = e;
+    return energy(leapfrog_step(lf, c->target, m, z, 1, true));
+  };
+  T Hp = A(eps);
+  T dH = H - Hp;
+  bool too_high = dH > log_a_cross;
+  for (int it = 0; it < max_n_iters; ++it) {
+    epsp = too_high ? d * eps : invd * eps;
+    Hp = A(eps);  // Q3: evaluated at ϵ, not ϵ′ (src/trajectory.jl:799-800)
+    dH = H - Hp;
+    if (too_high != (dH > log_a_cross)) break;
+    eps = epsp;
+  }
+  T lo = jl_min(eps, epsp), hi = jl_max(eps, epsp);  // minmax
+  eps = lo; epsp = hi;
+  for (int it = 0; it < max_n_iters; ++it) {
+    T mid = eps / 2 + epsp / 2;  // Statistics.middle
+    Hp = A(mid);
+    dH = H - Hp;
+    if (dH > log_a_max) eps = mid;
+    else if (dH < log_a_min) epsp = mid;
+    else { eps = mid; break; }
+  }
+  return eps;
+}
+
+template <class T>
+void leapfrog_all(Ctx<T>* c, int64_t n_steps, bool fwd) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t i = 0; i < c->N; ++i)
+    c->store(i, leapfrog_step(c->lfcfg(i), c->target, c->metric_view(i), c->load(i), n_steps, fwd));
+}
+
+template <class T>
+std::vector<T> find_good_stepsize_all(Ctx<T>* c, T init, int max_n_iters) {
+  std::vector<T> out(c->N);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t i = 0; i < c->N; ++i) out[i] = find_good_stepsize_chain(c, i, init, max_n_iters);
+  return out;
+}
+
+// --- adaptation ------------------------------------------------------------------------------
+template <class T>
+void da_reset(Ctx<T>* c) {  // reset!(das) (src/adaptation/stepsize.jl:40-53)
+  for (int64_t i = 0; i < c->N; ++i) {
+    c->da_m[i] = 0;
+    c->da_mu[i] = std::log(10 * c->da_eps[i]);
+    c->da_xbar[i] = 0;
+    c->da_Hbar[i] = 0;
+  }
+}
+
+template <class T>
+void da_adapt(Ctx<T>* c) {  // adapt_stepsize! (src/adaptation/stepsize.jl:178-210), per chain
+  for (int64_t i = 0; i < c->N; ++i) {
+    T alpha = c->stat[i].acceptance_rate;
+    int32_t m = c->da_m[i] + 1;
+    T eta_H = T(1) / (T(m) + c->da_t0);
+    T Hbar = (T(1) - eta_H) * c->da_Hbar[i] + eta_H * (c->da_delta - jl_min(T(1), alpha));
+    T x = c->da_mu[i] - Hbar * (std::sqrt(T(m)) / c->da_gamma);
+    T eta_x = std::pow(T(m), -c->da_kappa);
+    T xbar = (T(1) - eta_x) * c->da_xbar[i] + eta_x * x;
+    T eps = std::exp(x);
+    if (!std::isfinite(eps)) continue;  // previous (m, ϵ, x̄, H̄) kept (:199-203)
+    c->da_m[i] = m;
+    c->da_eps[i] = eps;
+    c->da_xbar[i] = xbar;
+    c->da_Hbar[i] = Hbar;
+  }
+}
+
+template <class T>
+void wv_reset(Ctx<T>* c) {  // reset!(wv) (src/adaptation/massmatrix.jl:133-138)
+  c->wv_n = 0;
+  std::fill(c->wv_mu.begin(), c->wv_mu.end(), T(0));
+  std::fill(c->wv_M.begin(), c->wv_M.end(), T(0));
+}
+
+template <class T>
+void wv_push(Ctx<T>* c) {  // push! (:141-149)
+  c->wv_n += 1;
+  T n = T(c->wv_n);
+  for (int64_t k = 0; k < c->D * c->N; ++k) {
+    T delta = c->th[k] - c->wv_mu[k];
+    c->wv_mu[k] = c->wv_mu[k] + delta / n;
+    c->wv_M[k] = c->wv_M[k] + delta * delta * ((n - 1) / n);
+  }
+}
+
+template <class T>
+void wv_update(Ctx<T>* c) {  // update! (:60-62) + get_estimation (:152-157)
+  if (c->wv_n < c->wv_nmin) return;
+  T n = T(c->wv_n), e = T(1e-3);
+  for (int64_t k = 0; k < c->D * c->N; ++k) c->wv_var[k] = n / ((n + 5) * (n - 1)) * c->wv_M[k] + e * (5 / (n + 5));
+}
+
+template <class T>
+int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts) {  // src/sampler.jl:72-90
+  if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
+  const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
+  const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
+  if (i == 1 && c->adapt_kind == AHMC_ADAPT_STAN) {  // initialize! (stan_adaptor.jl:105-115)
+    c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);
+  }
+  if (c->adapt_kind == AHMC_ADAPT_STAN) {  // adapt!(tp::StanHMCAdaptor, ...) (:137-159)
+    c->stan_i += 1;
+    da_adapt(c);
+    bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
+    bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
+    if (in_window && has_mm) {
+      wv_push(c);
+      if (window_end) wv_update(c);
+    }
+    if (window_end) {
+      da_reset(c);
+      if (has_mm) wv_reset(c);
+    }
+  } else {
+    if (has_ss) da_adapt(c);        // NaiveHMCAdaptor: ssa then pc (Adaptation.jl:52-60)
+    if (has_mm) { wv_push(c); wv_update(c); }
+  }
+  if (i == n_adapts && has_ss) {  // finalize! (stepsize.jl:55-62): ϵ = exp(x̄)
+    for (int64_t k = 0; k < c->N; ++k) c->da_eps[k] = std::exp(c->da_xbar[k]);
+  }
+  // update(h, adaptor), update(κ, adaptor) (src/sampler.jl:3-22)
+  if (has_mm) {
+    int rc = set_metric(c, AHMC_METRIC_DIAG, c->wv_var.data(), (int64_t)c->wv_var.size());
+    if (rc) return rc;
+  }
+  if (has_ss) {
+    c->eps_nom = c->da_eps;
+    c->eps_scalar = false;
+  }
+  return AHMC_OK;
+}
+
+template <class T>
+int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
+  c->adapt_kind = kind;
+  c->da_delta = (T)delta;
+  c->stan_init = ib; c->stan_term = tb; c->stan_window = ws;
+  c->stan_i = 0;
+  // NesterovDualAveraging(δ, ϵ) → DAState(ϵ) (stepsize.jl:25-33)
+  c->da_eps = c->eps_nom;
+  c->da_m.assign(c->N, 0);
+  c->da_mu.resize(c->N); c->da_xbar.assign(c->N, T(0)); c->da_Hbar.assign(c->N, T(0));
+  for (int64_t i = 0; i < c->N; ++i) c->da_mu[i] = std::log(10 * c->da_eps[i]);
+  // WelfordVar{T}(size(metric); var = copy(M⁻¹)) per chain (src/AdvancedHMC.jl:113-115)
+  if (c->metric_kind == AHMC_METRIC_DIAG) {
+    c->wv_n = 0;
+    c->wv_mu.assign(c->D * c->N, T(0));
+    c->wv_M.assign(c->D * c->N, T(0));
+    c->wv_var.resize(c->D * c->N);
+    for (int64_t i = 0; i < c->N; ++i)
+      for (int64_t d = 0; d < c->D; ++d)
+        c->wv_var[d + i * c->D] = c->minv[c->metric_per_chain ? d + i * c->D : d];
+  }
+  return AHMC_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+#define FOR_CTX(ctx, ...)                                                                      \
+  do {                                                                                         \
+    CtxBase* _b = reinterpret_cast<CtxBase*>(ctx);                                             \
+    if (!_b) return AHMC_ERR_ARGUMENT;                                                         \
+    if (_b->dtype == AHMC_F32) { using T = float; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ } \
+    else { using T = double; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ }                 \
+  } while (0)
+
+extern "C" {
+
+int32_t ahmc_abi_version(void) { return AHMC_ABI_VERSION; }
+const char* ahmc_backend(void) { return "cpu-oracle"; }
+
+int32_t ahmc_create(int32_t device, int32_t dtype, int64_t D, int64_t N, void* stream, ahmc_ctx** out) {
+  (void)device; (void)stream;
+  if (!out) { g_create_err = "ahmc_create: out is NULL"; return AHMC_ERR_ARGUMENT; }
+  if (D < 1 || N < 1) { g_create_err = "ahmc_create: D and N must be >= 1"; return AHMC_ERR_ARGUMENT; }
+  if (dtype != AHMC_F32 && dtype != AHMC_F64) { g_create_err = "ahmc_create: dtype must be AHMC_F32 or AHMC_F64"; return AHMC_ERR_ARGUMENT; }
+  auto init = [&](auto* c) {
+    using T = typename std::remove_reference<decltype(c->th[0])>::type;
+    c->dtype = dtype; c->D = D; c->N = N;
+    c->th.assign(D * N, T(0)); c->r.assign(D * N, T(0)); c->g.assign(D * N, T(0));
+    c->lp.assign(N, T(0)); c->lk.assign(N, T(0));
+    c->eps_nom.assign(N, T(0.1)); c->eps_cur.assign(N, T(0.1));
+    c->stat.assign(N, TStat<T>());
+  };
+  if (dtype == AHMC_F32) { auto* c = new Ctx<float>(); init(c); *out = reinterpret_cast<ahmc_ctx*>(static_cast<CtxBase*>(c)); }
+  else { auto* c = new Ctx<double>(); init(c); *out = reinterpret_cast<ahmc_ctx*>(static_cast<CtxBase*>(c)); }
+  return AHMC_OK;
+}
+
+int32_t ahmc_destroy(ahmc_ctx* ctx) {
+  delete reinterpret_cast<CtxBase*>(ctx);
+  return AHMC_OK;
+}
+
+const char* ahmc_last_error(const ahmc_ctx* ctx) {
+  if (!ctx) return g_create_err.c_str();
+  return reinterpret_cast<const CtxBase*>(ctx)->err.c_str();
+}
+
+int32_t ahmc_sync(ahmc_ctx* ctx) { return ctx ? AHMC_OK : AHMC_ERR_ARGUMENT; }
+void* ahmc_stream(ahmc_ctx*) { return nullptr; }
+
+// oracle-only switch: reproduce the reference's matrix-mode batch coupling (Q1)
+int32_t ahmco_set_ref_compat(ahmc_ctx* ctx, int32_t on) {
+  FOR_CTX(ctx, { c->ref_compat = on != 0; return AHMC_OK; });
+}
+
+int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params) {
+  FOR_CTX(ctx, {
+    int64_t need = 0;
+    switch (kind) {
+      case AHMC_TARGET_ISO_GAUSS: case AHMC_TARGET_FUNNEL: case AHMC_TARGET_HIER_GAUSS: need = 0; break;
+      case AHMC_TARGET_DIAG_GAUSS: need = 2 * c->D; break;
+      case AHMC_TARGET_DENSE_GAUSS: need = c->D * c->D; break;
+      case AHMC_TARGET_EXTERNAL: need = 0; break;
+      default: return fail(c, AHMC_ERR_ARGUMENT, "set_target: unknown target kind");
+    }
+    if (kind == AHMC_TARGET_FUNNEL && c->D < 2) return fail(c, AHMC_ERR_ARGUMENT, "funnel needs D >= 2");
+    if (kind == AHMC_TARGET_HIER_GAUSS && c->D < 3) return fail(c, AHMC_ERR_ARGUMENT, "hier_gauss needs D >= 3");
+    if (n_params != need || (need > 0 && !params)) return fail(c, AHMC_ERR_ARGUMENT, "set_target: wrong parameter count for this family");
+    c->target.kind = kind;
+    const T* p = static_cast<const T*>(params);
+    c->target.params.assign(p, p + need);
+    c->have_point = false;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n) {
+  FOR_CTX(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
+}
+
+int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
+  FOR_CTX(ctx, {
+    if (c->metric_kind == AHMC_METRIC_UNIT) return fail(c, AHMC_ERR_ARGUMENT, "get_metric: unit metric has no array");
+    if (n != (int64_t)c->minv.size()) return fail(c, AHMC_ERR_ARGUMENT, "get_metric: size mismatch");
+    std::memcpy(out, c->minv.data(), sizeof(T) * n);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_stepsize(ahmc_ctx* ctx, const void* eps, int64_t n) {
+  FOR_CTX(ctx, {
+    if (!eps || (n != 1 && n != c->N)) return fail(c, AHMC_ERR_ARGUMENT, "set_stepsize: need 1 or N step sizes");
+    const T* e = static_cast<const T*>(eps);
+    for (int64_t i = 0; i < c->N; ++i) c->eps_nom[i] = e[n == 1 ? 0 : i];
+    c->eps_cur = c->eps_nom;
+    c->eps_scalar = (n == 1);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_get_stepsize(ahmc_ctx* ctx, void* out) {
+  FOR_CTX(ctx, { std::memcpy(out, c->eps_nom.data(), sizeof(T) * c->N); return AHMC_OK; });
+}
+
+int32_t ahmc_set_integrator(ahmc_ctx* ctx, int32_t kind, double param) {
+  FOR_CTX(ctx, {
+    if (kind < AHMC_INTEGRATOR_LEAPFROG || kind > AHMC_INTEGRATOR_TEMPERED) return fail(c, AHMC_ERR_ARGUMENT, "set_integrator: unknown kind");
+    c->integ_kind = kind;
+    c->integ_param = (T)param;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_seed(ahmc_ctx* ctx, uint64_t seed, uint64_t chain_offset, uint64_t chain_stride, uint64_t iteration) {
+  FOR_CTX(ctx, { c->seed = seed; c->chain_offset = chain_offset; c->chain_stride = chain_stride; c->iteration = iteration; return AHMC_OK; });
+}
+
+int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r) {
+  FOR_CTX(ctx, {
+    if (!theta) return fail(c, AHMC_ERR_ARGUMENT, "set_position: theta is NULL");
+    if (c->target.kind == AHMC_TARGET_EXTERNAL) return fail(c, AHMC_ERR_STATE, "set_position needs a built-in target; use set_phasepoint");
+    const T* th = static_cast<const T*>(theta);
+    const T* rr = static_cast<const T*>(r);
+    std::vector<T> zero(c->D, T(0));
+    for (int64_t i = 0; i < c->N; ++i) {
+      PhasePoint<T> z = make_phasepoint(c->target, c->metric_view(i), th + i * c->D, rr ? rr + i * c->D : zero.data());
+      c->store(i, z);
+    }
+    c->have_point = true;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_phasepoint(ahmc_ctx* ctx, const void* theta, const void* r, const void* lp, const void* grad) {
+  FOR_CTX(ctx, {
+    if (!theta || !r || !lp || !grad) return fail(c, AHMC_ERR_ARGUMENT, "set_phasepoint: NULL argument");
+    std::memcpy(c->th.data(), theta, sizeof(T) * c->D * c->N);
+    std::memcpy(c->r.data(), r, sizeof(T) * c->D * c->N);
+    std::memcpy(c->g.data(), grad, sizeof(T) * c->D * c->N);
+    const T* l = static_cast<const T*>(lp);
+    for (int64_t i = 0; i < c->N; ++i) {
+      c->lp[i] = sanitize(l[i]);
+      c->lk[i] = sanitize(neg_kinetic(c->metric_view(i), c->r.data() + i * c->D));
+    }
+    c->have_point = true;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_get_phasepoint(ahmc_ctx* ctx, void* theta, void* r, void* lp, void* grad, void* lk) {
+  FOR_CTX(ctx, {
+    size_t nb = sizeof(T) * c->D * c->N;
+    if (theta) std::memcpy(theta, c->th.data(), nb);
+    if (r) std::memcpy(r, c->r.data(), nb);
+    if (grad) std::memcpy(grad, c->g.data(), nb);
+    if (lp) std::memcpy(lp, c->lp.data(), sizeof(T) * c->N);
+    if (lk) std::memcpy(lk, c->lk.data(), sizeof(T) * c->N);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "refresh before set_position");
+    for (int64_t i = 0; i < c->N; ++i) c->store(i, refresh(c, i, c->load(i), (T)alpha));
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "leapfrog before set_position");
+    c->eps_cur = c->eps_nom;
+    bool fwd = n_steps > 0;
+    if (c->ref_compat) {
+      // Q1: matrix-mode loop, all chains stop at the first step where any chain is non-finite
+      int64_t n = n_steps < 0 ? -n_steps : n_steps;
+      for (int64_t s = 1; s <= n; ++s) {
+        bool all_finite = true;
+        for (int64_t i = 0; i < c->N; ++i) {
+          LeapfrogCfg<T> lf = c->lfcfg(i);
+          MetricView<T> m = c->metric_view(i);
+          PhasePoint<T> z = c->load(i);
+          PhasePoint<T> zn = leapfrog_step(lf, c->target, m, z, 1, fwd, (std::vector<PhasePoint<T>>*)nullptr, s - 1, n);
+          c->store(i, zn);
+          all_finite = all_finite && phasepoint_isfinite(m, zn);
+        }
+        if (!all_finite) break;
+      }
+      return AHMC_OK;
+    }
+    leapfrog_all(c, n_steps, fwd);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "lf_pre before set_phasepoint");
+    for (int64_t k = 0; k < c->N; ++k) {
+      LeapfrogCfg<T> lf = c->lfcfg(k);
+      MetricView<T> m = c->metric_view(k);
+      T eps = fwd ? lf.eps : -lf.eps;
+      std::vector<T> r(c->r.begin() + k * c->D, c->r.begin() + (k + 1) * c->D), kr(c->D);
+      temper(lf, r, i, true, n_steps);
+      for (int64_t d = 0; d < c->D; ++d) r[d] = r[d] - eps / 2 * c->g[d + k * c->D];
+      dHdr(m, r.data(), kr.data());
+      for (int64_t d = 0; d < c->D; ++d) {
+        c->th[d + k * c->D] = c->th[d + k * c->D] + eps * kr[d];
+        c->r[d + k * c->D] = r[d];
+      }
+    }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_lf_post(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps, const void* lp, const void* grad_neg) {
+  FOR_CTX(ctx, {
+    if (!lp || !grad_neg) return fail(c, AHMC_ERR_ARGUMENT, "lf_post: NULL argument");
+    const T* l = static_cast<const T*>(lp);
+    const T* gn = static_cast<const T*>(grad_neg);
+    for (int64_t k = 0; k < c->N; ++k) {
+      LeapfrogCfg<T> lf = c->lfcfg(k);
+      MetricView<T> m = c->metric_view(k);
+      T eps = fwd ? lf.eps : -lf.eps;
+      std::vector<T> r(c->r.begin() + k * c->D, c->r.begin() + (k + 1) * c->D);
+      for (int64_t d = 0; d < c->D; ++d) {
+        c->g[d + k * c->D] = gn[d + k * c->D];
+        r[d] = r[d] - eps / 2 * gn[d + k * c->D];
+      }
+      temper(lf, r, i, false, n_steps);
+      std::copy(r.begin(), r.end(), c->r.begin() + k * c->D);
+      c->lp[k] = sanitize(l[k]);
+      c->lk[k] = sanitize(neg_kinetic(m, r.data()));
+    }
+    return AHMC_OK;
+  });
+}
+
+void* ahmc_theta_ptr(ahmc_ctx* ctx) {
+  CtxBase* b = reinterpret_cast<CtxBase*>(ctx);
+  if (!b) return nullptr;
+  if (b->dtype == AHMC_F32) return static_cast<Ctx<float>*>(b)->th.data();
+  return static_cast<Ctx<double>*>(b)->th.data();
+}
+
+int32_t ahmc_hmc_transition(ahmc_ctx* ctx, int64_t L, double lambda, int32_t sampler) {
+  FOR_CTX(ctx, { return hmc_transition(c, L, lambda, sampler, T(0)); });
+}
+
+int32_t ahmc_nuts_transition(ahmc_ctx* ctx, int32_t max_depth, double delta_max, int32_t criterion, int32_t sampler) {
+  FOR_CTX(ctx, { return nuts_transition_all(c, max_depth, delta_max, criterion, sampler, T(0)); });
+}
+
+int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
+  FOR_CTX(ctx, {
+    if (!out) return fail(c, AHMC_ERR_ARGUMENT, "get_stat: out is NULL");
+    int32_t* oi = static_cast<int32_t*>(out);
+    T* of = static_cast<T*>(out);
+    for (int64_t i = 0; i < c->N; ++i) {
+      const TStat<T>& s = c->stat[i];
+      switch (field) {
+        case AHMC_STAT_N_STEPS: oi[i] = s.n_steps; break;
+        case AHMC_STAT_IS_ACCEPT: oi[i] = s.is_accept; break;
+        case AHMC_STAT_ACCEPTANCE_RATE: of[i] = s.acceptance_rate; break;
+        case AHMC_STAT_LOG_DENSITY: of[i] = s.log_density; break;
+        case AHMC_STAT_HAMILTONIAN_ENERGY: of[i] = s.hamiltonian_energy; break;
+        case AHMC_STAT_HAMILTONIAN_ENERGY_ERROR: of[i] = s.hamiltonian_energy_error; break;
+        case AHMC_STAT_MAX_HAMILTONIAN_ENERGY_ERROR: of[i] = s.max_hamiltonian_energy_error; break;
+        case AHMC_STAT_TREE_DEPTH: oi[i] = s.tree_depth; break;
+        case AHMC_STAT_NUMERICAL_ERROR: oi[i] = s.numerical_error; break;
+        case AHMC_STAT_STEP_SIZE: of[i] = c->eps_cur[i]; break;
+        case AHMC_STAT_NOM_STEP_SIZE: of[i] = c->eps_nom[i]; break;
+        default: return fail(c, AHMC_ERR_ARGUMENT, "get_stat: unknown field");
+      }
+    }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "find_good_stepsize before set_position");
+    std::vector<T> out = find_good_stepsize_all(c, (T)initial_step_size, max_n_iters);
+    c->eps_nom = out;
+    c->eps_cur = out;
+    c->eps_scalar = false;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t init_buffer, int32_t term_buffer, int32_t window_size) {
+  FOR_CTX(ctx, {
+    if (kind < AHMC_ADAPT_NONE || kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: unknown adaptor kind");
+    return adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
+  });
+}
+
+int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts) {
+  FOR_CTX(ctx, { return adapt(c, i, n_adapts); });
+}
+
+int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size, int64_t n_adapts,
+                          int64_t* window_start, int64_t* window_end, int64_t* splits, int32_t cap, int32_t* n_splits) {
+  StanWindows w = stan_windows(init_buffer, term_buffer, window_size, n_adapts);
+  if (window_start) *window_start = w.window_start;
+  if (window_end) *window_end = w.window_end;
+  if (n_splits) *n_splits = (int32_t)w.splits.size();
+  if (splits)
+    for (int32_t k = 0; k < cap && k < (int32_t)w.splits.size(); ++k) splits[k] = w.splits[k];
+  return AHMC_OK;
+}
+
+int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup, void* samples_out) {
+  FOR_CTX(ctx, {
+    if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample: cfg is NULL");
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "sample before set_position");
+    if (drop_warmup && c->adapt_kind == AHMC_ADAPT_NONE)
+      return fail(c, AHMC_ERR_ARGUMENT, "Cannot drop warmup samples if there is no adaptation phase.");  // src/sampler.jl:172
+    T* so = static_cast<T*>(samples_out);
+    bool reset_done = false;
+    for (int64_t i = 1; i <= n_samples; ++i) {  // src/sampler.jl:182-228
+      int rc = cfg->nuts ? nuts_transition_all(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, (T)cfg->refresh_alpha)
+                         : hmc_transition(c, cfg->L, cfg->lambda, cfg->sampler, (T)cfg->refresh_alpha);
+      if (rc) return rc;
+      rc = adapt(c, i, n_adapts);
+      if (rc) return rc;
+      if (!drop_warmup || i > n_adapts) {
+        if (!reset_done) { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); reset_done = true; }
+        accumulate(c);
+        int64_t j = i - (drop_warmup ? n_adapts : 0);
+        if (so) std::memcpy(so + (j - 1) * c->D * c->N, c->th.data(), sizeof(T) * c->D * c->N);
+      }
+    }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transitions, int64_t* n_divergent, void* sum_theta, void* sumsq_theta) {
+  FOR_CTX(ctx, {
+    if (total_n_steps) *total_n_steps = c->acc_nsteps;
+    if (n_transitions) *n_transitions = c->acc_ntrans;
+    if (n_divergent) *n_divergent = c->acc_ndiv;
+    size_t nb = sizeof(T) * c->D * c->N;
+    if (sum_theta) { if (c->acc_sum.empty()) std::memset(sum_theta, 0, nb); else std::memcpy(sum_theta, c->acc_sum.data(), nb); }
+    if (sumsq_theta) { if (c->acc_sumsq.empty()) std::memset(sumsq_theta, 0, nb); else std::memcpy(sumsq_theta, c->acc_sumsq.data(), nb); }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
+  FOR_CTX(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); return AHMC_OK; });
+}
+
+// ---- oracle-only probes used by the golden tests (pieces of src/trajectory.jl) ---------------
+double ahmco_logaddexp(double a, double b) { return logaddexp(a, b); }
+void ahmco_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  Philox4 p = philox4x32_10(c0, c1, c2, c3, k0, k1);
+  std::memcpy(out, p.v, sizeof(p.v));
+}
+double ahmco_uniform(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t purpose, uint32_t slot) {
+  Rng g{(uint32_t)seed, (uint32_t)(seed >> 32), chain, iter};
+  return g.uniform(purpose, slot);
+}
+double ahmco_normal(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t purpose, uint32_t d) {
+  Rng g{(uint32_t)seed, (uint32_t)(seed >> 32), chain, iter};
+  return g.normal(purpose, d);
+}
+// BinaryTree combine statistics (test/trajectory.jl:231-246)
+void ahmco_tree_combine(double sa1, int64_t n1, double dh1, double sa2, int64_t n2, double dh2, double* sa, int64_t* n, double* dh) {
+  BinaryTree<double> a, b;
+  a.sum_alpha = sa1; a.n_alpha = n1; a.dH_max = dh1;
+  b.sum_alpha = sa2; b.n_alpha = n2; b.dH_max = dh2;
+  BinaryTree<double> t = combine(a, b);
+  *sa = t.sum_alpha; *n = t.n_alpha; *dh = t.dH_max;
+}
+// Termination algebra (test/trajectory.jl:199-229)
+int32_t ahmco_termination_mul(int32_t d1, int32_t n1, int32_t d2, int32_t n2) {
+  return isterminated(Termination{d1 != 0, n1 != 0} * Termination{d2 != 0, n2 != 0}) ? 1 : 0;
+}
+// temper schedule (test/integrator.jl:89-106): returns the factor applied to r
+double ahmco_temper_factor(double alpha, int64_t i, int32_t is_half, int64_t n_steps) {
+  LeapfrogCfg<double> lf;
+  lf.kind = AHMC_INTEGRATOR_TEMPERED;
+  lf.alpha = alpha;
+  std::vector<double> r(1, 1.0);
+  temper(lf, r, i, is_half != 0, n_steps);
+  return r[0];
+}
+// U-turn criteria on an explicit (left, right, rho) triple, unit metric (test/trajectory.jl:249-325)
+int32_t ahmco_uturn(int32_t criterion, int64_t D, const double* thl, const double* rl, const double* thr, const double* rr, const double* rho) {
+  MetricView<double> m{AHMC_METRIC_UNIT, D, nullptr, nullptr, nullptr};
+  NutsCfg<double> cfg;
+  cfg.criterion = criterion;
+  NutsEnv<double> e{nullptr, nullptr, &m, &cfg, nullptr, 0};
+  BinaryTree<double> t;
+  t.zleft.th.assign(thl, thl + D); t.zleft.r.assign(rl, rl + D);
+  t.zright.th.assign(thr, thr + D); t.zright.r.assign(rr, rr + D);
+  t.rho.assign(rho, rho + D);
+  return uturn(e, t, t, t).dynamic ? 1 : 0;
+}
+// multinomial sampler combine: returns ℓw and writes whether the first candidate is kept
+double ahmco_multinomial_combine(double lw1, double lw2, double randexp, int32_t* keep_first) {
+  double lw = logaddexp(lw1, lw2);
+  *keep_first = (lw < lw1 + randexp) ? 1 : 0;
+  return lw;
+}
+int32_t ahmco_slice_combine(int64_t n1, int64_t n2, double u) { return (double)(n1 + n2) * u < (double)n1 ? 1 : 0; }
+
+}  // extern "C"
