@@ -598,8 +598,12 @@ class Engine:
                       getattr(adaptor, "window_size", 25))
         self._call("ahmc_adaptor_init", adaptor.code, float(adaptor.delta), ib, tb, ws)
 
-    def adapt(self, i, n_adapts):
-        self._call("ahmc_adapt", int(i), int(n_adapts))
+    def adapt(self, i, n_adapts, theta=None, alpha=None):
+        """adapt!(h, κ, adaptor, i, n_adapts, θ, α) (src/sampler.jl:72-90); θ/α default to the
+        context's position and the last transition's acceptance_rate"""
+        th = None if theta is None else self._mat(theta, "θ")
+        al = None if alpha is None else np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=self.dtype), (self.N,)))
+        self._call("ahmc_adapt", int(i), int(n_adapts), capi.as_ptr(th), capi.as_ptr(al))
 
     # -- bulk driver --
     def run(self, kernel: HMCKernel, n_samples, n_adapts=0, drop_warmup=False, samples_out=None):

@@ -1,0 +1,930 @@
+// ahmc_api.hip — host side of the C ABI (include/ahmc_hip.h) for the HIP engine (gfx950).
+// Owns the context (device buffers, stream), validates arguments the way the reference's Julia
+// methods do, and enqueues the kernels of ahmc_kernels.hpp.  No CPU compute path exists here:
+// every numerical result comes from a kernel.
+#include "ahmc_hip.h"
+#include "ahmc_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+using namespace ahmc;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct CtxBase {
+  virtual ~CtxBase() {}
+  std::string err;
+  int dtype = AHMC_F64;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+};
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      c->err = std::string(#expr) + ": " + hipGetErrorString(_e);                         \
+      return AHMC_ERR_RUNTIME;                                                            \
+    }                                                                                     \
+  } while (0)
+
+struct StanWindows {
+  int64_t window_start = 0, window_end = 0;
+  std::vector<int64_t> splits;
+};
+
+// initialize!(::StanHMCAdaptorState, ...) (src/adaptation/stan_adaptor.jl:13-50) — host integers
+StanWindows stan_windows(int64_t init_buffer, int64_t term_buffer, int64_t window_size, int64_t n_adapts) {
+  StanWindows w;
+  w.window_start = init_buffer + 1;
+  w.window_end = n_adapts - term_buffer;
+  int64_t next_window = init_buffer + window_size;
+  while (next_window <= w.window_end) {
+    int64_t next_window_boundary = next_window + 2 * window_size;
+    if (next_window_boundary > w.window_end) next_window = w.window_end;
+    w.splits.push_back(next_window);
+    window_size *= 2;
+    next_window += window_size;
+  }
+  if (!w.splits.empty() && w.splits.back() == n_adapts) w.splits.pop_back();
+  return w;
+}
+
+template <class T>
+struct Ctx : CtxBase {
+  int64_t D = 0, N = 0;
+  int G = 0, E = 0;  // thread geometry chosen for D
+  // phase point
+  T *th = nullptr, *r = nullptr, *g = nullptr, *lp = nullptr, *lk = nullptr;
+  bool have_point = false;
+  // target
+  int target_kind = AHMC_TARGET_ISO_GAUSS;
+  T* tparams = nullptr;
+  // metric
+  int metric_kind = AHMC_METRIC_UNIT;
+  bool minv_per_chain = false;
+  T *minv = nullptr, *sqrt_minv = nullptr;  // capacity D*N
+  int64_t minv_n = 0;
+  // integrator
+  int integ_kind = AHMC_INTEGRATOR_LEAPFROG;
+  double integ_param = 0;
+  T *eps_nom = nullptr, *eps_cur = nullptr;
+  bool eps_scalar = true;
+  double eps_scalar_value = 0.1;
+  // rng
+  uint64_t seed = 0, chain_offset = 0, chain_stride = 1, iteration = 0;
+  // stats
+  int32_t *st_nsteps = nullptr, *st_accept = nullptr, *st_depth = nullptr, *st_numerr = nullptr;
+  T *st_accrate = nullptr, *st_logdens = nullptr, *st_H = nullptr, *st_Herr = nullptr, *st_maxHerr = nullptr;
+  // accumulators
+  long long *acc_nsteps = nullptr, *acc_ndiv = nullptr;
+  T *acc_sum = nullptr, *acc_sumsq = nullptr;
+  int64_t acc_ntrans = 0;
+  // NUTS scratch
+  T* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  unsigned int* queue = nullptr;
+  int nuts_blocks = 0;
+  // static multinomial
+  T* hmc_H = nullptr;
+  size_t hmc_H_elems = 0;
+  // adaptation
+  int adapt_kind = AHMC_ADAPT_NONE;
+  double da_delta = 0.8;
+  int32_t* da_m = nullptr;
+  T *da_eps = nullptr, *da_mu = nullptr, *da_xbar = nullptr, *da_Hbar = nullptr;
+  int64_t wv_n = 0, wv_nmin = 10;
+  T *wv_mu = nullptr, *wv_M = nullptr, *wv_var = nullptr;
+  T *ext_th = nullptr, *ext_alpha = nullptr;  // staging for ahmc_adapt(θ, α) arguments
+  int stan_init = 75, stan_term = 50, stan_window = 25;
+  int64_t stan_i = 0;
+  StanWindows windows;
+  int n_cu = 256;
+
+  ~Ctx() override {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    void* bufs[] = {th, r, g, lp, lk, tparams, minv, sqrt_minv, eps_nom, eps_cur, st_nsteps, st_accept, st_depth,
+                    st_numerr, st_accrate, st_logdens, st_H, st_Herr, st_maxHerr, acc_nsteps, acc_ndiv, acc_sum,
+                    acc_sumsq, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar, da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha};
+    for (void* b : bufs)
+      if (b) (void)hipFree(b);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+template <class T>
+int fail(Ctx<T>* c, int code, const std::string& msg) {
+  c->err = msg;
+  return code;
+}
+
+template <class T, class U>
+int dev_alloc(Ctx<T>* c, U** ptr, size_t n) {
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(ptr), n * sizeof(U)));
+  return AHMC_OK;
+}
+
+// (G, E) for a given D: the largest number of chains per wave that keeps E <= 4 registers-wide
+// vectors per lane, preferring 16-byte accesses (E*sizeof(T) == 16) once D allows it.
+inline bool pick_geometry(int64_t D, int& G, int& E) {
+  if (D <= 4) { G = 4; E = 1; }
+  else if (D <= 8) { G = 8; E = 1; }
+  else if (D <= 16) { G = 16; E = 1; }
+  else if (D <= 32) { G = 16; E = 2; }
+  else if (D <= 64) { G = 32; E = 2; }
+  else if (D <= 128) { G = 64; E = 2; }
+  else if (D <= 256) { G = 64; E = 4; }
+  else return false;
+  const char* ov = getenv("AHMC_GEOMETRY");  // "G,E" override for experiments
+  if (ov) {
+    int g = 0, e = 0;
+    if (sscanf(ov, "%d,%d", &g, &e) == 2 && (int64_t)g * e >= D) {
+      const int ok[][2] = {{4, 1}, {8, 1}, {16, 1}, {16, 2}, {32, 1}, {32, 2}, {32, 4}, {64, 1}, {64, 2}, {64, 4}};
+      for (auto& p : ok)
+        if (p[0] == g && p[1] == e) { G = g; E = e; }
+    }
+  }
+  return true;
+}
+
+// call f(std::integral_constant<int,G>{}, std::integral_constant<int,E>{}) for the context's geometry
+template <class F>
+void with_geometry(int G, int E, F&& f) {
+#define AHMC_GEO_CASE(g, e) \
+  if (G == g && E == e) { f(std::integral_constant<int, g>{}, std::integral_constant<int, e>{}); return; }
+  AHMC_GEO_CASE(4, 1) AHMC_GEO_CASE(8, 1) AHMC_GEO_CASE(16, 1) AHMC_GEO_CASE(16, 2) AHMC_GEO_CASE(32, 1)
+  AHMC_GEO_CASE(32, 2) AHMC_GEO_CASE(32, 4) AHMC_GEO_CASE(64, 1) AHMC_GEO_CASE(64, 2) AHMC_GEO_CASE(64, 4)
+#undef AHMC_GEO_CASE
+}
+
+template <class T>
+KP<T> make_kp(Ctx<T>* c) {
+  KP<T> p;
+  memset(&p, 0, sizeof(p));
+  p.D = (int)c->D;
+  p.N = c->N;
+  p.th = c->th; p.r = c->r; p.g = c->g; p.lp = c->lp; p.lk = c->lk;
+  p.minv = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
+  p.sqrt_minv = c->metric_kind == AHMC_METRIC_DIAG ? c->sqrt_minv : nullptr;
+  p.minv_per_chain = c->minv_per_chain ? 1 : 0;
+  p.eps_nom = c->eps_nom;
+  p.eps_cur = c->eps_cur;
+  p.lf.kind = c->integ_kind;
+  p.lf.sqrt_alpha = c->integ_kind == AHMC_INTEGRATOR_TEMPERED ? (T)std::sqrt((T)c->integ_param) : T(1);
+  p.jitter = (T)c->integ_param;
+  p.tp.kind = c->target_kind;
+  p.tp.D = (int)c->D;
+  p.tp.params = c->tparams;
+  p.k0 = (uint32_t)c->seed;
+  p.k1 = (uint32_t)(c->seed >> 32);
+  p.chain_offset = (uint32_t)c->chain_offset;
+  p.chain_stride = (uint32_t)c->chain_stride;
+  p.iteration = (uint32_t)c->iteration;
+  p.st_nsteps = c->st_nsteps; p.st_accept = c->st_accept; p.st_depth = c->st_depth; p.st_numerr = c->st_numerr;
+  p.st_accrate = c->st_accrate; p.st_logdens = c->st_logdens; p.st_H = c->st_H; p.st_Herr = c->st_Herr;
+  p.st_maxHerr = c->st_maxHerr;
+  p.acc_nsteps = c->acc_nsteps; p.acc_ndiv = c->acc_ndiv; p.acc_sum = c->acc_sum; p.acc_sumsq = c->acc_sumsq;
+  p.scratch = c->scratch;
+  p.queue = c->queue;
+  p.hmc_H = c->hmc_H;
+  return p;
+}
+
+template <class T>
+unsigned group_grid(Ctx<T>* c) {  // blocks of 256 threads covering N groups of G lanes
+  int64_t threads = c->N * c->G;
+  return (unsigned)((threads + 255) / 256);
+}
+
+template <class T>
+int check_builtin(Ctx<T>* c, const char* what) {
+  if (c->target_kind == AHMC_TARGET_EXTERNAL)
+    return fail(c, AHMC_ERR_STATE, std::string(what) + " needs a built-in target; with AHMC_TARGET_EXTERNAL use ahmc_lf_pre/ahmc_lf_post");
+  if (c->target_kind == AHMC_TARGET_DENSE_GAUSS)
+    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": AHMC_TARGET_DENSE_GAUSS has no HIP kernel yet");
+  return AHMC_OK;
+}
+
+template <class T>
+int launch_fill_caches(Ctx<T>* c) {
+  KP<T> p = make_kp(c);
+  with_geometry(c->G, c->E, [&](auto g, auto e) {
+    hipLaunchKernelGGL((k_fill_caches<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0,
+                       c->stream, p);
+  });
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+template <class T>
+int launch_kinetic(Ctx<T>* c) {
+  KP<T> p = make_kp(c);
+  with_geometry(c->G, c->E, [&](auto g, auto e) {
+    hipLaunchKernelGGL((k_kinetic<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0,
+                       c->stream, p);
+  });
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+template <class T>
+int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
+  if (kind == AHMC_METRIC_UNIT) {
+    c->metric_kind = kind;
+    c->minv_per_chain = false;
+    c->minv_n = 0;
+    return AHMC_OK;
+  }
+  if (kind == AHMC_METRIC_DENSE) return fail(c, AHMC_ERR_UNSUPPORTED, "DenseEuclideanMetric has no HIP kernel yet (SURVEY §8a: config 4 only)");
+  if (kind != AHMC_METRIC_DIAG) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: unknown metric kind");
+  if (!minv) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: M⁻¹ pointer is NULL");
+  if (n != c->D && n != c->D * c->N)
+    return fail(c, AHMC_ERR_ARGUMENT, "AxesMismatch: diagonal M⁻¹ must have D or D*N elements");
+  if (!c->minv) {
+    int rc = dev_alloc(c, &c->minv, (size_t)(c->D * c->N));
+    if (rc) return rc;
+    rc = dev_alloc(c, &c->sqrt_minv, (size_t)(c->D * c->N));
+    if (rc) return rc;
+  }
+  if (minv != c->minv) HIPCHK(hipMemcpyAsync(c->minv, minv, sizeof(T) * n, hipMemcpyDefault, c->stream));
+  hipLaunchKernelGGL((k_sqrt<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->minv, c->sqrt_minv, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));  // the source may be a pageable host buffer
+  c->metric_kind = kind;
+  c->minv_per_chain = (n == c->D * c->N) && c->N != 1;
+  c->minv_n = n;
+  return AHMC_OK;
+}
+
+template <class T>
+int ensure_nuts_scratch(Ctx<T>* c, int max_depth, int& blocks, size_t& smem) {
+  const int CPW = 64 / c->G;
+  const int NLEV = max_depth > 1 ? max_depth - 1 : 1;
+  const int waves_per_block = 4;
+  smem = (size_t)waves_per_block * ((size_t)NUTS_NS * NLEV * CPW * sizeof(T) + (size_t)NLEV * CPW * sizeof(int));
+  const int64_t n_chunks = (c->N + CPW - 1) / CPW;
+  int occ = 0;
+  hipError_t e = hipSuccess;
+  with_geometry(c->G, c->E, [&](auto g, auto ee) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, decltype(g)::value, decltype(ee)::value>, 256, smem);
+  });
+  if (e != hipSuccess || occ < 1) occ = 1;
+  if (occ > 8) occ = 8;
+  int64_t want = (n_chunks + waves_per_block - 1) / waves_per_block;
+  int64_t cap = (int64_t)c->n_cu * occ;
+  const char* ov = getenv("AHMC_NUTS_BLOCKS_PER_CU");
+  if (ov && atoi(ov) > 0) cap = (int64_t)c->n_cu * atoi(ov);
+  blocks = (int)std::min<int64_t>(want, cap);
+  if (blocks < 1) blocks = 1;
+  size_t need = (size_t)blocks * waves_per_block * CPW * NLEV * NUTS_NV * (size_t)(c->G * c->E) * sizeof(T);
+  if (need > c->scratch_bytes) {
+    if (c->scratch) HIPCHK(hipFree(c->scratch));
+    c->scratch = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->scratch), need));
+    c->scratch_bytes = need;
+  }
+  return AHMC_OK;
+}
+
+template <class T>
+int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha,
+                    bool accum) {
+  if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
+  int rc = check_builtin(c, "nuts_transition");
+  if (rc) return rc;
+  if (sampler != AHMC_TS_MULTINOMIAL && sampler != AHMC_TS_SLICE)
+    return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
+  if (criterion == AHMC_TC_STRICT) return fail(c, AHMC_ERR_UNSUPPORTED, "StrictGeneralisedNoUTurn has no HIP kernel yet");
+  if (criterion != AHMC_TC_CLASSIC && criterion != AHMC_TC_GENERALISED)
+    return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
+  if (max_depth < 1 || max_depth > 24) return fail(c, AHMC_ERR_ARGUMENT, "max_depth must be in 1..24");
+  int blocks = 0;
+  size_t smem = 0;
+  rc = ensure_nuts_scratch(c, max_depth, blocks, smem);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(c->queue, 0, sizeof(unsigned int), c->stream));
+  KP<T> p = make_kp(c);
+  p.max_depth = max_depth;
+  p.delta_max = (T)delta_max;
+  p.criterion = criterion;
+  p.sampler = sampler;
+  p.refresh_alpha = (T)refresh_alpha;
+  p.accum = accum ? 1 : 0;
+  const int CPW = 64 / c->G;
+  p.n_chunks = (unsigned int)((c->N + CPW - 1) / CPW);
+  with_geometry(c->G, c->E, [&](auto g, auto e) {
+    hipLaunchKernelGGL((k_nuts<T, decltype(g)::value, decltype(e)::value>), dim3(blocks), dim3(256), smem, c->stream, p);
+  });
+  HIPCHK(hipGetLastError());
+  c->iteration += 1;
+  return AHMC_OK;
+}
+
+template <class T>
+int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refresh_alpha, bool accum) {
+  if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
+  int rc = check_builtin(c, "hmc_transition");
+  if (rc) return rc;
+  if (sampler != AHMC_TS_ENDPOINT && sampler != AHMC_TS_MULTINOMIAL)
+    return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
+  if (lambda > 0) {  // nsteps(τ) for FixedIntegrationTime (src/trajectory.jl:241-243)
+    if (!c->eps_scalar) return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
+    int64_t n = (int64_t)std::floor(lambda / (double)(T)c->eps_scalar_value);
+    L = n < 1 ? 1 : n;
+  }
+  if (L < 0) L = -L;
+  if (sampler == AHMC_TS_MULTINOMIAL) {
+    size_t need = (size_t)(L + 1) * (size_t)c->N;
+    if (need > c->hmc_H_elems) {
+      if (c->hmc_H) HIPCHK(hipFree(c->hmc_H));
+      c->hmc_H = nullptr;
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->hmc_H), need * sizeof(T)));
+      c->hmc_H_elems = need;
+    }
+  }
+  KP<T> p = make_kp(c);
+  p.L = L;
+  p.sampler = sampler;
+  p.refresh_alpha = (T)refresh_alpha;
+  p.accum = accum ? 1 : 0;
+  with_geometry(c->G, c->E, [&](auto g, auto e) {
+    hipLaunchKernelGGL((k_hmc<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p);
+  });
+  HIPCHK(hipGetLastError());
+  c->iteration += 1;
+  return AHMC_OK;
+}
+
+template <class T>
+int reset_accum(Ctx<T>* c) {
+  HIPCHK(hipMemsetAsync(c->acc_nsteps, 0, sizeof(long long) * c->N, c->stream));
+  HIPCHK(hipMemsetAsync(c->acc_ndiv, 0, sizeof(long long) * c->N, c->stream));
+  HIPCHK(hipMemsetAsync(c->acc_sum, 0, sizeof(T) * c->D * c->N, c->stream));
+  HIPCHK(hipMemsetAsync(c->acc_sumsq, 0, sizeof(T) * c->D * c->N, c->stream));
+  c->acc_ntrans = 0;
+  return AHMC_OK;
+}
+
+template <class T>
+int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
+  c->adapt_kind = kind;
+  c->da_delta = delta;
+  c->stan_init = ib; c->stan_term = tb; c->stan_window = ws;
+  c->stan_i = 0;
+  if (kind == AHMC_ADAPT_NONE) return AHMC_OK;
+  int rc;
+  if (!c->da_m) {
+    if ((rc = dev_alloc(c, &c->da_m, (size_t)c->N))) return rc;
+    if ((rc = dev_alloc(c, &c->da_eps, (size_t)c->N))) return rc;
+    if ((rc = dev_alloc(c, &c->da_mu, (size_t)c->N))) return rc;
+    if ((rc = dev_alloc(c, &c->da_xbar, (size_t)c->N))) return rc;
+    if ((rc = dev_alloc(c, &c->da_Hbar, (size_t)c->N))) return rc;
+  }
+  // NesterovDualAveraging(δ, ϵ) → DAState(ϵ) (src/adaptation/stepsize.jl:25-33): a reset with ϵ = nominal ϵ
+  HIPCHK(hipMemcpyAsync(c->da_eps, c->eps_nom, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
+  {
+    AdaptP<T> a;
+    memset(&a, 0, sizeof(a));
+    a.N = c->N;
+    a.da_reset = 1;
+    a.da_m = c->da_m; a.da_eps = c->da_eps; a.da_mu = c->da_mu; a.da_xbar = c->da_xbar; a.da_Hbar = c->da_Hbar;
+    a.eps_nom = c->eps_nom;
+    hipLaunchKernelGGL((k_adapt_da<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+  }
+  // WelfordVar{T}(size(metric); var = copy(M⁻¹)) per chain (src/AdvancedHMC.jl:113-115)
+  if (c->metric_kind == AHMC_METRIC_DIAG && kind != AHMC_ADAPT_STEPSIZE) {
+    const int64_t DN = c->D * c->N;
+    if (!c->wv_mu) {
+      if ((rc = dev_alloc(c, &c->wv_mu, (size_t)DN))) return rc;
+      if ((rc = dev_alloc(c, &c->wv_M, (size_t)DN))) return rc;
+      if ((rc = dev_alloc(c, &c->wv_var, (size_t)DN))) return rc;
+    }
+    if (!c->minv_per_chain && c->N != 1) {  // promote a shared (D,) M⁻¹ to per-chain (D,N)
+      hipLaunchKernelGGL((k_bcast_cols<T>), dim3((unsigned)((DN + 255) / 256)), dim3(256), 0, c->stream, c->minv,
+                         c->wv_var, c->D, c->N);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(c->minv, c->wv_var, sizeof(T) * DN, hipMemcpyDeviceToDevice, c->stream));
+      hipLaunchKernelGGL((k_sqrt<T>), dim3((unsigned)((DN + 255) / 256)), dim3(256), 0, c->stream, c->minv, c->sqrt_minv, DN);
+      HIPCHK(hipGetLastError());
+      c->minv_per_chain = true;
+      c->minv_n = DN;
+    } else {
+      HIPCHK(hipMemcpyAsync(c->wv_var, c->minv, sizeof(T) * DN, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipMemsetAsync(c->wv_mu, 0, sizeof(T) * DN, c->stream));
+    HIPCHK(hipMemsetAsync(c->wv_M, 0, sizeof(T) * DN, c->stream));
+    c->wv_n = 0;
+  }
+  return AHMC_OK;
+}
+
+// adapt!(h, κ, adaptor, i, n_adapts, z, α) + update(h/κ, adaptor) (src/sampler.jl:72-90, :3-22)
+template <class T>
+int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr) {
+  if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
+  const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
+  const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
+  bool do_push = false, do_update = false, wv_reset = false, da_reset = false;
+  if (c->adapt_kind == AHMC_ADAPT_STAN) {
+    if (i == 1) c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);  // initialize!
+    c->stan_i += 1;  // adapt!(tp::StanHMCAdaptor, ...) (stan_adaptor.jl:137-159)
+    const bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
+    const bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
+    if (in_window && has_mm) {
+      do_push = true;
+      do_update = window_end;
+    }
+    if (window_end) {
+      da_reset = true;
+      wv_reset = has_mm;
+    }
+  } else if (has_mm) {
+    do_push = true;
+    do_update = true;
+  }
+  AdaptP<T> a;
+  memset(&a, 0, sizeof(a));
+  a.N = c->N;
+  a.DN = c->D * c->N;
+  if (has_ss) {
+    a.do_da = 1;
+    a.da_reset = da_reset ? 1 : 0;
+    a.da_finalize = (i == n_adapts) ? 1 : 0;
+    a.delta = (T)c->da_delta; a.gamma = T(0.05); a.t0 = T(10); a.kappa = T(0.75);  // stepsize.jl:168-172
+    a.da_m = c->da_m; a.da_eps = c->da_eps; a.da_mu = c->da_mu; a.da_xbar = c->da_xbar; a.da_Hbar = c->da_Hbar;
+    a.alpha = c->st_accrate;
+    if (alpha_ext) {  // caller-supplied α (host or device): stage it on the stream
+      if (!c->ext_alpha) { int rc2 = dev_alloc(c, &c->ext_alpha, (size_t)c->N); if (rc2) return rc2; }
+      HIPCHK(hipMemcpyAsync(c->ext_alpha, alpha_ext, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+      a.alpha = c->ext_alpha;
+    }
+    a.eps_nom = c->eps_nom;
+    hipLaunchKernelGGL((k_adapt_da<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    c->eps_scalar = false;
+  }
+  if (has_mm && (do_push || wv_reset)) {
+    if (do_push) c->wv_n += 1;
+    a.do_push = do_push ? 1 : 0;
+    a.do_update = (do_update && c->wv_n >= c->wv_nmin) ? 1 : 0;  // update!(ve) (massmatrix.jl:60-62)
+    a.wv_reset = wv_reset ? 1 : 0;
+    a.wv_n = (T)c->wv_n;
+    a.th = c->th;
+    if (th_ext) {  // caller-supplied θ
+      if (!c->ext_th) { int rc2 = dev_alloc(c, &c->ext_th, (size_t)a.DN); if (rc2) return rc2; }
+      HIPCHK(hipMemcpyAsync(c->ext_th, th_ext, sizeof(T) * a.DN, hipMemcpyDefault, c->stream));
+      a.th = c->ext_th;
+    }
+    a.wv_mu = c->wv_mu; a.wv_M = c->wv_M; a.wv_var = c->wv_var;
+    a.minv = c->minv; a.sqrt_minv = c->sqrt_minv;
+    hipLaunchKernelGGL((k_adapt_wv<T>), dim3((unsigned)((a.DN + 255) / 256)), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    if (wv_reset) c->wv_n = 0;
+  }
+  return AHMC_OK;
+}
+
+}  // namespace
+
+#define FOR_CTX(ctx, ...)                                                                              \
+  do {                                                                                                 \
+    CtxBase* _b = reinterpret_cast<CtxBase*>(ctx);                                                     \
+    if (!_b) return AHMC_ERR_ARGUMENT;                                                                 \
+    (void)hipSetDevice(_b->device);                                                                    \
+    if (_b->dtype == AHMC_F32) { using T = float; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ }    \
+    else { using T = double; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ }                         \
+  } while (0)
+
+template <class T>
+static int32_t create_impl(int32_t device, int32_t dtype, int64_t D, int64_t N, void* stream, ahmc_ctx** out) {
+  auto* c = new Ctx<T>();
+  c->dtype = dtype;
+  c->device = device;
+  c->D = D;
+  c->N = N;
+  auto bail = [&](const std::string& m, int code) {
+    g_create_err = m;
+    delete c;
+    return code;
+  };
+  if (!pick_geometry(D, c->G, c->E))
+    return bail("ahmc_create: D > 256 has no HIP kernel geometry yet (workgroup-per-chain path is future work)", AHMC_ERR_UNSUPPORTED);
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e), AHMC_ERR_RUNTIME);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  if (stream) {
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e), AHMC_ERR_RUNTIME);
+    c->own_stream = true;
+  }
+  const size_t DN = (size_t)D * N, n = (size_t)N;
+  bool ok = true;
+  auto A = [&](auto** p, size_t cnt) {
+    if (ok && hipMalloc(reinterpret_cast<void**>(p), cnt * sizeof(**p)) != hipSuccess) ok = false;
+  };
+  A(&c->th, DN); A(&c->r, DN); A(&c->g, DN); A(&c->lp, n); A(&c->lk, n);
+  A(&c->eps_nom, n); A(&c->eps_cur, n);
+  A(&c->st_nsteps, n); A(&c->st_accept, n); A(&c->st_depth, n); A(&c->st_numerr, n);
+  A(&c->st_accrate, n); A(&c->st_logdens, n); A(&c->st_H, n); A(&c->st_Herr, n); A(&c->st_maxHerr, n);
+  A(&c->acc_nsteps, n); A(&c->acc_ndiv, n); A(&c->acc_sum, DN); A(&c->acc_sumsq, DN);
+  A(&c->queue, 64);
+  if (!ok) return bail("ahmc_create: hipMalloc failed (out of device memory?)", AHMC_ERR_RUNTIME);
+  (void)hipMemsetAsync(c->th, 0, sizeof(T) * DN, c->stream);
+  (void)hipMemsetAsync(c->r, 0, sizeof(T) * DN, c->stream);
+  (void)hipMemsetAsync(c->g, 0, sizeof(T) * DN, c->stream);
+  (void)hipMemsetAsync(c->st_nsteps, 0, sizeof(int32_t) * n, c->stream);
+  (void)hipMemsetAsync(c->st_accept, 0, sizeof(int32_t) * n, c->stream);
+  (void)hipMemsetAsync(c->st_depth, 0, sizeof(int32_t) * n, c->stream);
+  (void)hipMemsetAsync(c->st_numerr, 0, sizeof(int32_t) * n, c->stream);
+  T* fl[] = {c->st_accrate, c->st_logdens, c->st_H, c->st_Herr, c->st_maxHerr, c->lp, c->lk};
+  for (T* f : fl) (void)hipMemsetAsync(f, 0, sizeof(T) * n, c->stream);
+  hipLaunchKernelGGL((k_fill<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->eps_nom, T(0.1), (int64_t)n);
+  hipLaunchKernelGGL((k_fill<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->eps_cur, T(0.1), (int64_t)n);
+  (void)hipMemsetAsync(c->acc_nsteps, 0, sizeof(long long) * n, c->stream);
+  (void)hipMemsetAsync(c->acc_ndiv, 0, sizeof(long long) * n, c->stream);
+  (void)hipMemsetAsync(c->acc_sum, 0, sizeof(T) * DN, c->stream);
+  (void)hipMemsetAsync(c->acc_sumsq, 0, sizeof(T) * DN, c->stream);
+  e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return bail(std::string("ahmc_create: ") + hipGetErrorString(e), AHMC_ERR_RUNTIME);
+  *out = reinterpret_cast<ahmc_ctx*>(static_cast<CtxBase*>(c));
+  return AHMC_OK;
+}
+
+extern "C" {
+
+int32_t ahmc_abi_version(void) { return AHMC_ABI_VERSION; }
+const char* ahmc_backend(void) { return "hip:gfx950"; }
+
+int32_t ahmc_create(int32_t device, int32_t dtype, int64_t D, int64_t N, void* stream, ahmc_ctx** out) {
+  if (!out) { g_create_err = "ahmc_create: out is NULL"; return AHMC_ERR_ARGUMENT; }
+  if (D < 1 || N < 1) { g_create_err = "ahmc_create: D and N must be >= 1"; return AHMC_ERR_ARGUMENT; }
+  if (dtype == AHMC_F32) return create_impl<float>(device, dtype, D, N, stream, out);
+  if (dtype == AHMC_F64) return create_impl<double>(device, dtype, D, N, stream, out);
+  g_create_err = "ahmc_create: dtype must be AHMC_F32 or AHMC_F64";
+  return AHMC_ERR_ARGUMENT;
+}
+
+int32_t ahmc_destroy(ahmc_ctx* ctx) {
+  delete reinterpret_cast<CtxBase*>(ctx);
+  return AHMC_OK;
+}
+
+const char* ahmc_last_error(const ahmc_ctx* ctx) {
+  if (!ctx) return g_create_err.c_str();
+  return reinterpret_cast<const CtxBase*>(ctx)->err.c_str();
+}
+
+int32_t ahmc_sync(ahmc_ctx* ctx) {
+  FOR_CTX(ctx, { HIPCHK(hipStreamSynchronize(c->stream)); return AHMC_OK; });
+}
+
+void* ahmc_stream(ahmc_ctx* ctx) {
+  CtxBase* b = reinterpret_cast<CtxBase*>(ctx);
+  return b ? reinterpret_cast<void*>(b->stream) : nullptr;
+}
+
+int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params) {
+  FOR_CTX(ctx, {
+    int64_t need = 0;
+    switch (kind) {
+      case AHMC_TARGET_ISO_GAUSS: case AHMC_TARGET_FUNNEL: case AHMC_TARGET_HIER_GAUSS: case AHMC_TARGET_EXTERNAL: need = 0; break;
+      case AHMC_TARGET_DIAG_GAUSS: need = 2 * c->D; break;
+      case AHMC_TARGET_DENSE_GAUSS: need = c->D * c->D; break;
+      default: return fail(c, AHMC_ERR_ARGUMENT, "set_target: unknown target kind");
+    }
+    if (kind == AHMC_TARGET_FUNNEL && c->D < 2) return fail(c, AHMC_ERR_ARGUMENT, "funnel needs D >= 2");
+    if (kind == AHMC_TARGET_HIER_GAUSS && c->D < 3) return fail(c, AHMC_ERR_ARGUMENT, "hier_gauss needs D >= 3");
+    if (n_params != need || (need > 0 && !params)) return fail(c, AHMC_ERR_ARGUMENT, "set_target: wrong parameter count for this family");
+    if (c->tparams) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tparams)); c->tparams = nullptr; }
+    if (need > 0) {
+      int rc = dev_alloc(c, &c->tparams, (size_t)need);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(c->tparams, params, sizeof(T) * need, hipMemcpyDefault, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    c->target_kind = kind;
+    c->have_point = false;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n) {
+  FOR_CTX(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
+}
+
+int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
+  FOR_CTX(ctx, {
+    if (c->metric_kind != AHMC_METRIC_DIAG) return fail(c, AHMC_ERR_ARGUMENT, "get_metric: unit metric has no array");
+    if (n != c->minv_n) return fail(c, AHMC_ERR_ARGUMENT, "get_metric: size mismatch");
+    HIPCHK(hipMemcpyAsync(out, c->minv, sizeof(T) * n, hipMemcpyDefault, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_stepsize(ahmc_ctx* ctx, const void* eps, int64_t n) {
+  FOR_CTX(ctx, {
+    if (!eps || (n != 1 && n != c->N)) return fail(c, AHMC_ERR_ARGUMENT, "set_stepsize: need 1 or N step sizes");
+    if (n == 1) {
+      T v;
+      HIPCHK(hipMemcpy(&v, eps, sizeof(T), hipMemcpyDefault));
+      hipLaunchKernelGGL((k_fill<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->eps_nom, v, c->N);
+      HIPCHK(hipGetLastError());
+      c->eps_scalar_value = (double)v;
+    } else {
+      HIPCHK(hipMemcpyAsync(c->eps_nom, eps, sizeof(T) * n, hipMemcpyDefault, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->eps_cur, c->eps_nom, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->eps_scalar = (n == 1);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_get_stepsize(ahmc_ctx* ctx, void* out) {
+  FOR_CTX(ctx, {
+    HIPCHK(hipMemcpyAsync(out, c->eps_nom, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_integrator(ahmc_ctx* ctx, int32_t kind, double param) {
+  FOR_CTX(ctx, {
+    if (kind < AHMC_INTEGRATOR_LEAPFROG || kind > AHMC_INTEGRATOR_TEMPERED) return fail(c, AHMC_ERR_ARGUMENT, "set_integrator: unknown kind");
+    c->integ_kind = kind;
+    c->integ_param = param;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_seed(ahmc_ctx* ctx, uint64_t seed, uint64_t chain_offset, uint64_t chain_stride, uint64_t iteration) {
+  FOR_CTX(ctx, {
+    c->seed = seed; c->chain_offset = chain_offset; c->chain_stride = chain_stride; c->iteration = iteration;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r) {
+  FOR_CTX(ctx, {
+    if (!theta) return fail(c, AHMC_ERR_ARGUMENT, "set_position: theta is NULL");
+    int rc = check_builtin(c, "set_position");
+    if (rc) return rc;
+    const size_t nb = sizeof(T) * c->D * c->N;
+    HIPCHK(hipMemcpyAsync(c->th, theta, nb, hipMemcpyDefault, c->stream));
+    if (r) HIPCHK(hipMemcpyAsync(c->r, r, nb, hipMemcpyDefault, c->stream));
+    else HIPCHK(hipMemsetAsync(c->r, 0, nb, c->stream));
+    rc = launch_fill_caches(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_point = true;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_phasepoint(ahmc_ctx* ctx, const void* theta, const void* r, const void* lp, const void* grad) {
+  FOR_CTX(ctx, {
+    if (!theta || !r || !lp || !grad) return fail(c, AHMC_ERR_ARGUMENT, "set_phasepoint: NULL argument");
+    const size_t nb = sizeof(T) * c->D * c->N;
+    HIPCHK(hipMemcpyAsync(c->th, theta, nb, hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(c->r, r, nb, hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(c->g, grad, nb, hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(c->lp, lp, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+    int rc = launch_kinetic(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_point = true;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_get_phasepoint(ahmc_ctx* ctx, void* theta, void* r, void* lp, void* grad, void* lk) {
+  FOR_CTX(ctx, {
+    const size_t nb = sizeof(T) * c->D * c->N;
+    if (theta) HIPCHK(hipMemcpyAsync(theta, c->th, nb, hipMemcpyDefault, c->stream));
+    if (r) HIPCHK(hipMemcpyAsync(r, c->r, nb, hipMemcpyDefault, c->stream));
+    if (grad) HIPCHK(hipMemcpyAsync(grad, c->g, nb, hipMemcpyDefault, c->stream));
+    if (lp) HIPCHK(hipMemcpyAsync(lp, c->lp, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+    if (lk) HIPCHK(hipMemcpyAsync(lk, c->lk, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "refresh before set_position");
+    int rc = check_builtin(c, "refresh_momentum");
+    if (rc) return rc;
+    KP<T> p = make_kp(c);
+    p.refresh_alpha = (T)alpha;
+    with_geometry(c->G, c->E, [&](auto g, auto e) {
+      hipLaunchKernelGGL((k_refresh<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p);
+    });
+    HIPCHK(hipGetLastError());
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "leapfrog before set_position");
+    int rc = check_builtin(c, "leapfrog");
+    if (rc) return rc;
+    KP<T> p = make_kp(c);
+    p.n_steps = n_steps;
+    with_geometry(c->G, c->E, [&](auto g, auto e) {
+      hipLaunchKernelGGL((k_leapfrog<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p);
+    });
+    HIPCHK(hipGetLastError());
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "lf_pre before set_phasepoint");
+    KP<T> p = make_kp(c);
+    const int64_t DN = c->D * c->N;
+    hipLaunchKernelGGL((k_lf_pre<T>), dim3((unsigned)((DN + 255) / 256)), dim3(256), 0, c->stream, p, (int)fwd, i, n_steps);
+    HIPCHK(hipGetLastError());
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_lf_post(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps, const void* lp, const void* grad_neg) {
+  FOR_CTX(ctx, {
+    if (!lp || !grad_neg) return fail(c, AHMC_ERR_ARGUMENT, "lf_post: NULL argument");
+    const int64_t DN = c->D * c->N;
+    // stage the caller's arrays (host or device) through c->g / c->lp
+    hipPointerAttribute_t at;
+    const T* gsrc = static_cast<const T*>(grad_neg);
+    T* staged = nullptr;
+    bool on_device = hipPointerGetAttributes(&at, grad_neg) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    if (!on_device) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&staged), sizeof(T) * DN));
+      HIPCHK(hipMemcpyAsync(staged, grad_neg, sizeof(T) * DN, hipMemcpyDefault, c->stream));
+      gsrc = staged;
+    }
+    HIPCHK(hipMemcpyAsync(c->lp, lp, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+    KP<T> p = make_kp(c);
+    hipLaunchKernelGGL((k_lf_post<T>), dim3((unsigned)((DN + 255) / 256)), dim3(256), 0, c->stream, p, (int)fwd, i, n_steps, gsrc);
+    HIPCHK(hipGetLastError());
+    int rc = launch_kinetic(c);
+    if (staged) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(staged)); }
+    return rc;
+  });
+}
+
+void* ahmc_theta_ptr(ahmc_ctx* ctx) {
+  CtxBase* b = reinterpret_cast<CtxBase*>(ctx);
+  if (!b) return nullptr;
+  if (b->dtype == AHMC_F32) return static_cast<Ctx<float>*>(b)->th;
+  return static_cast<Ctx<double>*>(b)->th;
+}
+
+int32_t ahmc_hmc_transition(ahmc_ctx* ctx, int64_t L, double lambda, int32_t sampler) {
+  FOR_CTX(ctx, { return hmc_transition(c, L, lambda, sampler, 0.0, false); });
+}
+
+int32_t ahmc_nuts_transition(ahmc_ctx* ctx, int32_t max_depth, double delta_max, int32_t criterion, int32_t sampler) {
+  FOR_CTX(ctx, { return nuts_transition(c, max_depth, delta_max, criterion, sampler, 0.0, false); });
+}
+
+int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
+  FOR_CTX(ctx, {
+    if (!out) return fail(c, AHMC_ERR_ARGUMENT, "get_stat: out is NULL");
+    const void* src = nullptr;
+    size_t nb = sizeof(T) * c->N;
+    switch (field) {
+      case AHMC_STAT_N_STEPS: src = c->st_nsteps; nb = sizeof(int32_t) * c->N; break;
+      case AHMC_STAT_IS_ACCEPT: src = c->st_accept; nb = sizeof(int32_t) * c->N; break;
+      case AHMC_STAT_ACCEPTANCE_RATE: src = c->st_accrate; break;
+      case AHMC_STAT_LOG_DENSITY: src = c->st_logdens; break;
+      case AHMC_STAT_HAMILTONIAN_ENERGY: src = c->st_H; break;
+      case AHMC_STAT_HAMILTONIAN_ENERGY_ERROR: src = c->st_Herr; break;
+      case AHMC_STAT_MAX_HAMILTONIAN_ENERGY_ERROR: src = c->st_maxHerr; break;
+      case AHMC_STAT_TREE_DEPTH: src = c->st_depth; nb = sizeof(int32_t) * c->N; break;
+      case AHMC_STAT_NUMERICAL_ERROR: src = c->st_numerr; nb = sizeof(int32_t) * c->N; break;
+      case AHMC_STAT_STEP_SIZE: src = c->eps_cur; break;
+      case AHMC_STAT_NOM_STEP_SIZE: src = c->eps_nom; break;
+      default: return fail(c, AHMC_ERR_ARGUMENT, "get_stat: unknown field");
+    }
+    HIPCHK(hipMemcpyAsync(out, src, nb, hipMemcpyDefault, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
+  FOR_CTX(ctx, {
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "find_good_stepsize before set_position");
+    int rc = check_builtin(c, "find_good_stepsize");
+    if (rc) return rc;
+    KP<T> p = make_kp(c);
+    p.init_eps = (T)initial_step_size;
+    p.max_iters = max_n_iters;
+    T* out = c->eps_cur;
+    with_geometry(c->G, c->E, [&](auto g, auto e) {
+      hipLaunchKernelGGL((k_find_eps<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p, out);
+    });
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->eps_nom, c->eps_cur, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
+    c->eps_scalar = false;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t init_buffer, int32_t term_buffer, int32_t window_size) {
+  FOR_CTX(ctx, {
+    if (kind < AHMC_ADAPT_NONE || kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: unknown adaptor kind");
+    return adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
+  });
+}
+
+int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* alpha) {
+  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha)); });
+}
+
+int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size, int64_t n_adapts,
+                          int64_t* window_start, int64_t* window_end, int64_t* splits, int32_t cap, int32_t* n_splits) {
+  StanWindows w = stan_windows(init_buffer, term_buffer, window_size, n_adapts);
+  if (window_start) *window_start = w.window_start;
+  if (window_end) *window_end = w.window_end;
+  if (n_splits) *n_splits = (int32_t)w.splits.size();
+  if (splits)
+    for (int32_t k = 0; k < cap && k < (int32_t)w.splits.size(); ++k) splits[k] = w.splits[k];
+  return AHMC_OK;
+}
+
+int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup, void* samples_out) {
+  FOR_CTX(ctx, {
+    if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample: cfg is NULL");
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "sample before set_position");
+    if (drop_warmup && c->adapt_kind == AHMC_ADAPT_NONE)
+      return fail(c, AHMC_ERR_ARGUMENT, "Cannot drop warmup samples if there is no adaptation phase.");  // src/sampler.jl:172
+    T* so = static_cast<T*>(samples_out);
+    bool reset_done = false;
+    const size_t nb = sizeof(T) * c->D * c->N;
+    for (int64_t i = 1; i <= n_samples; ++i) {  // src/sampler.jl:182-228
+      const bool keep = !drop_warmup || i > n_adapts;
+      if (keep && !reset_done) {
+        int rc0 = reset_accum(c);
+        if (rc0) return rc0;
+        reset_done = true;
+      }
+      int rc = cfg->nuts ? nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, keep)
+                         : hmc_transition(c, cfg->L, cfg->lambda, cfg->sampler, cfg->refresh_alpha, keep);
+      if (rc) return rc;
+      rc = adapt(c, i, n_adapts);
+      if (rc) return rc;
+      if (keep) {
+        c->acc_ntrans += 1;
+        if (so) {
+          int64_t j = i - (drop_warmup ? n_adapts : 0);
+          HIPCHK(hipMemcpyAsync(so + (size_t)(j - 1) * c->D * c->N, c->th, nb, hipMemcpyDefault, c->stream));
+        }
+      }
+    }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transitions, int64_t* n_divergent, void* sum_theta, void* sumsq_theta) {
+  FOR_CTX(ctx, {
+    std::vector<long long> a((size_t)c->N), b((size_t)c->N);
+    HIPCHK(hipMemcpyAsync(a.data(), c->acc_nsteps, sizeof(long long) * c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(b.data(), c->acc_ndiv, sizeof(long long) * c->N, hipMemcpyDeviceToHost, c->stream));
+    const size_t nb = sizeof(T) * c->D * c->N;
+    if (sum_theta) HIPCHK(hipMemcpyAsync(sum_theta, c->acc_sum, nb, hipMemcpyDefault, c->stream));
+    if (sumsq_theta) HIPCHK(hipMemcpyAsync(sumsq_theta, c->acc_sumsq, nb, hipMemcpyDefault, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    long long s = 0, d = 0;
+    for (int64_t i = 0; i < c->N; ++i) { s += a[(size_t)i]; d += b[(size_t)i]; }
+    if (total_n_steps) *total_n_steps = s;
+    if (n_transitions) *n_transitions = c->acc_ntrans;
+    if (n_divergent) *n_divergent = d;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
+  FOR_CTX(ctx, { return reset_accum(c); });
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// ahmc_device.hpp — device-side building blocks of the chain-batched HMC/NUTS engine (gfx950).
+//
+// Thread mapping: a chain is owned by a *group* of G consecutive lanes of one
+// wave64 (G ∈ {4,8,16,32,64}); lane l of the group holds the E contiguous elements
+// d = l*E .. l*E+E-1 of every (D,) vector of its chain in registers.  G*E >= D; padded elements
+// are kept at exactly 0 (momentum/gradient) so they never contribute to a reduction.
+// All per-chain scalars (energies, weights, RNG draws, control flow) are computed redundantly
+// and bit-identically by every lane of the group, so control flow is uniform inside a group.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ahmc {
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based RNG.  Stream layout is the specification shared with the oracle:
+//   counter = (chain, iteration, purpose, slot), key = (seed_lo, seed_hi)
+// ------------------------------------------------------------------------------------------------
+enum : uint32_t { RNG_MOMENTUM = 0, RNG_TRANSITION = 1, RNG_JITTER = 2, RNG_FINDEPS = 3 };
+constexpr uint32_t COUPLED_CHAIN = 0xFFFFFFFFu;
+
+struct Philox4 {
+  uint32_t v[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+
+// 53-bit uniform in the open interval (0,1)
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+  uint64_t bits = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
+  return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+struct Rng {
+  uint32_t k0, k1, chain, iter;
+  __device__ __forceinline__ Philox4 raw(uint32_t purpose, uint32_t slot) const {
+    return philox4x32_10(chain, iter, purpose, slot, k0, k1);
+  }
+  __device__ __forceinline__ double uniform(uint32_t purpose, uint32_t slot) const {
+    Philox4 p = raw(purpose, slot);
+    return u53(p.v[0], p.v[1]);
+  }
+  __device__ __forceinline__ bool boolean(uint32_t purpose, uint32_t slot) const {
+    return (raw(purpose, slot).v[0] >> 31) != 0;
+  }
+  __device__ __forceinline__ double randexp(uint32_t purpose, uint32_t slot) const {
+    return -log(uniform(purpose, slot));
+  }
+  // Box–Muller pair `pair` → (z0, z1) = standard normals of elements 2*pair, 2*pair+1
+  __device__ __forceinline__ void normal_pair(uint32_t purpose, uint32_t pair, double& z0, double& z1) const {
+    Philox4 p = raw(purpose, pair);
+    double u1 = u53(p.v[0], p.v[1]), u2 = u53(p.v[2], p.v[3]);
+    double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(6.283185307179586476925286766559 * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+  }
+};
+
+// E standard normals for the elements d0 .. d0+E-1 owned by this lane
+template <class T, int E>
+__device__ __forceinline__ void normals(const Rng& rng, uint32_t purpose, int d0, T (&z)[E]) {
+  if constexpr (E == 1) {
+    double a, b;
+    rng.normal_pair(purpose, (uint32_t)d0 >> 1, a, b);
+    z[0] = (T)((d0 & 1) ? b : a);
+  } else {
+    static_assert(E % 2 == 0, "E must be 1 or even");
+#pragma unroll
+    for (int e = 0; e < E; e += 2) {
+      double a, b;
+      rng.normal_pair(purpose, (uint32_t)(d0 + e) >> 1, a, b);
+      z[e] = (T)a;
+      z[e + 1] = (T)b;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// numerics helpers that must follow Julia semantics (NaN-propagating min/max; LogExpFunctions)
+// ------------------------------------------------------------------------------------------------
+template <class T> struct Lim;
+template <> struct Lim<float> {
+  static __device__ __forceinline__ float inf() { return __int_as_float(0x7f800000); }
+  static __device__ __forceinline__ float nan() { return __int_as_float(0x7fc00000); }
+};
+template <> struct Lim<double> {
+  static __device__ __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+  static __device__ __forceinline__ double nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+};
+
+template <class T> __device__ __forceinline__ T jl_min(T a, T b) { return (a != a || b != b) ? Lim<T>::nan() : (a < b ? a : b); }
+template <class T> __device__ __forceinline__ T jl_max(T a, T b) { return (a != a || b != b) ? Lim<T>::nan() : (a > b ? a : b); }
+template <class T> __device__ __forceinline__ bool is_finite(T v) { return isfinite(v); }
+// PhasePoint constructor: non-finite ℓπ/ℓκ values become -Inf (src/hamiltonian.jl:95-104)
+template <class T> __device__ __forceinline__ T sanitize(T v) { return is_finite(v) ? v : -Lim<T>::inf(); }
+// LogExpFunctions.logaddexp (src/trajectory.jl:192,198)
+template <class T> __device__ __forceinline__ T logaddexp(T x, T y) {
+  T d = (x == y) ? T(0) : fabs(x - y);
+  return jl_max(x, y) + log1p(exp(-d));
+}
+template <class T> __device__ __forceinline__ T maxabs(T a, T b) { return fabs(a) > fabs(b) ? a : b; }  // :526
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane primitives inside a group of G lanes.  Butterfly all-reduce built from DPP
+// (quad_perm / row_half_mirror / row_mirror), ds_swizzle (xor 16) and v_permlane32_swap (xor 32):
+// no LDS traffic, no address VGPRs.  Every lane of the group ends with the same bits.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(dpp_i32<CTRL>(__float_as_int(v)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(dpp_i32<CTRL>(hi), dpp_i32<CTRL>(lo));
+}
+// partner = lane ^ 16 inside each half-wave (ds_swizzle bit-mode: and=0x1f, or=0, xor=0x10)
+__device__ __forceinline__ float swz16(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
+__device__ __forceinline__ double swz16(double v) {
+  int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+  int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+  return __hiloint2double(hi, lo);
+}
+// own + value of lane ^ 32.  v_permlane32_swap swaps lanes [63:32] of its first operand with
+// lanes [31:0] of its second; with both = v the returned pair is {own, partner} for lanes < 32
+// and {partner, own} for lanes >= 32, so p[0] + p[1] is the same sum, bit for bit, in both.
+__device__ __forceinline__ float xor32_sum(float v) {
+  auto p = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(p[0]) + __int_as_float(p[1]);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+  auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// all-reduce (sum) of K independent values across the G lanes of each group
+template <int G, class T, int K>
+__device__ __forceinline__ void group_allsum(T (&v)[K]) {
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group size");
+  if constexpr (G >= 2) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_mov<0xB1>(v[k]);  // quad_perm [1,0,3,2]
+  }
+  if constexpr (G >= 4) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x4E>(v[k]);  // quad_perm [2,3,0,1]
+  }
+  if constexpr (G >= 8) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x141>(v[k]);  // row_half_mirror
+  }
+  if constexpr (G >= 16) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x140>(v[k]);  // row_mirror
+  }
+  if constexpr (G >= 32) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += swz16(v[k]);
+  }
+  if constexpr (G >= 64) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = xor32_sum(v[k]);
+  }
+}
+template <int G, class T>
+__device__ __forceinline__ T group_sum1(T x) {
+  T v[1] = {x};
+  group_allsum<G>(v);
+  return v[0];
+}
+
+// broadcast the value held by lane `src` (0..G-1) of the group to the whole group
+template <int G>
+__device__ __forceinline__ int group_bcast_i32(int v, int src) {
+  int base = (int)(__lane_id() & ~(unsigned)(G - 1));
+  return __builtin_amdgcn_ds_bpermute((base + src) << 2, v);
+}
+template <int G> __device__ __forceinline__ float group_bcast(float v, int src) {
+  return __int_as_float(group_bcast_i32<G>(__float_as_int(v), src));
+}
+template <int G> __device__ __forceinline__ double group_bcast(double v, int src) {
+  return __hiloint2double(group_bcast_i32<G>(__double2hiint(v), src), group_bcast_i32<G>(__double2loint(v), src));
+}
+
+// ------------------------------------------------------------------------------------------------
+// built-in log-density families (include/ahmc_hip.h AHMC_TARGET_*).  `grad` receives the
+// reference's cached gradient -∇ℓπ (src/hamiltonian.jl:45-48).  The return value is this lane's
+// PARTIAL of ℓπ: the caller sums it over the group together with the kinetic partial, so the
+// common Gaussian case costs one butterfly per leapfrog step.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct TargetP {
+  int kind;
+  int D;
+  const T* params;
+};
+
+#define AHMC_LOG2PI 1.8378770664093454835606594728112
+
+template <class T, int G, int E>
+__device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E], T (&grad)[E], int lane, int d0) {
+  const T log2pi = (T)AHMC_LOG2PI;
+  const int D = tp.D;
+  T part = 0;
+  switch (tp.kind) {
+    case 0: {  // AHMC_TARGET_ISO_GAUSS (test/common.jl:40-44, m = 0, s = 1)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        bool ok = d0 + e < D;
+        part += ok ? -(log2pi + th[e] * th[e]) / 2 : T(0);
+        grad[e] = ok ? th[e] : T(0);
+      }
+      break;
+    }
+    case 1: {  // AHMC_TARGET_DIAG_GAUSS: params = m[D], s[D]
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        bool ok = d0 + e < D;
+        T m = ok ? tp.params[d0 + e] : T(0);
+        T s = ok ? tp.params[D + d0 + e] : T(1);
+        T diff = m - th[e];
+        T s2 = s * s;
+        part += ok ? -(log2pi + 2 * log(s) + diff * diff / s2) / 2 : T(0);
+        grad[e] = ok ? -(diff / s2) : T(0);
+      }
+      break;
+    }
+    case 2: {  // AHMC_TARGET_FUNNEL (research/notebooks/geweke_test.ipynb cell 4)
+      T y = group_bcast<G>(th[0], 0);
+      T ssp = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        int d = d0 + e;
+        ssp += (d >= 1 && d < D) ? th[e] * th[e] : T(0);
+      }
+      T ss = group_sum1<G>(ssp);
+      T ey = exp(-y);
+      T nm1 = (T)(D - 1);
+      T total = -(log2pi + 2 * log(T(3)) + y * y / 9) / 2 - nm1 * (log2pi + y) / 2 - ss * ey / 2;
+      part = (lane == 0) ? total : T(0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        int d = d0 + e;
+        T gv = (d == 0) ? -(-y / 9 - nm1 / 2 + ss * ey / 2) : th[e] * ey;
+        grad[e] = (d < D) ? gv : T(0);
+      }
+      break;
+    }
+    case 3: {  // AHMC_TARGET_HIER_GAUSS: θ = (μ, log τ, x...)
+      T mu = group_bcast<G>(th[0], 0);
+      T lt = (E >= 2) ? group_bcast<G>(th[E >= 2 ? 1 : 0], 0) : group_bcast<G>(th[0], 1);
+      T s[2] = {0, 0};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        int d = d0 + e;
+        T df = th[e] - mu;
+        bool ok = d >= 2 && d < D;
+        s[0] += ok ? df : T(0);
+        s[1] += ok ? df * df : T(0);
+      }
+      group_allsum<G>(s);
+      T itau2 = exp(-2 * lt);
+      T n = (T)(D - 2);
+      T total = -(log2pi + mu * mu) / 2 - (log2pi + lt * lt) / 2 - n * (log2pi + 2 * lt) / 2 - s[1] * itau2 / 2;
+      part = (lane == 0) ? total : T(0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        int d = d0 + e;
+        T gv;
+        if (d == 0) gv = -(-mu + s[0] * itau2);
+        else if (d == 1) gv = -(-lt - n + s[1] * itau2);
+        else gv = (th[e] - mu) * itau2;
+        grad[e] = (d < D) ? gv : T(0);
+      }
+      break;
+    }
+    default: {
+#pragma unroll
+      for (int e = 0; e < E; ++e) grad[e] = Lim<T>::nan();
+      part = Lim<T>::nan();
+    }
+  }
+  return part;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-chain phase point in registers and one leapfrog step (src/integrator.jl:233-243)
+// ------------------------------------------------------------------------------------------------
+template <class T, int E>
+struct Point {
+  T th[E], r[E], g[E];  // θ, r, -∇ℓπ(θ)
+  T lp, lk;             // ℓπ(θ), ℓκ = -K(r)  (sanitised)
+};
+
+template <class T, int E>
+__device__ __forceinline__ void copy_vec(T (&dst)[E], const T (&src)[E]) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) dst[e] = src[e];
+}
+
+template <class T> struct LeapfrogP {
+  int kind;       // AHMC_INTEGRATOR_*
+  T sqrt_alpha;   // TemperedLeapfrog: sqrt(α)
+};
+
+// temper(lf, r, (i, is_half), n_steps) (src/integrator.jl:198-209)
+template <class T, int E>
+__device__ __forceinline__ void temper(const LeapfrogP<T>& lf, T (&r)[E], int64_t i, bool is_half, int64_t n_steps) {
+  if (lf.kind != 2) return;
+  int64_t i_temper = 2 * (i - 1) + 1 + (is_half ? 0 : 1);
+  if (i_temper <= n_steps) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = r[e] * lf.sqrt_alpha;
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = r[e] / lf.sqrt_alpha;
+  }
+}
+
+// kinetic partial: Σ_e M⁻¹ r² over this lane's elements (Unit: minv = 1)
+template <class T, int E>
+__device__ __forceinline__ T kinetic_partial(const T (&r)[E], const T (&minv)[E]) {
+  T s = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) s += (r[e] * r[e]) * minv[e];
+  return s;
+}
+
+// One leapfrog step of step i of n (tempering indices) with signed step size eps:
+//   r -= ϵ/2 g ; θ += ϵ M⁻¹ r ; (ℓπ, g) = ∂H∂θ(θ) ; r -= ϵ/2 g ; ℓκ = -½ rᵀM⁻¹r ; sanitise
+template <class T, int G, int E>
+__device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp,
+                                              const LeapfrogP<T>& lf, int lane, int d0, int64_t i, int64_t n) {
+  temper(lf, z.r, i, true, n);
+  const T eh = eps / 2;
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
+  T red[2];
+  red[0] = target_eval<T, G, E>(tp, z.th, z.g, lane, d0);
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+  temper(lf, z.r, i, false, n);
+  red[1] = kinetic_partial(z.r, minv);
+  group_allsum<G>(red);
+  z.lp = sanitize(red[0]);
+  z.lk = sanitize(-red[1] / 2);
+}
+
+// phasepoint(h, θ, r): fill the caches at the current (θ, r) (src/hamiltonian.jl:115-119)
+template <class T, int G, int E>
+__device__ __forceinline__ void fill_caches(Point<T, E>& z, const T (&minv)[E], const TargetP<T>& tp, int lane, int d0) {
+  T red[2];
+  red[0] = target_eval<T, G, E>(tp, z.th, z.g, lane, d0);
+  red[1] = kinetic_partial(z.r, minv);
+  group_allsum<G>(red);
+  z.lp = sanitize(red[0]);
+  z.lk = sanitize(-red[1] / 2);
+}
+
+// vector load/store of one chain's slice: element d0+e of chain c lives at base[off + d0 + e].
+// Full, 16-byte aligned lanes use dwordx4/dwordx2 accesses (CH elements per access).
+template <class T, int E>
+__device__ __forceinline__ void load_vec(T (&v)[E], const T* __restrict__ base, int64_t off, int d0, int D, T pad) {
+  constexpr int CH = (E * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : E;
+  const T* ptr = base + off + d0;
+  if (CH > 1 && d0 + E <= D && (reinterpret_cast<uintptr_t>(ptr) % (CH * sizeof(T)) == 0)) {
+    using V = T __attribute__((ext_vector_type(CH)));
+#pragma unroll
+    for (int e = 0; e < E; e += CH) {
+      V t = *reinterpret_cast<const V*>(ptr + e);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) v[e + k] = t[k];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = (d0 + e < D) ? ptr[e] : pad;
+  }
+}
+template <class T, int E>
+__device__ __forceinline__ void store_vec(const T (&v)[E], T* __restrict__ base, int64_t off, int d0, int D) {
+  constexpr int CH = (E * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : E;
+  T* ptr = base + off + d0;
+  if (CH > 1 && d0 + E <= D && (reinterpret_cast<uintptr_t>(ptr) % (CH * sizeof(T)) == 0)) {
+    using V = T __attribute__((ext_vector_type(CH)));
+#pragma unroll
+    for (int e = 0; e < E; e += CH) {
+      V t;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) t[k] = v[e + k];
+      *reinterpret_cast<V*>(ptr + e) = t;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (d0 + e < D) ptr[e] = v[e];
+  }
+}
+
+}  // namespace ahmc

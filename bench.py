@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py — leapfrog-steps/sec of the chain-batched NUTS hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): D=128 isotropic Gaussian,
+DiagEuclideanMetric (per-chain M⁻¹), NUTS(δ=0.8) = MultinomialTS + GeneralisedNoUTurn(max_depth
+10, Δ_max 1000) with StanHMCAdaptor, 65 536 chains per GPU, Float64, synthetic θ0 ~ U(0,1).
+
+A "step" is ONE NUTS transition of all chains (one launch of k_nuts).  Setup (untimed):
+find_good_stepsize + `--adapt` Stan-adaptation transitions.  Then W warm-up steps and exactly K
+timed steps, bracketed by barrier + synchronize; MAX over ranks; rank 0 prints one JSON line.
+`value` = Σ n_steps over all chains and ranks in the timed region ÷ that time.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); chains shard with no
+data-path collective (weak scaling, 65 536 chains per GPU, Philox chain offset = rank·N); the
+only collectives are the timing reductions and the final gather of per-dimension moments.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md chip table)
+
+
+def algorithmic_bytes_per_leapfrog(D, diag, itemsize):
+    """B_lf = (6·D + D_M)·sizeof(T) + 4·sizeof(T)"""
+    return (6 * D + (D if diag else 0)) * itemsize + 4 * itemsize
+
+
+def build_engine(A, lib, D, N, seed, chain_offset, stream=0, device=0):
+    metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    eng = A.Engine(h, N, dtype=np.float64, rng=A.PhiloxRNG(seed, chain_offset), lib=lib, device=device, stream=stream)
+    lf = A.Leapfrog(np.full(N, 0.1))
+    eng.set_integrator(lf)
+    th0 = np.random.default_rng(seed + chain_offset).random((D, N))
+    eng.set_position(np.asfortranarray(th0))
+    eng.find_good_stepsize()
+    eng.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)))
+    kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+    return eng, kernel
+
+
+def cpu_baseline(A, D, n_adapt, steps, seed, chains):
+    """The CPU oracle (scalar restatement of the reference, OpenMP over chains) on a bounded
+    sample of the same workload, timed on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_oracle  # test infrastructure: used here only as the timed CPU baseline
+
+    lib = A.CLib(build_oracle.build())
+    eng, kernel = build_engine(A, lib, D, chains, seed, 0)
+    eng.run(kernel, n_adapt, n_adapt)
+    eng.run(kernel, 1, 0)
+    t0 = time.perf_counter()
+    eng.run(kernel, steps, 0)
+    dt = time.perf_counter() - t0
+    acc = eng.accum(moments=False)
+    eng.close()
+    return acc["total_n_steps"] / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--adapt", type=int, default=200, help="untimed Stan adaptation transitions")
+    ap.add_argument("--seed", type=int, default=0x5EED0002)
+    ap.add_argument("--cpu-chains", type=int, default=0, help="0 = 128 per host core, capped at --chains")
+    ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ahmc_amd as A
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    lib = A.load_hip_library()  # raises if the HIP engine is not built: no fallback
+    D, N = args.dim, args.chains
+    stream = torch.cuda.Stream(device=local_rank)
+    eng, kernel = build_engine(A, lib, D, N, args.seed, rank * N, stream=stream.cuda_stream, device=local_rank)
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # setup (untimed): adaptation, then W warm-up steps in the sampling phase
+    eng.run(kernel, args.adapt, args.adapt)
+    if args.warmup > 0:
+        eng.run(kernel, args.warmup, 0)
+    barrier()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    eng.run(kernel, args.steps, 0)  # K transitions, accumulators reset at the first one
+    ev1.record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1)
+
+    acc = eng.accum(moments=True)
+    n_leap = acc["total_n_steps"]
+    tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tn = torch.tensor([float(n_leap), float(acc["n_divergent"])], dtype=torch.float64, device=f"cuda:{local_rank}")
+    # per-dimension pooled moments of this shard; gathered over RCCL at the end
+    n_draws = acc["n_transitions"] * N
+    mom = torch.tensor(np.stack([acc["sum_theta"].sum(axis=1), acc["sumsq_theta"].sum(axis=1)]) / n_draws,
+                       dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        gathered = [torch.empty_like(mom) for _ in range(world)]
+        dist.all_gather(gathered, mom)
+        mom = torch.stack(gathered).mean(dim=0)
+    dt_max = float(tt.item())
+    total_leap = float(tn[0].item())
+    mean = mom[0].cpu().numpy()
+    var = mom[1].cpu().numpy() - mean ** 2
+
+    if rank == 0:
+        B_lf = algorithmic_bytes_per_leapfrog(D, True, 8)
+        per_launch_s = (kernel_ms / 1e3) / args.steps
+        achieved = (n_leap / args.steps) * B_lf / per_launch_s / 1e9  # this rank's dominant kernel
+        out = {
+            "metric": "leapfrog-steps/sec (whole node) at n_chains x D",
+            "value": total_leap / dt_max,
+            "unit": "leapfrog-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cfg2: D={D} iso Gaussian, DiagEuclideanMetric per-chain, NUTS(0.8) MultinomialTS+GeneralisedNoUTurn "
+                            f"max_depth 10, StanHMCAdaptor ({args.adapt} untimed adaptation steps), {N} chains/GPU",
+                "chains_per_gpu": N, "D": D, "parallelism": f"chain-shard x{world}",
+                "mean_leapfrogs_per_transition": total_leap / (args.steps * N * world),
+                "divergent": float(tn[1].item()),
+                "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_nuts<double,64,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_leapfrog": B_lf, "avg_launch_ms": per_launch_s * 1e3,
+            },
+        }
+        if not args.no_cpu_baseline:
+            try:
+                cores = os.cpu_count() or 1
+                # bounded sample sized to the host: 128 chains per core (capped at the GPU's own N),
+                # the same adaptation, then `cpu_steps` timed sampling transitions (~10-20 s in all)
+                cpu_chains = args.cpu_chains or min(N, 128 * cores)
+                cpu_steps = args.cpu_steps
+                t_all = time.perf_counter()
+                v, cdt = cpu_baseline(A, D, args.adapt, cpu_steps, args.seed, cpu_chains)
+                out["cpu_baseline"] = {
+                    "value": v, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+                    "sample": f"{cpu_chains} chains x D={D}, same kernel/adaptor, {cpu_steps} timed transitions "
+                              f"({cdt:.1f} s) after {args.adapt} adaptation steps ({time.perf_counter() - t_all:.1f} s in all); "
+                              "C++ restatement of the reference (oracle/), OpenMP over chains on all host cores, not Julia",
+                }
+            except Exception as ex:  # the baseline leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

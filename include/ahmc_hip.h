@@ -211,9 +211,12 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
  * window_size) = (75, 50, 25) for Stan (stan_adaptor.jl:94-103).                             */
 int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t init_buffer,
                           int32_t term_buffer, int32_t window_size);
-/* adapt!(h, κ, adaptor, i, n_adapts, z, α) (src/sampler.jl:72-90): uses the last transition's
- * acceptance_rate and position; updates metric and nominal step size in place.               */
-int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts);
+/* adapt!(h, κ, adaptor, i, n_adapts, θ, α) (src/sampler.jl:72-90): updates the adaptor, the
+ * metric and the nominal step size in place.  theta (D,N) / alpha T[N] are the position and the
+ * acceptance rate to adapt on; NULL means "the context's current θ" / "the last transition's
+ * acceptance_rate" (what the sample loop passes, src/sampler.jl:187).                        */
+int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta,
+                   const void* alpha);
 /* Stan window schedule for n_adapts (stan_adaptor.jl:13-50): writes up to cap split points,
  * returns their count in *n_splits and the window start/end.  Pure host logic.               */
 int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size,

@@ -1077,9 +1077,9 @@ void da_reset(Ctx<T>* c) {  // reset!(das) (src/adaptation/stepsize.jl:40-53)
 }
 
 template <class T>
-void da_adapt(Ctx<T>* c) {  // adapt_stepsize! (src/adaptation/stepsize.jl:178-210), per chain
+void da_adapt(Ctx<T>* c, const T* alpha_ext = nullptr) {  // adapt_stepsize! (src/adaptation/stepsize.jl:178-210), per chain
   for (int64_t i = 0; i < c->N; ++i) {
-    T alpha = c->stat[i].acceptance_rate;
+    T alpha = alpha_ext ? alpha_ext[i] : c->stat[i].acceptance_rate;
     int32_t m = c->da_m[i] + 1;
     T eta_H = T(1) / (T(m) + c->da_t0);
     T Hbar = (T(1) - eta_H) * c->da_Hbar[i] + eta_H * (c->da_delta - jl_min(T(1), alpha));
@@ -1103,11 +1103,11 @@ void wv_reset(Ctx<T>* c) {  // reset!(wv) (src/adaptation/massmatrix.jl:133-138)
 }
 
 template <class T>
-void wv_push(Ctx<T>* c) {  // push! (:141-149)
+void wv_push(Ctx<T>* c, const T* th_ext = nullptr) {  // push! (:141-149)
   c->wv_n += 1;
   T n = T(c->wv_n);
   for (int64_t k = 0; k < c->D * c->N; ++k) {
-    T delta = c->th[k] - c->wv_mu[k];
+    T delta = (th_ext ? th_ext[k] : c->th[k]) - c->wv_mu[k];
     c->wv_mu[k] = c->wv_mu[k] + delta / n;
     c->wv_M[k] = c->wv_M[k] + delta * delta * ((n - 1) / n);
   }
@@ -1121,7 +1121,7 @@ void wv_update(Ctx<T>* c) {  // update! (:60-62) + get_estimation (:152-157)
 }
 
 template <class T>
-int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts) {  // src/sampler.jl:72-90
+int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr) {  // src/sampler.jl:72-90
   if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
   const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
   const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
@@ -1130,11 +1130,11 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts) {  // src/sampler.jl:72-90
   }
   if (c->adapt_kind == AHMC_ADAPT_STAN) {  // adapt!(tp::StanHMCAdaptor, ...) (:137-159)
     c->stan_i += 1;
-    da_adapt(c);
+    da_adapt(c, alpha_ext);
     bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
     bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
     if (in_window && has_mm) {
-      wv_push(c);
+      wv_push(c, th_ext);
       if (window_end) wv_update(c);
     }
     if (window_end) {
@@ -1142,8 +1142,8 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts) {  // src/sampler.jl:72-90
       if (has_mm) wv_reset(c);
     }
   } else {
-    if (has_ss) da_adapt(c);        // NaiveHMCAdaptor: ssa then pc (Adaptation.jl:52-60)
-    if (has_mm) { wv_push(c); wv_update(c); }
+    if (has_ss) da_adapt(c, alpha_ext);  // NaiveHMCAdaptor: ssa then pc (Adaptation.jl:52-60)
+    if (has_mm) { wv_push(c, th_ext); wv_update(c); }
   }
   if (i == n_adapts && has_ss) {  // finalize! (stepsize.jl:55-62): ϵ = exp(x̄)
     for (int64_t k = 0; k < c->N; ++k) c->da_eps[k] = std::exp(c->da_xbar[k]);
@@ -1481,8 +1481,8 @@ int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t ini
   });
 }
 
-int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts) {
-  FOR_CTX(ctx, { return adapt(c, i, n_adapts); });
+int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* alpha) {
+  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha)); });
 }
 
 int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size, int64_t n_adapts,

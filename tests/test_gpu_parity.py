@@ -1,0 +1,468 @@
+"""GPU parity: HIP engine (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star: "within a stated fp tolerance"):
+  Float64: 1e-9 relative on energies/positions after a transition (the two sides differ only by
+           FMA contraction and libm-vs-ocml last-ulp differences in log/exp/sincos); discrete
+           statistics (n_steps, tree_depth, is_accept) must agree on >= 99.9 % of chains.
+  Float32: 2e-3 relative on single leapfrog trajectories; discrete statistics >= 90 % per
+           transition (decisions sit within 1e-7 of a tie far more often), plus moment checks.
+"""
+import numpy as np
+import pytest
+
+import ahmc_amd as A
+
+pytestmark = pytest.mark.gpu
+
+RTOL = {np.float64: 1e-9, np.float32: 2e-3}
+ATOL = {np.float64: 1e-9, np.float32: 2e-3}
+
+
+def make_target(name, D, rng):
+    if name == "iso":
+        return A.IsoGaussian(D)
+    if name == "diag":
+        return A.DiagGaussian(rng.normal(size=D), 0.5 + rng.random(D))
+    if name == "funnel":
+        return A.Funnel(D)
+    if name == "hier":
+        return A.HierGaussian(D)
+    raise KeyError(name)
+
+
+def make_metric(name, D, N, rng):
+    if name == "unit":
+        return A.UnitEuclideanMetric((D, N))
+    if name == "diag_shared":
+        return A.DiagEuclideanMetric(0.5 + rng.random(D))
+    return A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+
+
+def pair(hip, oracle, h, N, dtype, seed=7, eps=None, lf=None):
+    engines = []
+    for lib in (hip, oracle):
+        e = A.Engine(h, N, dtype=dtype, rng=seed, lib=lib)
+        if lf is not None:
+            e.set_integrator(lf)
+        elif eps is not None:
+            e.set_integrator(A.Leapfrog(eps))
+        engines.append(e)
+    return engines
+
+
+def assert_points_close(zg, zo, dtype, what=""):
+    rt, at = RTOL[dtype], ATOL[dtype]
+    np.testing.assert_allclose(zg.theta, zo.theta, rtol=rt, atol=at, err_msg=what + " theta")
+    np.testing.assert_allclose(zg.r, zo.r, rtol=rt, atol=at, err_msg=what + " r")
+    np.testing.assert_allclose(zg.lp.gradient, zo.lp.gradient, rtol=rt, atol=at, err_msg=what + " grad")
+    np.testing.assert_allclose(zg.lp.value, zo.lp.value, rtol=rt, atol=at * 10, err_msg=what + " lp")
+    np.testing.assert_allclose(zg.lk.value, zo.lk.value, rtol=rt, atol=at * 10, err_msg=what + " lk")
+
+
+GEOM_D = [3, 5, 10, 24, 32, 50, 100, 128, 200]  # one D per thread geometry (G,E)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("D", GEOM_D)
+def test_phasepoint_and_leapfrog_all_geometries(hip, oracle, rng, dtype, D):
+    """phasepoint(h, θ, r) and step(lf, h, z, n) (src/hamiltonian.jl:115-119, src/integrator.jl:216-265)"""
+    N = 37
+    h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), A.IsoGaussian(D))
+    g, o = pair(hip, oracle, h, N, dtype, eps=0.05 + 0.1 * rng.random(N))
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th, r)
+    assert_points_close(g.phasepoint(), o.phasepoint(), dtype, "phasepoint")
+    for n in (7, -4):
+        for e in (g, o):
+            e.step(n)
+        assert_points_close(g.phasepoint(), o.phasepoint(), dtype, f"step({n})")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("target", ["iso", "diag", "funnel", "hier"])
+@pytest.mark.parametrize("metric", ["unit", "diag_shared", "diag_chain"])
+def test_targets_and_metrics(hip, oracle, rng, dtype, target, metric):
+    """∂H∂θ for every built-in family, ∂H∂r / neg_energy for Unit and Diag (src/hamiltonian.jl:45-68,155-177)"""
+    D, N = 10, 64
+    h = A.Hamiltonian(make_metric(metric, D, N, rng), make_target(target, D, rng))
+    g, o = pair(hip, oracle, h, N, dtype, eps=0.02)
+    th, r = 0.5 * rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th, r)
+        e.step(5)
+    assert_points_close(g.phasepoint(), o.phasepoint(), dtype, f"{target}/{metric}")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_step_loop_equals_step_n(hip, dtype, rng):
+    """test/integrator.jl:17-32: step looped 10x == step(.., 10) (DETATOL 5e-3; here exact)"""
+    D, N = 5, 16
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
+    a = A.Engine(h, N, dtype=dtype, lib=hip)
+    b = A.Engine(h, N, dtype=dtype, lib=hip)
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for e in (a, b):
+        e.set_integrator(A.Leapfrog(0.1))
+        e.set_position(th, r)
+    for _ in range(10):
+        a.step(1)
+    b.step(10)
+    za, zb = a.phasepoint(), b.phasepoint()
+    np.testing.assert_array_equal(za.theta, zb.theta)
+    np.testing.assert_array_equal(za.r, zb.r)
+
+
+def test_harmonic_oscillator(hip):
+    """test/integrator.jl:108-153: 1-D harmonic oscillator, ϵ=0.01, radius and H within 2e-3 of their mean"""
+    h = A.Hamiltonian(A.UnitEuclideanMetric((1, 4)), A.DiagGaussian([0.0], [1.0]))
+    e = A.Engine(h, 4, lib=hip)
+    e.set_integrator(A.Leapfrog(0.01))
+    q0 = np.random.default_rng(1).normal(size=(1, 4))
+    p0 = np.random.default_rng(2).normal(size=(1, 4))
+    e.set_position(q0, p0)
+    rs, Hs = [], []
+    for i in range(2000):
+        e.step(5)
+        z = e.phasepoint()
+        rs.append(np.sqrt(z.theta[0] ** 2 + z.r[0] ** 2))
+        Hs.append(-(z.lp.value + z.lk.value))
+    rs, Hs = np.array(rs)[200:], np.array(Hs)[200:]
+    assert np.all(np.abs(rs - rs.mean(axis=0)) < 2e-3)
+    assert np.all(np.abs(Hs - Hs.mean(axis=0)) < 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("metric", ["unit", "diag_chain"])
+def test_refresh_momentum(hip, oracle, rng, dtype, metric):
+    """rand_momentum + refresh (src/metric.jl:290-309, src/hamiltonian.jl:213-220): same Philox stream"""
+    D, N = 10, 50
+    h = A.Hamiltonian(make_metric(metric, D, N, rng), A.IsoGaussian(D))
+    g, o = pair(hip, oracle, h, N, dtype, seed=99)
+    th = rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+        e.refresh()
+    assert_points_close(g.phasepoint(), o.phasepoint(), dtype, "refresh")
+    # partial refreshment (src/hamiltonian.jl:243-254)
+    for e in (g, o):
+        e.refresh(A.PartialMomentumRefreshment(0.3))
+    assert_points_close(g.phasepoint(), o.phasepoint(), dtype, "partial refresh")
+
+
+def test_tempered_and_jittered(hip, oracle, rng):
+    """TemperedLeapfrog / JitteredLeapfrog (src/integrator.jl:140-156, :198-209)"""
+    D, N = 5, 32
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
+    g, o = pair(hip, oracle, h, N, np.float64, lf=A.TemperedLeapfrog(0.1, 1.05))
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th, r)
+        e.step(7)
+    assert_points_close(g.phasepoint(), o.phasepoint(), np.float64, "tempered")
+    k = A.HMCKernel(A.Trajectory(A.EndPointTS, A.JitteredLeapfrog(np.full(N, 0.1), 0.5), A.FixedNSteps(5)))
+    g, o = pair(hip, oracle, h, N, np.float64, lf=k.tau.integrator)
+    for e in (g, o):
+        e.set_position(th)
+        e.transition(k)
+    sg, so = g.stats(), o.stats()
+    np.testing.assert_allclose(sg["step_size"], so["step_size"], rtol=1e-12)
+    assert np.ptp(sg["step_size"]) > 0
+    assert_points_close(g.phasepoint(), o.phasepoint(), np.float64, "jittered transition")
+
+
+def compare_transition_stats(sg, so, dtype, min_match):
+    same = (sg["n_steps"] == so["n_steps"]) & (sg["is_accept"] == so["is_accept"]) & (sg["tree_depth"] == so["tree_depth"])
+    frac = same.mean()
+    assert frac >= min_match, f"only {frac:.4f} of chains took the same discrete decisions"
+    rt = RTOL[dtype] * 100
+    for k in ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error",
+              "max_hamiltonian_energy_error", "step_size"):
+        np.testing.assert_allclose(sg[k][same], so[k][same], rtol=rt, atol=rt, err_msg=k)
+    np.testing.assert_array_equal(sg["numerical_error"][same], so["numerical_error"][same])
+    return same
+
+
+@pytest.mark.parametrize("dtype,min_match", [(np.float64, 0.999), (np.float32, 0.9)])
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
+@pytest.mark.parametrize("metric", ["unit", "diag_chain"])
+def test_static_hmc_transitions(hip, oracle, rng, dtype, min_match, TS, metric):
+    """static transition (src/trajectory.jl:271-390, :855-880): 5 consecutive transitions"""
+    D, N = 5, 512
+    h = A.Hamiltonian(make_metric(metric, D, N, rng), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(TS, A.Leapfrog(np.full(N, 0.3)), A.FixedNSteps(10)))
+    g, o = pair(hip, oracle, h, N, dtype, seed=3, lf=k.tau.integrator)
+    th = rng.random((D, N))
+    for e in (g, o):
+        e.set_position(th)
+    for it in range(5):
+        for e in (g, o):
+            e.transition(k)
+        same = compare_transition_stats(g.stats(), o.stats(), dtype, min_match if it == 0 else 0.5)
+        if dtype == np.float64:
+            zg, zo = g.phasepoint(), o.phasepoint()
+            np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(zg.r[:, same], zo.r[:, same], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("dtype,min_match", [(np.float64, 0.999), (np.float32, 0.9)])
+@pytest.mark.parametrize("TS", [A.MultinomialTS, A.SliceTS])
+@pytest.mark.parametrize("TC", [A.GeneralisedNoUTurn, A.ClassicNoUTurn])
+def test_nuts_transitions(hip, oracle, rng, dtype, min_match, TS, TC):
+    """dynamic transition + build_tree (src/trajectory.jl:626-742): iterative kernel == recursion"""
+    D, N = 10, 1024
+    h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(TS, A.Leapfrog(np.full(N, 0.25)), TC(max_depth=8)))
+    g, o = pair(hip, oracle, h, N, dtype, seed=11, lf=k.tau.integrator)
+    th = rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+    for it in range(4):
+        for e in (g, o):
+            e.transition(k)
+        sg, so = g.stats(), o.stats()
+        same = compare_transition_stats(sg, so, dtype, min_match if it == 0 else 0.5)
+        assert sg["tree_depth"].max() >= 3  # the trees are non-trivial
+        if dtype == np.float64:
+            zg, zo = g.phasepoint(), o.phasepoint()
+            np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(zg.lp.gradient[:, same], zo.lp.gradient[:, same], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("D,target", [(32, "funnel"), (128, "iso"), (100, "hier"), (3, "iso")])
+def test_nuts_geometries_and_targets(hip, oracle, rng, D, target):
+    """NUTS on the BASELINE config shapes at oracle-sized N, incl. divergent funnel paths"""
+    N = 256
+    h = A.Hamiltonian(A.DiagEuclideanMetric((D, N)), make_target(target, D, rng))
+    eps = 0.5 if target == "funnel" else 0.2
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(np.full(N, eps)), A.GeneralisedNoUTurn()))
+    g, o = pair(hip, oracle, h, N, np.float64, seed=5, lf=k.tau.integrator)
+    th = rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+    n_div = 0
+    for it in range(3):
+        for e in (g, o):
+            e.transition(k)
+        sg, so = g.stats(), o.stats()
+        compare_transition_stats(sg, so, np.float64, 0.995 if it == 0 else 0.5)
+        n_div += int(sg["numerical_error"].sum())
+    if target == "funnel":
+        assert n_div > 0, "the funnel at eps=0.5 must produce divergent transitions (Δ_max test, :500-507)"
+
+
+def test_max_depth_and_single_leaf(hip, oracle, rng):
+    """max_depth = 1 (one leaf) and a tiny step size that always hits max_depth"""
+    D, N = 5, 64
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
+    for md, eps in ((1, 0.2), (4, 1e-3)):
+        k = A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(eps), A.GeneralisedNoUTurn(max_depth=md)))
+        g, o = pair(hip, oracle, h, N, np.float64, seed=2, lf=k.tau.integrator)
+        th = rng.normal(size=(D, N))
+        for e in (g, o):
+            e.set_position(th)
+            e.transition(k)
+        sg, so = g.stats(), o.stats()
+        compare_transition_stats(sg, so, np.float64, 1.0)
+        if eps < 0.01:
+            assert np.all(sg["tree_depth"] == md) and np.all(sg["n_steps"] == 2 ** md - 1)
+
+
+def test_nonfinite_start_is_rejected(hip, oracle, rng):
+    """non-finite energies → -Inf, proposal rejected, numerical_error flagged (src/hamiltonian.jl:95-104)"""
+    D, N = 5, 32
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(1e200), A.FixedNSteps(3)))
+    g, o = pair(hip, oracle, h, N, np.float64, lf=k.tau.integrator)
+    th = rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+        e.transition(k)
+    sg, so = g.stats(), o.stats()
+    assert not sg["is_accept"].any() and sg["numerical_error"].all()
+    np.testing.assert_array_equal(sg["is_accept"], so["is_accept"])
+    np.testing.assert_array_equal(sg["numerical_error"], so["numerical_error"])
+    np.testing.assert_allclose(g.theta(), th)  # reverted columns (accept_phasepoint!, :312-332)
+
+
+def test_find_good_stepsize(hip, oracle, rng):
+    """find_good_stepsize per chain (src/trajectory.jl:768-837)"""
+    D, N = 10, 128
+    h = A.Hamiltonian(A.DiagEuclideanMetric((D, N)), A.IsoGaussian(D))
+    g, o = pair(hip, oracle, h, N, np.float64, seed=21)
+    th = rng.normal(size=(D, N))
+    out = []
+    for e in (g, o):
+        e.set_position(th)
+        out.append(e.find_good_stepsize())
+    same = out[0] == out[1]
+    assert same.mean() >= 0.99
+    assert np.all(out[0] > 0) and len(np.unique(out[0])) > 1
+
+
+@pytest.mark.parametrize("kind", ["stan", "naive", "stepsize", "massmatrix"])
+def test_adaptation(hip, oracle, rng, kind):
+    """adapt! glue + dual averaging + Welford + Stan windows (src/sampler.jl:72-90, src/adaptation/*.jl)"""
+    D, N, n_adapts = 5, 256, 150
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.DiagGaussian(np.zeros(D), np.array([0.5, 1.0, 2.0, 1.0, 0.3])))
+    lf = A.Leapfrog(np.full(N, 0.1))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=6)))
+    ad = {"stan": A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)),
+          "naive": A.NaiveHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)),
+          "stepsize": A.StepSizeAdaptor(0.8, lf), "massmatrix": A.MassMatrixAdaptor(metric)}[kind]
+    g, o = pair(hip, oracle, h, N, np.float64, seed=17, lf=lf)
+    th = rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+        e.adaptor_init(ad)
+    # The dual-averaging feedback loop (ϵ → α → ϵ, gain 20√m/(m+10) ≈ 3 around m = 10..30) is
+    # not contractive per realisation: 1e-16 differences between two correct implementations
+    # grow to 1e-6 within ~30 iterations (measured).  So the adaptor is compared on IDENTICAL
+    # inputs: the oracle's chain drives both adaptors through adapt!(…, θ, α).
+    for i in range(1, n_adapts + 21):
+        o.transition(k)
+        theta, alpha = o.theta(), o.stats(["acceptance_rate"])["acceptance_rate"]
+        for e in (g, o):
+            e.adapt(i, n_adapts, theta, alpha)
+        if i in (1, 10, 99, 100, 101, n_adapts - 1, n_adapts, n_adapts + 5):
+            np.testing.assert_allclose(g.get_stepsize(), o.get_stepsize(), rtol=1e-10, err_msg=f"ϵ at i={i}")
+            if kind != "stepsize":
+                np.testing.assert_allclose(g.get_metric(), o.get_metric(), rtol=1e-10, err_msg=f"M⁻¹ at i={i}")
+        # the oracle keeps sampling with its own adapted (ϵ, M⁻¹)
+    eg = g.get_stepsize()
+    if kind != "stepsize":
+        Mg = g.get_metric()
+        if kind != "massmatrix":
+            assert np.ptp(Mg) > 0
+        # Welford estimate of the target variances (0.25, 1, 4, 1, 0.09), rtol 0.2 as test/adaptation.jl:173-227
+        if kind in ("naive", "massmatrix"):
+            np.testing.assert_allclose(np.median(Mg, axis=1), [0.25, 1.0, 4.0, 1.0, 0.09], rtol=0.35)
+    if kind in ("stan", "naive", "stepsize"):
+        assert np.all(eg != 0.1)
+    # short-horizon end-to-end: HIP transitions + HIP adaptor vs oracle, before the feedback
+    # loop has amplified rounding differences
+    g2, o2 = pair(hip, oracle, h, N, np.float64, seed=23, lf=lf)
+    for e in (g2, o2):
+        e.set_position(th)
+        e.adaptor_init(ad)
+    for i in range(1, 9):
+        for e in (g2, o2):
+            e.transition(k)
+            e.adapt(i, n_adapts)
+    np.testing.assert_allclose(g2.get_stepsize(), o2.get_stepsize(), rtol=1e-7)
+
+
+def test_bulk_sample_equals_stepwise(hip, rng):
+    """ahmc_sample (one enqueue for the whole loop of src/sampler.jl:182-228) == per-iteration calls"""
+    D, N, n, n_adapts = 10, 200, 60, 40
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.2))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+    ad = A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf))
+    th = rng.normal(size=(D, N))
+    a = A.Engine(h, N, rng=5, lib=hip)
+    b = A.Engine(h, N, rng=5, lib=hip)
+    for e in (a, b):
+        e.set_integrator(lf)
+        e.set_position(th)
+        e.adaptor_init(ad)
+    out = np.zeros((D, N, n - n_adapts), order="F")
+    a.run(k, n, n_adapts, drop_warmup=True, samples_out=out)
+    a.sync()
+    total = 0
+    for i in range(1, n + 1):
+        b.transition(k)
+        b.adapt(i, n_adapts)
+        if i > n_adapts:
+            np.testing.assert_array_equal(out[:, :, i - n_adapts - 1], b.theta())
+            total += int(b.stats(["n_steps"])["n_steps"].sum())
+    acc = a.accum()
+    assert acc["total_n_steps"] == total and acc["n_transitions"] == n - n_adapts
+    np.testing.assert_allclose(acc["sum_theta"], out.sum(axis=2), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(acc["sumsq_theta"], (out ** 2).sum(axis=2), rtol=1e-12, atol=1e-12)
+
+
+def test_same_rng_vector_gives_identical_chains(hip, rng):
+    """test/sampler-vec.jl:69-80: a vector of identically seeded RNGs ⇒ all chains bit-identical"""
+    D, N = 5, 5
+    for TS in (A.EndPointTS, A.MultinomialTS):
+        h = A.Hamiltonian(A.DiagEuclideanMetric((D, N)), A.IsoGaussian(D))
+        k = A.HMCKernel(A.Trajectory(TS, A.Leapfrog(np.full(N, 0.1)), A.FixedNSteps(10)))
+        th0 = np.repeat(rng.random((D, 1)), N, axis=1)
+        samples, _ = A.sample([A.PhiloxRNG(1) for _ in range(N)], h, k, th0, 20, lib=hip)
+        for s in samples[1:10]:
+            for j in range(1, N):
+                np.testing.assert_array_equal(s[:, j], s[:, 0])
+
+
+@pytest.mark.parametrize("metricT", [A.UnitEuclideanMetric, A.DiagEuclideanMetric])
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
+def test_sampler_vec_statistical(hip, metricT, TS):
+    """test/sampler-vec.jl:36-43: 5 chains × D=5, mean(samples) ≈ 0 atol RNDATOL*n_chains = 2.5
+    (2 000 samples here; the far tighter 0.2 bound is what we assert)"""
+    D, N = 5, 5
+    h = A.Hamiltonian(metricT((D, N)), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(TS, A.Leapfrog(np.full(N, 0.1)), A.FixedNSteps(10)))
+    th0 = np.random.default_rng(100).random((D, N))
+    samples, stats = A.sample(100, h, k, th0, 2000, lib=hip)
+    m = np.mean(samples, axis=0)
+    assert np.all(np.abs(m) < 0.2)
+    assert set(stats[0]) >= {"n_steps", "is_accept", "acceptance_rate", "log_density", "hamiltonian_energy",
+                             "hamiltonian_energy_error", "numerical_error", "step_size", "nom_step_size", "is_adapt"}
+
+
+def test_nuts_with_stan_adaptor_statistical(hip):
+    """cfg2-shaped run at small N: NUTS(0.8)+StanHMCAdaptor recovers N(0, I) moments"""
+    D, N = 16, 512
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    e = A.Engine(h, N, rng=1, lib=hip)
+    lf = A.Leapfrog(np.full(N, 0.1))
+    e.set_integrator(lf)
+    e.set_position(np.random.default_rng(0).random((D, N)))
+    e.find_good_stepsize()
+    e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+    e.run(k, 500, 300, drop_warmup=True)
+    acc = e.accum()
+    n = acc["n_transitions"]
+    assert n == 200
+    mean = acc["sum_theta"].sum(axis=1) / (n * N)
+    var = acc["sumsq_theta"].sum(axis=1) / (n * N) - mean ** 2
+    assert np.all(np.abs(mean) < 0.03), mean
+    assert np.all(np.abs(var - 1) < 0.06), var
+    assert acc["n_divergent"] == 0
+    assert 3 <= acc["total_n_steps"] / (n * N) <= 20
+
+
+def test_full_size_properties(hip):
+    """BASELINE cfg2 at full size (65 536 chains × D=128, Float64): size-independent properties —
+    determinism under the same seed, energy bookkeeping H-H0 == stat, Σ n_steps == accumulator,
+    2^depth-1 <= n_steps < 2^(depth+1), acceptance in [0,1], no write outside the state."""
+    D, N = 128, 65536
+    h = A.Hamiltonian(A.DiagEuclideanMetric((D,)), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(0.3), A.GeneralisedNoUTurn()))
+    th0 = np.random.default_rng(3).random((D, N))
+    res = []
+    for rep in range(2):
+        e = A.Engine(h, N, rng=42, lib=hip)
+        e.set_integrator(k.tau.integrator)
+        e.set_position(th0)
+        e.run(k, 3)
+        st = e.stats()
+        z = e.phasepoint()
+        acc = e.accum(moments=False)
+        res.append((st, z, acc))
+        e.close()
+    (s1, z1, a1), (s2, z2, a2) = res
+    np.testing.assert_array_equal(z1.theta, z2.theta)
+    np.testing.assert_array_equal(s1["n_steps"], s2["n_steps"])
+    assert a1["total_n_steps"] == a2["total_n_steps"] and a1["n_transitions"] == 3
+    d, n = s1["tree_depth"], s1["n_steps"]
+    assert np.all(n >= 2 ** d - 1) and np.all(n < 2 ** (d + 1))
+    assert np.all((s1["acceptance_rate"] >= 0) & (s1["acceptance_rate"] <= 1))
+    np.testing.assert_allclose(-(z1.lp.value + z1.lk.value), s1["hamiltonian_energy"], rtol=1e-12)
+    np.testing.assert_allclose(z1.lp.gradient, z1.theta, rtol=1e-12)  # -∇ℓπ = θ for N(0, I)
+    assert np.all(np.isfinite(z1.theta)) and not s1["numerical_error"].any()
