@@ -4,6 +4,7 @@
 // every numerical result comes from a kernel.
 #include "ahmc_hip.h"
 #include "ahmc_kernels.hpp"
+#include "ahmc_nuts.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -64,6 +65,9 @@ struct Ctx : CtxBase {
   int64_t D = 0, N = 0;
   int G = 0, E = 0;  // thread geometry chosen for D
   // phase point
+  T *vbase = nullptr, *tbase = nullptr;  // slabs; the per-field pointers are aliases into them
+  int32_t* ibase = nullptr;
+  long long* lbase = nullptr;
   T *th = nullptr, *r = nullptr, *g = nullptr, *lp = nullptr, *lk = nullptr;
   bool have_point = false;
   // target
@@ -93,6 +97,7 @@ struct Ctx : CtxBase {
   T* scratch = nullptr;
   size_t scratch_bytes = 0;
   unsigned int* queue = nullptr;
+  int32_t* redo = nullptr;  // per-chain "redo in the log domain" flags of the NUTS fast pass
   int nuts_blocks = 0;
   // static multinomial
   T* hmc_H = nullptr;
@@ -113,9 +118,8 @@ struct Ctx : CtxBase {
   ~Ctx() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    void* bufs[] = {th, r, g, lp, lk, tparams, minv, sqrt_minv, eps_nom, eps_cur, st_nsteps, st_accept, st_depth,
-                    st_numerr, st_accrate, st_logdens, st_H, st_Herr, st_maxHerr, acc_nsteps, acc_ndiv, acc_sum,
-                    acc_sumsq, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar, da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha};
+    void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
+                    da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -134,24 +138,30 @@ int dev_alloc(Ctx<T>* c, U** ptr, size_t n) {
   return AHMC_OK;
 }
 
-// (G, E) for a given D: the largest number of chains per wave that keeps E <= 4 registers-wide
-// vectors per lane, preferring 16-byte accesses (E*sizeof(T) == 16) once D allows it.
+// Thread geometries (G lanes per chain, E elements per lane) with compiled kernels.
+// The per-chain scalar work of NUTS (energies, weights, RNG, transcendental functions) costs one
+// wave instruction no matter how many chains share the wave, so the default packs as many chains
+// per wave as the register file allows: E = 8 (64 B per lane for Float64) from D = 32 up.
+#define AHMC_GEOMETRIES(X) \
+  X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(8, 8) X(16, 8) X(32, 8) X(64, 8) X(8, 4) X(16, 4) X(32, 4) X(64, 4) X(64, 2)
+
 inline bool pick_geometry(int64_t D, int& G, int& E) {
   if (D <= 4) { G = 4; E = 1; }
-  else if (D <= 8) { G = 8; E = 1; }
-  else if (D <= 16) { G = 16; E = 1; }
-  else if (D <= 32) { G = 16; E = 2; }
-  else if (D <= 64) { G = 32; E = 2; }
-  else if (D <= 128) { G = 64; E = 2; }
+  else if (D <= 8) { G = 4; E = 2; }
+  else if (D <= 16) { G = 4; E = 4; }
+  else if (D <= 32) { G = 8; E = 4; }
+  else if (D <= 64) { G = 16; E = 4; }
+  else if (D <= 128) { G = 32; E = 4; }   // measured on cfg2 (f64): (32,4) 8.1e8, (64,2) 7.0e8, (16,8) 5.9e8 leapfrog/s
   else if (D <= 256) { G = 64; E = 4; }
+  else if (D <= 512) { G = 64; E = 8; }
   else return false;
   const char* ov = getenv("AHMC_GEOMETRY");  // "G,E" override for experiments
   if (ov) {
     int g = 0, e = 0;
     if (sscanf(ov, "%d,%d", &g, &e) == 2 && (int64_t)g * e >= D) {
-      const int ok[][2] = {{4, 1}, {8, 1}, {16, 1}, {16, 2}, {32, 1}, {32, 2}, {32, 4}, {64, 1}, {64, 2}, {64, 4}};
-      for (auto& p : ok)
-        if (p[0] == g && p[1] == e) { G = g; E = e; }
+#define AHMC_GEO_OK(gg, ee) if (g == gg && e == ee) { G = g; E = e; }
+      AHMC_GEOMETRIES(AHMC_GEO_OK)
+#undef AHMC_GEO_OK
     }
   }
   return true;
@@ -162,8 +172,7 @@ template <class F>
 void with_geometry(int G, int E, F&& f) {
 #define AHMC_GEO_CASE(g, e) \
   if (G == g && E == e) { f(std::integral_constant<int, g>{}, std::integral_constant<int, e>{}); return; }
-  AHMC_GEO_CASE(4, 1) AHMC_GEO_CASE(8, 1) AHMC_GEO_CASE(16, 1) AHMC_GEO_CASE(16, 2) AHMC_GEO_CASE(32, 1)
-  AHMC_GEO_CASE(32, 2) AHMC_GEO_CASE(32, 4) AHMC_GEO_CASE(64, 1) AHMC_GEO_CASE(64, 2) AHMC_GEO_CASE(64, 4)
+  AHMC_GEOMETRIES(AHMC_GEO_CASE)
 #undef AHMC_GEO_CASE
 }
 
@@ -173,12 +182,10 @@ KP<T> make_kp(Ctx<T>* c) {
   memset(&p, 0, sizeof(p));
   p.D = (int)c->D;
   p.N = c->N;
-  p.th = c->th; p.r = c->r; p.g = c->g; p.lp = c->lp; p.lk = c->lk;
+  p.vbase = c->vbase; p.tbase = c->tbase; p.ibase = c->ibase; p.lbase = c->lbase;
   p.minv = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
   p.sqrt_minv = c->metric_kind == AHMC_METRIC_DIAG ? c->sqrt_minv : nullptr;
   p.minv_per_chain = c->minv_per_chain ? 1 : 0;
-  p.eps_nom = c->eps_nom;
-  p.eps_cur = c->eps_cur;
   p.lf.kind = c->integ_kind;
   p.lf.sqrt_alpha = c->integ_kind == AHMC_INTEGRATOR_TEMPERED ? (T)std::sqrt((T)c->integ_param) : T(1);
   p.jitter = (T)c->integ_param;
@@ -190,10 +197,6 @@ KP<T> make_kp(Ctx<T>* c) {
   p.chain_offset = (uint32_t)c->chain_offset;
   p.chain_stride = (uint32_t)c->chain_stride;
   p.iteration = (uint32_t)c->iteration;
-  p.st_nsteps = c->st_nsteps; p.st_accept = c->st_accept; p.st_depth = c->st_depth; p.st_numerr = c->st_numerr;
-  p.st_accrate = c->st_accrate; p.st_logdens = c->st_logdens; p.st_H = c->st_H; p.st_Herr = c->st_Herr;
-  p.st_maxHerr = c->st_maxHerr;
-  p.acc_nsteps = c->acc_nsteps; p.acc_ndiv = c->acc_ndiv; p.acc_sum = c->acc_sum; p.acc_sumsq = c->acc_sumsq;
   p.scratch = c->scratch;
   p.queue = c->queue;
   p.hmc_H = c->hmc_H;
@@ -266,33 +269,67 @@ int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
   return AHMC_OK;
 }
 
-template <class T>
-int ensure_nuts_scratch(Ctx<T>* c, int max_depth, int& blocks, size_t& smem) {
+// Launch plan of k_nuts for this context: one chunk of 64/G chains per single-wave workgroup.
+//   occupancy (waves/CU) comes from the register budget; the LDS left per wave then decides how
+//   many vector slots (hottest first: pending levels 0,1,2,…, then the dormant ones) live in LDS;
+//   the rest go to a per-wave region of global scratch.
+template <class T, bool LINW>
+int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, size_t& smem, int& n_lds_slots) {
   const int CPW = 64 / c->G;
   const int NLEV = max_depth > 1 ? max_depth - 1 : 1;
-  const int waves_per_block = 4;
-  smem = (size_t)waves_per_block * ((size_t)NUTS_NS * NLEV * CPW * sizeof(T) + (size_t)NLEV * CPW * sizeof(int));
+  const int n_slots = 2 * NLEV + NUTS_DORMANT;
+  const size_t slot_bytes = (size_t)64 * c->E * sizeof(T);
+  const size_t scalar_bytes = (size_t)NUTS_NSC * NLEV * CPW * sizeof(T) + (size_t)NUTS_NSI * NLEV * CPW * sizeof(int);
   const int64_t n_chunks = (c->N + CPW - 1) / CPW;
-  int occ = 0;
+  int occ = 0;  // single-wave workgroups per CU
   hipError_t e = hipSuccess;
   with_geometry(c->G, c->E, [&](auto g, auto ee) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, decltype(g)::value, decltype(ee)::value>, 256, smem);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, decltype(g)::value, decltype(ee)::value, LINW>, 64,
+                                                     scalar_bytes);
   });
-  if (e != hipSuccess || occ < 1) occ = 1;
-  if (occ > 8) occ = 8;
-  int64_t want = (n_chunks + waves_per_block - 1) / waves_per_block;
-  int64_t cap = (int64_t)c->n_cu * occ;
-  const char* ov = getenv("AHMC_NUTS_BLOCKS_PER_CU");
-  if (ov && atoi(ov) > 0) cap = (int64_t)c->n_cu * atoi(ov);
-  blocks = (int)std::min<int64_t>(want, cap);
-  if (blocks < 1) blocks = 1;
-  size_t need = (size_t)blocks * waves_per_block * CPW * NLEV * NUTS_NV * (size_t)(c->G * c->E) * sizeof(T);
+  if (e != hipSuccess || occ < 1) occ = 4;
+  if (occ > 32) occ = 32;
+  const char* ov = getenv("AHMC_NUTS_WAVES_PER_CU");
+  if (ov && atoi(ov) > 0) occ = atoi(ov);
+  const size_t lds_per_cu = 160 * 1024;
+  size_t per_wave = lds_per_cu / (size_t)occ;
+  if (per_wave > 64 * 1024) per_wave = 64 * 1024;
+  per_wave = per_wave > scalar_bytes + 128 ? per_wave - scalar_bytes - 128 : 0;
+  n_lds_slots = (int)std::min<size_t>((size_t)n_slots, per_wave / slot_bytes);
+  const char* ovs = getenv("AHMC_NUTS_LDS_SLOTS");
+  if (ovs) n_lds_slots = std::max(0, std::min(n_slots, atoi(ovs)));
+  smem = (size_t)n_lds_slots * slot_bytes + scalar_bytes;
+  with_geometry(c->G, c->E, [&](auto g, auto ee) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nuts<T, decltype(g)::value, decltype(ee)::value, LINW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  (void)hipGetLastError();
+  blocks = (int)n_chunks;
+  size_t need = (size_t)blocks * (size_t)(n_slots - n_lds_slots) * slot_bytes + 256;
   if (need > c->scratch_bytes) {
-    if (c->scratch) HIPCHK(hipFree(c->scratch));
+    if (c->scratch) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipFree(c->scratch));
+    }
     c->scratch = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->scratch), need));
     c->scratch_bytes = need;
   }
+  return AHMC_OK;
+}
+
+template <class T, bool LINW>
+int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
+  int blocks = 0, n_lds_slots = 0;
+  size_t smem = 0;
+  int rc = plan_nuts<T, LINW>(c, max_depth, blocks, smem, n_lds_slots);
+  if (rc) return rc;
+  p.scratch = c->scratch;
+  p.n_lds_levels = n_lds_slots;
+  with_geometry(c->G, c->E, [&](auto g, auto e) {
+    hipLaunchKernelGGL((k_nuts<T, decltype(g)::value, decltype(e)::value, LINW>), dim3(blocks), dim3(64), smem, c->stream, p);
+  });
+  HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
 
@@ -308,11 +345,6 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   if (criterion != AHMC_TC_CLASSIC && criterion != AHMC_TC_GENERALISED)
     return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
   if (max_depth < 1 || max_depth > 24) return fail(c, AHMC_ERR_ARGUMENT, "max_depth must be in 1..24");
-  int blocks = 0;
-  size_t smem = 0;
-  rc = ensure_nuts_scratch(c, max_depth, blocks, smem);
-  if (rc) return rc;
-  HIPCHK(hipMemsetAsync(c->queue, 0, sizeof(unsigned int), c->stream));
   KP<T> p = make_kp(c);
   p.max_depth = max_depth;
   p.delta_max = (T)delta_max;
@@ -322,10 +354,21 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.accum = accum ? 1 : 0;
   const int CPW = 64 / c->G;
   p.n_chunks = (unsigned int)((c->N + CPW - 1) / CPW);
-  with_geometry(c->G, c->E, [&](auto g, auto e) {
-    hipLaunchKernelGGL((k_nuts<T, decltype(g)::value, decltype(e)::value>), dim3(blocks), dim3(256), smem, c->stream, p);
-  });
-  HIPCHK(hipGetLastError());
+  p.redo = c->redo;
+  static const bool no_linw = getenv("AHMC_NUTS_LOGW") != nullptr;
+  if (sampler == AHMC_TS_MULTINOMIAL && !no_linw) {
+    // fast pass: multinomial weights in the linear domain; chains that came near overflow are
+    // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
+    p.redo_only = 0;
+    rc = launch_nuts<T, true>(c, p, max_depth);
+    if (rc) return rc;
+    p.redo_only = 1;
+    rc = launch_nuts<T, false>(c, p, max_depth);
+  } else {
+    p.redo_only = 0;
+    rc = launch_nuts<T, false>(c, p, max_depth);
+  }
+  if (rc) return rc;
   c->iteration += 1;
   return AHMC_OK;
 }
@@ -519,7 +562,7 @@ static int32_t create_impl(int32_t device, int32_t dtype, int64_t D, int64_t N, 
     return code;
   };
   if (!pick_geometry(D, c->G, c->E))
-    return bail("ahmc_create: D > 256 has no HIP kernel geometry yet (workgroup-per-chain path is future work)", AHMC_ERR_UNSUPPORTED);
+    return bail("ahmc_create: D > 512 has no HIP kernel geometry yet (workgroup-per-chain path is future work)", AHMC_ERR_UNSUPPORTED);
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e), AHMC_ERR_RUNTIME);
   hipDeviceProp_t prop;
@@ -536,17 +579,24 @@ static int32_t create_impl(int32_t device, int32_t dtype, int64_t D, int64_t N, 
   auto A = [&](auto** p, size_t cnt) {
     if (ok && hipMalloc(reinterpret_cast<void**>(p), cnt * sizeof(**p)) != hipSuccess) ok = false;
   };
-  A(&c->th, DN); A(&c->r, DN); A(&c->g, DN); A(&c->lp, n); A(&c->lk, n);
-  A(&c->eps_nom, n); A(&c->eps_cur, n);
-  A(&c->st_nsteps, n); A(&c->st_accept, n); A(&c->st_depth, n); A(&c->st_numerr, n);
-  A(&c->st_accrate, n); A(&c->st_logdens, n); A(&c->st_H, n); A(&c->st_Herr, n); A(&c->st_maxHerr, n);
-  A(&c->acc_nsteps, n); A(&c->acc_ndiv, n); A(&c->acc_sum, DN); A(&c->acc_sumsq, DN);
+  // four slabs (see KP in ahmc_kernels.hpp); the per-field pointers below are aliases into them
+  A(&c->vbase, 5 * DN); A(&c->tbase, 9 * n); A(&c->ibase, 4 * n); A(&c->lbase, 2 * n);
+  if (ok) {
+    c->th = c->vbase; c->r = c->vbase + DN; c->g = c->vbase + 2 * DN; c->acc_sum = c->vbase + 3 * DN; c->acc_sumsq = c->vbase + 4 * DN;
+    c->lp = c->tbase; c->lk = c->tbase + n; c->eps_nom = c->tbase + 2 * n; c->eps_cur = c->tbase + 3 * n;
+    c->st_accrate = c->tbase + 4 * n; c->st_logdens = c->tbase + 5 * n; c->st_H = c->tbase + 6 * n; c->st_Herr = c->tbase + 7 * n;
+    c->st_maxHerr = c->tbase + 8 * n;
+    c->st_nsteps = c->ibase; c->st_accept = c->ibase + n; c->st_depth = c->ibase + 2 * n; c->st_numerr = c->ibase + 3 * n;
+    c->acc_nsteps = c->lbase; c->acc_ndiv = c->lbase + n;
+  }
   A(&c->queue, 64);
+  A(&c->redo, n);
   if (!ok) return bail("ahmc_create: hipMalloc failed (out of device memory?)", AHMC_ERR_RUNTIME);
   (void)hipMemsetAsync(c->th, 0, sizeof(T) * DN, c->stream);
   (void)hipMemsetAsync(c->r, 0, sizeof(T) * DN, c->stream);
   (void)hipMemsetAsync(c->g, 0, sizeof(T) * DN, c->stream);
   (void)hipMemsetAsync(c->st_nsteps, 0, sizeof(int32_t) * n, c->stream);
+  (void)hipMemsetAsync(c->redo, 0, sizeof(int32_t) * n, c->stream);
   (void)hipMemsetAsync(c->st_accept, 0, sizeof(int32_t) * n, c->stream);
   (void)hipMemsetAsync(c->st_depth, 0, sizeof(int32_t) * n, c->stream);
   (void)hipMemsetAsync(c->st_numerr, 0, sizeof(int32_t) * n, c->stream);

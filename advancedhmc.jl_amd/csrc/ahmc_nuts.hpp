@@ -1,0 +1,463 @@
+// ahmc_nuts.hpp — the NUTS transition kernel (src/trajectory.jl:626-742), gfx950.
+//
+// Iterative form of build_tree: leaves are visited in integration order; after
+// leaf i one merge is done per trailing zero bit of i, lowest level first — the same merges, in
+// the same order, with the same RNG draws as the reference's recursion.
+//
+// Mapping.  A chain = a group of G lanes (E elements per lane); a wave carries
+// 64/G chains in LOCKSTEP: every live chain of the wave is at the same (doubling j, leaf i), so
+// loop counters, merge levels and slot addresses are wave-uniform (scalar) and only "is this
+// chain still alive" is a per-lane predicate.  Waves are persistent and pull chunks of 64/G
+// chains from a global work queue.
+//
+// What lives where:
+//   registers : the moving edge of the tree (θ, r, -∇ℓπ), M⁻¹, and the turn statistic of the
+//               subtree being merged (A = ρ or θ_first; RF = r of its first-built leaf)
+//   vector slots (LDS for the hottest, global scratch for the rest; 16-byte-chunk-interleaved so
+//               every wave access is 64 consecutive 16-B pieces): the pending subtree of every
+//               level (A, RF), the dormant edge of the tree (θ, r, g), the whole-tree ρ, and
+//               (r0, g0) of the start point
+//   LDS scalars: per pending level {w = ℓw or n, Σα, nα, ΔH_max, candidate leaf index}
+// The multinomial/slice candidate is carried as a LEAF INDEX (signed distance from the start
+// point along the trajectory), not as a phase point: the selected point is re-integrated from the
+// start at the end (vector work only, no reductions, no RNG), which halves the pending state and
+// removes every candidate copy from the merge path.
+#pragma once
+
+#include "ahmc_kernels.hpp"
+
+namespace ahmc {
+
+constexpr int NUTS_NSC = 3;    // T scalars per level: w, Σα, ΔH_max
+constexpr int NUTS_NSI = 2;    // int scalars per level: nα, candidate leaf index
+constexpr int NUTS_DORMANT = 6;  // OTH_TH, OTH_R, OTH_G, TREE_A, Z0_R, Z0_G
+constexpr double LINW_LIMIT = 600.0;  // exp(600)·2^10 leaves is still far from the Float64 overflow; Float32 uses 60
+enum { SL_OTH_TH = 0, SL_OTH_R = 1, SL_OTH_G = 2, SL_TREE_A = 3, SL_Z0_R = 4, SL_Z0_G = 5 };
+
+template <class T, int E>
+struct Chunking {
+  static constexpr int CH = (E * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : E;  // elements per 16-B piece
+  static constexpr int NCH = E / CH;
+};
+
+// Vector slots of one wave.  Slot s, piece c, lane l lives at ((s*NCH + c)*64 + l)*CH elements.
+// Addresses are always formed as (wave-uniform slot base) + (32-bit lane offset) so that global
+// accesses use the saddr+voffset form and no per-lane 64-bit pointer has to stay live.
+template <class T, int E>
+struct Slots {
+  T* lds;          // first n_lds slots
+  T* glb;          // the remaining ones
+  int n_lds;
+  unsigned lane_off;  // lane64 * CH (elements)
+
+  template <class P>
+  static __device__ __forceinline__ void put(P* __restrict__ sb, unsigned off, const T (&v)[E]) {
+    constexpr int CH = Chunking<T, E>::CH, NCH = Chunking<T, E>::NCH;
+    if constexpr (CH > 1) {
+      using V = T __attribute__((ext_vector_type(CH)));
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        V t;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) t[k] = v[c * CH + k];
+        *reinterpret_cast<V*>(&sb[off + (unsigned)(c * 64 * CH)]) = t;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) sb[off + (unsigned)(c * 64)] = v[c];
+    }
+  }
+  template <class P>
+  static __device__ __forceinline__ void get(const P* __restrict__ sb, unsigned off, T (&v)[E]) {
+    constexpr int CH = Chunking<T, E>::CH, NCH = Chunking<T, E>::NCH;
+    if constexpr (CH > 1) {
+      using V = T __attribute__((ext_vector_type(CH)));
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        V t = *reinterpret_cast<const V*>(&sb[off + (unsigned)(c * 64 * CH)]);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) v[c * CH + k] = t[k];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) v[c] = sb[off + (unsigned)(c * 64)];
+    }
+  }
+  __device__ __forceinline__ void store(int slot, const T (&v)[E]) const {
+    constexpr int SE = Chunking<T, E>::NCH * 64 * Chunking<T, E>::CH;
+    if (slot < n_lds) put(lds + slot * SE, lane_off, v);
+    else put(glb + (size_t)(slot - n_lds) * SE, lane_off, v);
+  }
+  __device__ __forceinline__ void load(int slot, T (&v)[E]) const {
+    constexpr int SE = Chunking<T, E>::NCH * 64 * Chunking<T, E>::CH;
+    if (slot < n_lds) get(lds + slot * SE, lane_off, v);
+    else get(glb + (size_t)(slot - n_lds) * SE, lane_off, v);
+  }
+};
+
+// the vector half of a leapfrog step (no energies): used to re-integrate to the candidate
+template <class T, int G, int E>
+__device__ __forceinline__ void leapfrog_core(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp,
+                                              const LeapfrogP<T>& lf, int lane, int d0) {
+  temper(lf, z.r, 1, true, 1);
+  const T eh = eps / 2;
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
+  (void)target_eval<T, G, E>(tp, z.th, z.g, lane, d0);
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+  temper(lf, z.r, 1, false, 1);
+}
+
+// sequential scalar draws of one transition: draw k = half (k & 1) of Philox block k >> 1
+struct DrawStream {
+  Rng rng;
+  uint32_t k;
+  Philox4 blk;
+  __device__ __forceinline__ void init(const Rng& r) { rng = r; k = 0; }
+  __device__ __forceinline__ void fetch() {
+    if ((k & 1u) == 0u) blk = rng.raw(RNG_TRANSITION, k >> 1);
+  }
+  __device__ __forceinline__ double uniform() {
+    fetch();
+    double u = (k & 1u) ? u53(blk.v[2], blk.v[3]) : u53(blk.v[0], blk.v[1]);
+    ++k;
+    return u;
+  }
+  __device__ __forceinline__ bool boolean() {
+    fetch();
+    bool b = (((k & 1u) ? blk.v[2] : blk.v[0]) >> 31) != 0;
+    ++k;
+    return b;
+  }
+  __device__ __forceinline__ double randexp() { return -log(uniform()); }
+};
+
+template <class T, int G, int E, bool LINW>
+__global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
+  constexpr int CPW = 64 / G;
+  constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
+  constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nwaves = blockDim.x >> 6;
+  const int wib = threadIdx.x >> 6;
+  const int lane64 = threadIdx.x & 63;
+  const int lane = lane64 & (G - 1);
+  const int gi = lane64 / G;
+  const int d0 = lane * E;
+  const int NLEV = p.max_depth > 1 ? p.max_depth - 1 : 1;  // pending levels 0 .. NLEV-1
+  const int n_slots = 2 * NLEV + NUTS_DORMANT;
+  const int n_lds_slots = p.n_lds_levels;  // (re-used field) number of vector slots held in LDS
+  // LDS carve-up: [nwaves][n_lds_slots][SLOT_ELEMS] T | [nwaves][NSC][NLEV][CPW] T | [nwaves][NSI][NLEV][CPW] int
+  T* lds_vec = reinterpret_cast<T*>(smem) + (size_t)wib * n_lds_slots * SLOT_ELEMS;
+  T* sT = reinterpret_cast<T*>(smem) + (size_t)nwaves * n_lds_slots * SLOT_ELEMS + (size_t)wib * NUTS_NSC * NLEV * CPW;
+  int* sI = reinterpret_cast<int*>(reinterpret_cast<T*>(smem) + (size_t)nwaves * (n_lds_slots * SLOT_ELEMS + NUTS_NSC * NLEV * CPW)) +
+            (size_t)wib * NUTS_NSI * NLEV * CPW;
+#define S_W(lvl) sT[((0) * NLEV + (lvl)) * CPW + gi]
+#define S_SA(lvl) sT[((1) * NLEV + (lvl)) * CPW + gi]
+#define S_DH(lvl) sT[((2) * NLEV + (lvl)) * CPW + gi]
+#define S_NA(lvl) sI[((0) * NLEV + (lvl)) * CPW + gi]
+#define S_CK(lvl) sI[((1) * NLEV + (lvl)) * CPW + gi]
+  const int64_t wave_slot = (int64_t)blockIdx.x * nwaves + wib;
+  Slots<T, E> sl;
+  sl.lds = lds_vec;
+  sl.glb = p.scratch + wave_slot * (int64_t)(n_slots - n_lds_slots) * SLOT_ELEMS;
+  sl.n_lds = n_lds_slots;
+  sl.lane_off = (unsigned)lane64 * CH;
+  const int DORM = 2 * NLEV;  // first dormant slot
+  const bool classic = p.criterion == 0;
+  const bool slice = p.sampler == 2;
+
+  // One chunk of 64/G chains per wave, one wave per workgroup: the hardware dispatcher is the work
+  // queue.  (A persistent per-wave loop over chunks was measured first: it makes every prologue and
+  // epilogue value loop-invariant, the compiler hoists them all and the kernel needs 230+ VGPRs.)
+  {
+    const unsigned int chunk = blockIdx.x * nwaves + wib;
+    if (chunk >= p.n_chunks) return;
+    const int64_t c = (int64_t)chunk * CPW + gi;
+    const bool active = c < p.N && (p.redo_only == 0 || p.redo[c < p.N ? c : 0] != 0);
+    if (__builtin_amdgcn_ballot_w64(active) == 0) return;  // nothing to do for this wave (redo pass: the common case)
+    const int64_t cc = active ? c : 0;  // inactive groups shadow chain 0 and never write
+
+    // ---- transition prologue (src/sampler.jl:54-57): jitter, fresh momentum, caches ----
+    Point<T, E> cur;
+    T minv[E];
+    load_minv<T, E>(p, cc, d0, minv);
+    load_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D, T(0));
+    if (p.refresh_alpha != T(0)) load_vec<T, E>(cur.r, p.r(), cc * p.D, d0, p.D, T(0));
+    Rng rng = make_rng(p, cc);
+    const T eps = chain_eps(p, rng, cc);
+    draw_momentum<T, E>(p, rng, RNG_MOMENTUM, cc, d0, cur.r, p.refresh_alpha);
+    fill_caches<T, G, E>(cur, minv, p.tp, lane, d0);
+    const T H0 = -(cur.lp + cur.lk);
+    DrawStream ds;
+    ds.init(rng);
+    // both edges of the one-leaf tree are z0 (src/trajectory.jl:682-685)
+    sl.store(DORM + SL_OTH_TH, cur.th);
+    sl.store(DORM + SL_OTH_R, cur.r);
+    sl.store(DORM + SL_OTH_G, cur.g);
+    sl.store(DORM + SL_Z0_R, cur.r);
+    sl.store(DORM + SL_Z0_G, cur.g);
+    if (!classic) sl.store(DORM + SL_TREE_A, cur.r);  // ρ = r0 (TurnStatistic, :461-463)
+    T w_tree, sa_tree = 0, dh_tree = 0, lu = 0;
+    int na_tree = 0, ck_tree = 0;
+    if (slice) {
+      lu = -H0 - (T)ds.randexp();  // SliceTS(rng, z0) (:144-145)
+      w_tree = 1;
+    } else {
+      w_tree = LINW ? T(1) : T(0);  // MultinomialTS(rng, z0): ℓw = 0 (:155); LINW carries W = exp(ℓw)
+    }
+    bool cur_is_left = false;
+    int pos_cur = 0, pos_oth = 0;  // leaf index (signed distance from z0) of the two edges
+    bool numerical = false;
+    bool redo = false;  // LINW only: a weight came too close to overflow
+    int depth = 0;
+    bool done = !active;
+
+    for (int jw = 0; jw < p.max_depth; ++jw) {  // doubling loop (:691-723), wave-uniform
+      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+      // ---- direction (:693) and edge selection ----
+      bool vleft = false;
+      if (!done) vleft = ds.boolean();
+      const int v = vleft ? -1 : 1;
+      const bool need_swap = !done && (vleft != cur_is_left);
+      if (__builtin_amdgcn_ballot_w64(need_swap) != 0) {
+        if (need_swap) {
+          if (jw > 0) {  // at jw == 0 both edges are z0
+            Point<T, E> t;
+            sl.load(DORM + SL_OTH_TH, t.th);
+            sl.load(DORM + SL_OTH_R, t.r);
+            sl.load(DORM + SL_OTH_G, t.g);
+            sl.store(DORM + SL_OTH_TH, cur.th);
+            sl.store(DORM + SL_OTH_R, cur.r);
+            sl.store(DORM + SL_OTH_G, cur.g);
+            copy_vec(cur.th, t.th);
+            copy_vec(cur.r, t.r);
+            copy_vec(cur.g, t.g);
+          }
+          int ti = pos_cur; pos_cur = pos_oth; pos_oth = ti;
+          cur_is_left = vleft;
+        }
+      }
+      // ---- build the subtree of 2^jw leaves (:626-675) ----
+      const uint32_t nleaf = 1u << jw;
+      bool alive = !done;      // still adding leaves to this subtree
+      bool sub_term = false;
+      T A_c[E], RF_c[E];
+      T w_c = 0, sa_c = 0, dh_c = 0;
+      int na_c = 0, ck_c = 0;
+      for (uint32_t leaf = 1; leaf <= nleaf; ++leaf) {
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+        int merged = 0;
+        if (alive) {
+          // leaf: one leapfrog step in direction v (:638-647)
+          leapfrog_step<T, G, E>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+          pos_cur += v;
+          const T ne = cur.lp + cur.lk;  // neg_energy(z′)
+          const T dH = -ne - H0;
+          if constexpr (!LINW) sa_c = exp(jl_min(T(0), -dH));
+          na_c = 1;
+          dh_c = dH;
+          ck_c = pos_cur;
+          if (slice) {
+            w_c = (lu <= ne) ? T(1) : T(0);
+            sub_term = !(lu < p.delta_max + ne);  // Termination(::SliceTS, ...) (:500-502)
+          } else {
+            if constexpr (LINW) {
+              // multinomial weights in the linear domain: W = exp(ℓw), ℓw = H0 - H′ = -ΔH.  Then
+              // α′ = exp(min(0, -ΔH)) = min(1, W) bit for bit, subtree weights add, and the
+              // progressive-sampling tests ℓw < ℓw₁ + Exp(1) become u·W < W₁ — one exp per leaf
+              // instead of exp + log1p + log per merge.  Valid while no weight can overflow; a
+              // chain that meets -ΔH > 600 is flagged and redone by the log-domain kernel.
+              const T lw = H0 + ne;
+              w_c = exp(lw);
+              sa_c = jl_min(T(1), w_c);
+              redo = redo || (lw > (sizeof(T) == 4 ? T(60) : T(LINW_LIMIT)));
+            } else {
+              w_c = H0 + ne;
+            }
+            sub_term = !(-H0 < p.delta_max + ne);  // Termination(::MultinomialTS, ...) (:503-507)
+          }
+          numerical = numerical || sub_term;
+          if (classic) copy_vec(A_c, cur.th); else copy_vec(A_c, cur.r);
+          copy_vec(RF_c, cur.r);
+        }
+        // merges: one per trailing zero bit of `leaf` (:649-673); trip count is wave-uniform
+        const int nm = __builtin_ctz(leaf);
+        for (int lvl = 0; lvl < nm; ++lvl) {
+          const bool m = alive && !sub_term;
+          if (__builtin_amdgcn_ballot_w64(m) == 0) break;
+          if (m) {
+            T A_p[E], RF_p[E];
+            sl.load(2 * lvl, A_p);
+            sl.load(2 * lvl + 1, RF_p);
+            const T w_p = S_W(lvl);
+            // combine(rng, sampler′, sampler′′): `first` = the half built first (:178-195)
+            bool keep_first;
+            T w_new;
+            if (slice) {
+              w_new = w_p + w_c;
+              keep_first = w_new * (T)ds.uniform() < w_p;
+            } else {
+              if constexpr (LINW) w_new = w_p + w_c; else w_new = logaddexp(w_p, w_c);
+              if constexpr (LINW) keep_first = (T)ds.uniform() * w_new < w_p; else keep_first = w_new < w_p + (T)ds.randexp();
+            }
+            if (keep_first) ck_c = S_CK(lvl);
+            w_c = w_new;
+            // combine(treeleft, treeright) (:533-542); position order matters for maxabs only
+            sa_c = S_SA(lvl) + sa_c;
+            na_c = S_NA(lvl) + na_c;
+            const T dh_p = S_DH(lvl);
+            dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+            // isterminated(tc, h, tree′) on the merged subtree (:551-570)
+            T dots[2] = {0, 0};
+            if (classic) {
+              // ends: first-built leaf (A_p, RF_p) and the current leaf; Δθ = θ_right − θ_left
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                T thl = v > 0 ? A_p[e] : cur.th[e], thr = v > 0 ? cur.th[e] : A_p[e];
+                T rl = v > 0 ? RF_p[e] : cur.r[e], rr = v > 0 ? cur.r[e] : RF_p[e];
+                T dth = thr - thl;
+                dots[0] += dth * (minv[e] * (-rl));
+                dots[1] += (-dth) * (minv[e] * rr);
+                A_c[e] = A_p[e];
+              }
+              group_allsum<G>(dots);
+              sub_term = (dots[0] >= 0) || (dots[1] >= 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                A_c[e] = A_p[e] + A_c[e];  // ρ = ρ_left + ρ_right
+                dots[0] += A_c[e] * (minv[e] * RF_p[e]);
+                dots[1] += A_c[e] * (minv[e] * cur.r[e]);
+              }
+              group_allsum<G>(dots);
+              sub_term = (dots[0] <= 0) || (dots[1] <= 0);  // generalised_uturn_criterion (:619-621)
+            }
+            copy_vec(RF_c, RF_p);
+            merged = lvl + 1;
+          }
+        }
+        if (alive && sub_term) {
+          // enclosing unfinished subtrees still absorb the statistics of their first halves
+          // (tree′ = combine(treeleft, treeright) at every level that is a second half, :666)
+          const uint32_t pend = ((leaf - 1u) >> merged) << merged;
+          for (int q = merged; (pend >> q) != 0u; ++q) {
+            if ((pend >> q) & 1u) {
+              sa_c = S_SA(q) + sa_c;
+              na_c = S_NA(q) + na_c;
+              const T dh_p = S_DH(q);
+              dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+            }
+          }
+          alive = false;
+        } else if (alive && leaf < nleaf) {
+          // park the finished level-nm subtree until its sibling is built
+          sl.store(2 * nm, A_c);
+          sl.store(2 * nm + 1, RF_c);
+          S_W(nm) = w_c;
+          S_SA(nm) = sa_c;
+          S_DH(nm) = dh_c;
+          S_NA(nm) = na_c;
+          S_CK(nm) = ck_c;
+        }
+      }
+      // ---- top level of the doubling loop (:708-722) ----
+      if (!done) {
+        if (!sub_term) {
+          ++depth;
+          bool acc;  // mh_accept(rng, sampler, sampler′): biased progressive sampling (:202-206)
+          if (slice) acc = w_tree * (T)ds.uniform() < w_c;
+          else if constexpr (LINW) acc = (T)ds.uniform() * w_tree < w_c;
+          else acc = w_tree < w_c + (T)ds.randexp();
+          if (acc) ck_tree = ck_c;
+        }
+        sa_tree = sa_tree + sa_c;
+        na_tree = na_tree + na_c;
+        dh_tree = v < 0 ? maxabs(dh_c, dh_tree) : maxabs(dh_tree, dh_c);
+        if constexpr (LINW) w_tree = w_tree + w_c; else w_tree = slice ? w_tree + w_c : logaddexp(w_tree, w_c);
+        // isterminated(tc, h, tree) on the whole tree; its edges are `cur` and the dormant one
+        T dots[2] = {0, 0};
+        bool turn;
+        T oth_r[E];
+        sl.load(DORM + SL_OTH_R, oth_r);
+        if (classic) {
+          T oth_th[E];
+          sl.load(DORM + SL_OTH_TH, oth_th);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            T thl = cur_is_left ? cur.th[e] : oth_th[e], thr = cur_is_left ? oth_th[e] : cur.th[e];
+            T rl = cur_is_left ? cur.r[e] : oth_r[e], rr = cur_is_left ? oth_r[e] : cur.r[e];
+            T dth = thr - thl;
+            dots[0] += dth * (minv[e] * (-rl));
+            dots[1] += (-dth) * (minv[e] * rr);
+          }
+          group_allsum<G>(dots);
+          turn = (dots[0] >= 0) || (dots[1] >= 0);
+        } else {
+          T A_tree[E];
+          sl.load(DORM + SL_TREE_A, A_tree);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            A_tree[e] = A_tree[e] + A_c[e];
+            dots[0] += A_tree[e] * (minv[e] * cur.r[e]);
+            dots[1] += A_tree[e] * (minv[e] * oth_r[e]);
+          }
+          sl.store(DORM + SL_TREE_A, A_tree);
+          group_allsum<G>(dots);
+          turn = (dots[0] <= 0) || (dots[1] <= 0);
+        }
+        if (sub_term || turn) done = true;
+      }
+    }
+
+    // ---- Transition(zcand, stats) (:725-741): re-integrate from z0 to the candidate leaf ----
+    {
+      // `ce` is the chain index made opaque to the optimiser: otherwise every array address of the
+      // prologue is kept alive (2 VGPRs each) across the whole tree loop just to be reused here
+      int64_t ce = cc;
+      asm volatile("" : "+v"(ce));
+      Point<T, E> zc;
+      load_vec<T, E>(zc.th, p.th(), ce * p.D, d0, p.D, T(0));
+      sl.load(DORM + SL_Z0_R, zc.r);
+      sl.load(DORM + SL_Z0_G, zc.g);
+      const int steps = active ? (ck_tree < 0 ? -ck_tree : ck_tree) : 0;
+      const T es = ck_tree < 0 ? -eps : eps;
+      for (int s = 0;; ++s) {
+        const bool go = s < steps;
+        if (__builtin_amdgcn_ballot_w64(go) == 0) break;
+        if (go) leapfrog_core<T, G, E>(zc, minv, es, p.tp, p.lf, lane, d0);
+      }
+      if (active && redo) {
+        if (lane == 0) p.redo[ce] = 1;  // left untouched: the log-domain kernel redoes this chain
+      } else if (active) {
+        if (p.redo_only && lane == 0) p.redo[ce] = 0;
+        fill_caches<T, G, E>(zc, minv, p.tp, lane, d0);  // ℓπ, -∇ℓπ, ℓκ of the candidate
+        store_point<T, E>(p, ce, d0, lane, zc);
+        const T H = -(zc.lp + zc.lk);
+        if (lane == 0) {
+          p.eps_cur()[ce] = eps;
+          p.st_nsteps()[ce] = na_tree;
+          p.st_accept()[ce] = 1;
+          p.st_accrate()[ce] = sa_tree / (T)na_tree;
+          p.st_logdens()[ce] = zc.lp;
+          p.st_H()[ce] = H;
+          p.st_Herr()[ce] = H - H0;
+          p.st_maxHerr()[ce] = dh_tree;
+          p.st_depth()[ce] = depth;
+          p.st_numerr()[ce] = numerical ? 1 : 0;
+        }
+        accumulate<T, E>(p, ce, d0, lane, zc.th, na_tree, numerical ? 1 : 0);
+      }
+    }
+  }  // (single pass: one chunk of chains per wave)
+#undef S_W
+#undef S_SA
+#undef S_DH
+#undef S_NA
+#undef S_CK
+}
+
+}  // namespace ahmc

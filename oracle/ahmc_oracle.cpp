@@ -82,6 +82,16 @@ struct Rng {
   }
   bool boolean(uint32_t purpose, uint32_t slot) const { return (raw(purpose, slot).v[0] >> 31) != 0; }
   double randexp(uint32_t purpose, uint32_t slot) const { return -std::log(uniform(purpose, slot)); }
+  // sequential scalar draws of one NUTS transition: draw k = half (k & 1) of Philox block k >> 1
+  double seq_uniform(uint32_t k) const {
+    Philox4 p = raw(RNG_TRANSITION, k >> 1);
+    return (k & 1u) ? u53(p.v[2], p.v[3]) : u53(p.v[0], p.v[1]);
+  }
+  bool seq_boolean(uint32_t k) const {
+    Philox4 p = raw(RNG_TRANSITION, k >> 1);
+    return (((k & 1u) ? p.v[2] : p.v[0]) >> 31) != 0;
+  }
+  double seq_randexp(uint32_t k) const { return -std::log(seq_uniform(k)); }
   // standard normal for element d: Box–Muller on pair d/2
   double normal(uint32_t purpose, uint32_t d) const {
     Philox4 p = raw(purpose, d >> 1);
@@ -501,11 +511,11 @@ Sampler<T> combine_rng(NutsEnv<T>& e, const Sampler<T>& s1, const Sampler<T>& s2
   if (e.cfg->sampler == AHMC_TS_SLICE) {
     o.n = s1.n + s2.n;
     o.lu = s1.lu;
-    T u = (T)e.rng->uniform(RNG_TRANSITION, e.draw++);
+    T u = (T)e.rng->seq_uniform(e.draw++);
     o.zcand = (T(o.n) * u < T(s1.n)) ? s1.zcand : s2.zcand;
   } else {
     o.lw = logaddexp(s1.lw, s2.lw);
-    T ex = (T)e.rng->randexp(RNG_TRANSITION, e.draw++);
+    T ex = (T)e.rng->seq_randexp(e.draw++);
     o.zcand = (o.lw < s1.lw + ex) ? s1.zcand : s2.zcand;
   }
   return o;
@@ -590,7 +600,7 @@ PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0, TStat<T>& 
   Sampler<T> sampler;  // TS(rng, z0) (:144-155)
   sampler.zcand = z0;
   if (e.cfg->sampler == AHMC_TS_SLICE) {
-    sampler.lu = -energy(z0) - (T)e.rng->randexp(RNG_TRANSITION, e.draw++);
+    sampler.lu = -energy(z0) - (T)e.rng->seq_randexp(e.draw++);
     sampler.n = 1;
   } else {
     sampler.lw = 0;
@@ -599,7 +609,7 @@ PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0, TStat<T>& 
   PhasePoint<T> zcand = z0;
   int j = 0;
   while (!isterminated(term) && j < e.cfg->max_depth) {
-    bool vleft = e.rng->boolean(RNG_TRANSITION, e.draw++);  // :693
+    bool vleft = e.rng->seq_boolean(e.draw++);  // :693
     BuildResult<T> sub;
     BinaryTree<T> tl, tr;
     if (vleft) {
@@ -615,10 +625,10 @@ PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0, TStat<T>& 
       j = j + 1;
       bool acc;
       if (e.cfg->sampler == AHMC_TS_SLICE) {
-        T u = (T)e.rng->uniform(RNG_TRANSITION, e.draw++);
+        T u = (T)e.rng->seq_uniform(e.draw++);
         acc = T(sampler.n) * u < T(sub.sampler.n);  // :202
       } else {
-        T ex = (T)e.rng->randexp(RNG_TRANSITION, e.draw++);
+        T ex = (T)e.rng->seq_randexp(e.draw++);
         acc = sampler.lw < sub.sampler.lw + ex;  // :203-206
       }
       if (acc) zcand = sub.sampler.zcand;
