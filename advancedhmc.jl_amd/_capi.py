@@ -152,7 +152,10 @@ _HIP_LIB = None
 
 
 def hip_library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libahmc_hip.so")
+    # AHMC_HIP_LIB: another build of the SAME HIP engine (kernel-tuning experiments); its
+    # backend string is still checked by load_hip_library()
+    return os.environ.get("AHMC_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                          "libahmc_hip.so")
 
 
 def load_hip_library() -> CLib:

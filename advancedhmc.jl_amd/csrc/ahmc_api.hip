@@ -299,6 +299,8 @@ int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, size_t& smem, int& n_lds_sl
   const char* ovs = getenv("AHMC_NUTS_LDS_SLOTS");
   if (ovs) n_lds_slots = std::max(0, std::min(n_slots, atoi(ovs)));
   smem = (size_t)n_lds_slots * slot_bytes + scalar_bytes;
+  static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[ahmc] k_nuts<%s,%d,%d,linw=%d>: occupancy %d waves/CU, %d/%d vector slots in LDS, %zu B LDS/wave, %lld waves\n", sizeof(T) == 8 ? "f64" : "f32", c->G, c->E, (int)LINW, occ, n_lds_slots, n_slots, smem, (long long)n_chunks);
   with_geometry(c->G, c->E, [&](auto g, auto ee) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nuts<T, decltype(g)::value, decltype(ee)::value, LINW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

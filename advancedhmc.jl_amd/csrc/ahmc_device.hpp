@@ -142,6 +142,18 @@ __device__ __forceinline__ double swz16(double v) {
 // own + value of lane ^ 32.  v_permlane32_swap swaps lanes [63:32] of its first operand with
 // lanes [31:0] of its second; with both = v the returned pair is {own, partner} for lanes < 32
 // and {partner, own} for lanes >= 32, so p[0] + p[1] is the same sum, bit for bit, in both.
+// own + value of lane ^ 16: v_permlane16_swap swaps the odd 16-lane rows of its first operand with
+// the even rows of its second, so with both = v the pair holds {row 2k, row 2k+1} in every lane of
+// both rows — a pure VALU exchange (ds_swizzle would go through the LDS pipeline).
+__device__ __forceinline__ float xor16_sum(float v) {
+  auto p = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(p[0]) + __int_as_float(p[1]);
+}
+__device__ __forceinline__ double xor16_sum(double v) {
+  auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
 __device__ __forceinline__ float xor32_sum(float v) {
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
   return __int_as_float(p[0]) + __int_as_float(p[1]);
@@ -174,7 +186,7 @@ __device__ __forceinline__ void group_allsum(T (&v)[K]) {
   }
   if constexpr (G >= 32) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += swz16(v[k]);
+    for (int k = 0; k < K; ++k) v[k] = xor16_sum(v[k]);
   }
   if constexpr (G >= 64) {
 #pragma unroll

@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,57 @@
 #endif
 
 namespace {
+
+// Small-buffer vector for the per-chain D-vectors: the reference allocates a fresh array for every
+// intermediate (src/integrator.jl:237-243); a malloc per leapfrog would dominate this port and make
+// it scale badly over threads, so vectors up to 256 elements live inline (no heap traffic).
+template <class T>
+class Vec {
+  static constexpr size_t INLINE = 256;
+  size_t n_ = 0;
+  T buf_[INLINE];
+  std::vector<T> big_;
+  T* p() { return n_ <= INLINE ? buf_ : big_.data(); }
+  const T* p() const { return n_ <= INLINE ? buf_ : big_.data(); }
+
+ public:
+  Vec() {}
+  explicit Vec(size_t n) { resize(n); }
+  Vec(const Vec& o) : n_(o.n_) {
+    if (n_ <= INLINE) std::copy(o.buf_, o.buf_ + n_, buf_); else big_ = o.big_;
+  }
+  Vec& operator=(const Vec& o) {
+    if (this != &o) {
+      n_ = o.n_;
+      if (n_ <= INLINE) std::copy(o.buf_, o.buf_ + n_, buf_); else big_ = o.big_;
+    }
+    return *this;
+  }
+  void resize(size_t n) {
+    if (n > INLINE) {
+      if (n_ <= INLINE) big_.assign(buf_, buf_ + n_);
+      big_.resize(n);
+    } else if (n_ > INLINE) {
+      std::copy(big_.begin(), big_.begin() + n, buf_);
+    }
+    n_ = n;
+  }
+  template <class It>
+  void assign(It first, It last) {
+    n_ = 0;
+    resize((size_t)(last - first));
+    std::copy(first, last, p());
+  }
+  size_t size() const { return n_; }
+  T* data() { return p(); }
+  const T* data() const { return p(); }
+  T& operator[](size_t i) { return p()[i]; }
+  const T& operator[](size_t i) const { return p()[i]; }
+  T* begin() { return p(); }
+  T* end() { return p() + n_; }
+  const T* begin() const { return p(); }
+  const T* end() const { return p() + n_; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // RNG specification shared with the HIP engine: Philox4x32-10 (Salmon et al., SC'11).
@@ -253,7 +305,7 @@ T neg_kinetic(const MetricView<T>& m, const T* r) {
   } else if (m.kind == AHMC_METRIC_DIAG) {
     for (int64_t d = 0; d < D; ++d) s += (r[d] * r[d]) * m.minv[d];  // -sum(abs2.(r) .* M⁻¹)/2
   } else {
-    std::vector<T> tmp(D);
+    Vec<T> tmp(D);
     dHdr(m, r, tmp.data());  // mul!(_temp, M⁻¹, r); -dot(r, _temp)/2
     for (int64_t d = 0; d < D; ++d) s += r[d] * tmp[d];
   }
@@ -264,7 +316,7 @@ T neg_kinetic(const MetricView<T>& m, const T* r) {
 // (∂H∂r) is never read after construction except by isfinite, so it is recomputed on demand.
 template <class T>
 struct PhasePoint {
-  std::vector<T> th, r, g;
+  Vec<T> th, r, g;
   T lp = 0, lk = 0;
 };
 
@@ -280,7 +332,7 @@ bool phasepoint_isfinite(const MetricView<T>& m, const PhasePoint<T>& z) {
   if (!std::isfinite(z.lp) || !std::isfinite(z.lk)) return false;
   for (T v : z.g)
     if (!std::isfinite(v)) return false;
-  std::vector<T> kr(m.D);
+  Vec<T> kr(m.D);
   dHdr(m, z.r.data(), kr.data());
   for (T v : kr)
     if (!std::isfinite(v)) return false;
@@ -315,8 +367,8 @@ struct LeapfrogCfg {
 };
 
 // temper (src/integrator.jl:198-209); identity for the other integrators (:52-56)
-template <class T>
-inline void temper(const LeapfrogCfg<T>& lf, std::vector<T>& r, int64_t i, bool is_half, int64_t n_steps) {
+template <class T, class V>
+inline void temper(const LeapfrogCfg<T>& lf, V& r, int64_t i, bool is_half, int64_t n_steps) {
   if (lf.kind != AHMC_INTEGRATOR_TEMPERED) return;
   int64_t i_temper = 2 * (i - 1) + 1 + (is_half ? 0 : 1);
   T s = std::sqrt(lf.alpha);
@@ -337,7 +389,7 @@ PhasePoint<T> leapfrog_step(const LeapfrogCfg<T>& lf, const Target<T>& tg, const
   int64_t n_steps = n_steps_signed < 0 ? -n_steps_signed : n_steps_signed;  // :220
   T eps = fwd ? lf.eps : -lf.eps;                                           // :222
   PhasePoint<T> z = z0;
-  std::vector<T> th = z0.th, r = z0.r, g = z0.g, kr(D);
+  Vec<T> th = z0.th, r = z0.r, g = z0.g, kr(D);
   T value = z0.lp;
   // (i0, n_total) let a caller run one step of a longer tempered trajectory (ref_compat mode)
   const int64_t n_temper = n_total < 0 ? n_steps : n_total;
@@ -393,9 +445,12 @@ inline T maxabs(T a, T b) {  // :526
 }
 
 template <class T>
+using PRef = std::shared_ptr<const PhasePoint<T>>;
+
+template <class T>
 struct BinaryTree {  // :512-520
-  PhasePoint<T> zleft, zright;
-  std::vector<T> rho;  // TurnStatistic (:454-467); unused (empty) for ClassicNoUTurn
+  PRef<T> zleft, zright;  // references, like the Julia structs (no array copies on combine)
+  Vec<T> rho;  // TurnStatistic (:454-467); unused (empty) for ClassicNoUTurn
   T sum_alpha = 0;
   int64_t n_alpha = 0;
   T dH_max = 0;
@@ -417,7 +472,7 @@ BinaryTree<T> combine(const BinaryTree<T>& l, const BinaryTree<T>& r) {  // :533
 // tree sampler state: SliceTS (ℓu, n) / MultinomialTS (ℓw)  (:102-136)
 template <class T>
 struct Sampler {
-  PhasePoint<T> zcand;
+  PRef<T> zcand;
   T lw = 0;      // Multinomial: log total weight
   T lu = 0;      // Slice: log slice variable
   int64_t n = 0; // Slice: number of acceptable candidates
@@ -442,21 +497,21 @@ struct NutsEnv {
 };
 
 template <class T>
-inline T dot(const std::vector<T>& a, const std::vector<T>& b) {
+inline T dot(const Vec<T>& a, const Vec<T>& b) {
   T s = 0;
   for (size_t d = 0; d < a.size(); ++d) s += a[d] * b[d];
   return s;
 }
 
 template <class T>
-inline bool generalised_uturn_criterion(const std::vector<T>& rho, const std::vector<T>& pm,
-                                        const std::vector<T>& pp) {  // :619-621
+inline bool generalised_uturn_criterion(const Vec<T>& rho, const Vec<T>& pm,
+                                        const Vec<T>& pp) {  // :619-621
   return (dot(rho, pm) <= 0) || (dot(rho, pp) <= 0);
 }
 
 template <class T>
-std::vector<T> dHdr_vec(const MetricView<T>& m, const std::vector<T>& r) {
-  std::vector<T> o(r.size());
+Vec<T> dHdr_vec(const MetricView<T>& m, const Vec<T>& r) {
+  Vec<T> o(r.size());
   dHdr(m, r.data(), o.data());
   return o;
 }
@@ -468,38 +523,38 @@ Termination uturn(const NutsEnv<T>& e, const BinaryTree<T>& t, const BinaryTree<
   const MetricView<T>& m = *e.m;
   if (e.cfg->criterion == AHMC_TC_CLASSIC) {  // :551-557
     const int64_t D = m.D;
-    std::vector<T> dth(D), ndth(D), nr0(D);
+    Vec<T> dth(D), ndth(D), nr0(D);
     for (int64_t d = 0; d < D; ++d) {
-      dth[d] = t.zright.th[d] - t.zleft.th[d];
+      dth[d] = t.zright->th[d] - t.zleft->th[d];
       ndth[d] = -dth[d];
-      nr0[d] = -t.zleft.r[d];
+      nr0[d] = -t.zleft->r[d];
     }
-    bool s = (dot(dth, dHdr_vec(m, nr0)) >= 0) || (dot(ndth, dHdr_vec(m, t.zright.r)) >= 0);
+    bool s = (dot(dth, dHdr_vec(m, nr0)) >= 0) || (dot(ndth, dHdr_vec(m, t.zright->r)) >= 0);
     return Termination{s, false};
   }
-  bool s1 = generalised_uturn_criterion(t.rho, dHdr_vec(m, t.zleft.r), dHdr_vec(m, t.zright.r));  // :566-570
+  bool s1 = generalised_uturn_criterion(t.rho, dHdr_vec(m, t.zleft->r), dHdr_vec(m, t.zright->r));  // :566-570
   if (e.cfg->criterion == AHMC_TC_GENERALISED) return Termination{s1, false};
   // Strict (:579-617)
-  std::vector<T> rho2(m.D), rho3(m.D);
+  Vec<T> rho2(m.D), rho3(m.D);
   for (int64_t d = 0; d < m.D; ++d) {
-    rho2[d] = tl.rho[d] + tr.zleft.r[d];   // check_left_subtree :597-601
-    rho3[d] = tl.zright.r[d] + tr.rho[d];  // check_right_subtree :609-615
+    rho2[d] = tl.rho[d] + tr.zleft->r[d];   // check_left_subtree :597-601
+    rho3[d] = tl.zright->r[d] + tr.rho[d];  // check_right_subtree :609-615
   }
-  bool s2 = generalised_uturn_criterion(rho2, dHdr_vec(m, t.zleft.r), dHdr_vec(m, tr.zleft.r));
-  bool s3 = generalised_uturn_criterion(rho3, dHdr_vec(m, tl.zright.r), dHdr_vec(m, t.zright.r));
+  bool s2 = generalised_uturn_criterion(rho2, dHdr_vec(m, t.zleft->r), dHdr_vec(m, tr.zleft->r));
+  bool s3 = generalised_uturn_criterion(rho3, dHdr_vec(m, tl.zright->r), dHdr_vec(m, t.zright->r));
   return Termination{s1, false} * Termination{s2, false} * Termination{s3, false};
 }
 
 // sampler for a single-leaf tree (:163-176)
 template <class T>
-Sampler<T> leaf_sampler(const NutsEnv<T>& e, const Sampler<T>& s, T H0, const PhasePoint<T>& z) {
+Sampler<T> leaf_sampler(const NutsEnv<T>& e, const Sampler<T>& s, T H0, const PRef<T>& z) {
   Sampler<T> o;
   o.zcand = z;
   if (e.cfg->sampler == AHMC_TS_SLICE) {
     o.lu = s.lu;
-    o.n = (s.lu <= -energy(z)) ? 1 : 0;  // Int(s.ℓu <= neg_energy(zcand))
+    o.n = (s.lu <= -energy(*z)) ? 1 : 0;  // Int(s.ℓu <= neg_energy(zcand))
   } else {
-    o.lw = H0 + (-energy(z));  // H0 + neg_energy(zcand)
+    o.lw = H0 + (-energy(*z));  // H0 + neg_energy(zcand)
   }
   return o;
 }
@@ -537,18 +592,19 @@ struct BuildResult {
 
 // build_tree (:626-675)
 template <class T>
-BuildResult<T> build_tree(NutsEnv<T>& e, const PhasePoint<T>& z, const Sampler<T>& sampler, int v,
+BuildResult<T> build_tree(NutsEnv<T>& e, const PRef<T>& z, const Sampler<T>& sampler, int v,
                           int j, T H0) {
   if (j == 0) {
     // base case: one leapfrog step in direction v (:638-647)
-    PhasePoint<T> zp = leapfrog_step(*e.lf, *e.tg, *e.m, z, v, v > 0);
+    PRef<T> zpp = std::make_shared<PhasePoint<T>>(leapfrog_step(*e.lf, *e.tg, *e.m, *z, v, v > 0));
+    const PhasePoint<T>& zp = *zpp;
     T Hp = energy(zp);
     T dH = Hp - H0;
     T alpha = std::exp(jl_min(T(0), -dH));
     BuildResult<T> out;
-    out.sampler = leaf_sampler(e, sampler, H0, zp);
-    out.tree.zleft = zp;
-    out.tree.zright = zp;
+    out.sampler = leaf_sampler(e, sampler, H0, zpp);
+    out.tree.zleft = zpp;
+    out.tree.zright = zpp;
     if (e.cfg->criterion != AHMC_TC_CLASSIC) out.tree.rho = zp.r;  // TurnStatistic(tc, z′)
     out.tree.sum_alpha = alpha;
     out.tree.n_alpha = 1;
@@ -588,17 +644,19 @@ struct TStat {
 
 // dynamic transition (:677-742)
 template <class T>
-PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0, TStat<T>& st) {
+PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0v, TStat<T>& st) {
+  PRef<T> z0p = std::make_shared<PhasePoint<T>>(z0v);
+  const PhasePoint<T>& z0 = *z0p;
   T H0 = energy(z0);
   BinaryTree<T> tree;
-  tree.zleft = z0;
-  tree.zright = z0;
+  tree.zleft = z0p;
+  tree.zright = z0p;
   if (e.cfg->criterion != AHMC_TC_CLASSIC) tree.rho = z0.r;
   tree.sum_alpha = 0;
   tree.n_alpha = 0;
   tree.dH_max = 0;
   Sampler<T> sampler;  // TS(rng, z0) (:144-155)
-  sampler.zcand = z0;
+  sampler.zcand = z0p;
   if (e.cfg->sampler == AHMC_TS_SLICE) {
     sampler.lu = -energy(z0) - (T)e.rng->seq_randexp(e.draw++);
     sampler.n = 1;
@@ -606,7 +664,7 @@ PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0, TStat<T>& 
     sampler.lw = 0;
   }
   Termination term;
-  PhasePoint<T> zcand = z0;
+  PRef<T> zcand = z0p;
   int j = 0;
   while (!isterminated(term) && j < e.cfg->max_depth) {
     bool vleft = e.rng->seq_boolean(e.draw++);  // :693
@@ -642,17 +700,17 @@ PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0, TStat<T>& 
     sampler.zcand = zcand;
     term = term * sub.term * uturn(e, tree, tl, tr);  // :719-722
   }
-  T H = energy(zcand);
+  T H = energy(*zcand);
   st.n_steps = (int32_t)tree.n_alpha;
   st.is_accept = 1;
   st.acceptance_rate = tree.sum_alpha / T(tree.n_alpha);
-  st.log_density = zcand.lp;
+  st.log_density = zcand->lp;
   st.hamiltonian_energy = H;
   st.hamiltonian_energy_error = H - H0;
   st.max_hamiltonian_energy_error = tree.dH_max;
   st.tree_depth = j;
   st.numerical_error = term.numerical ? 1 : 0;
-  return zcand;
+  return *zcand;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -947,6 +1005,7 @@ void accumulate(Ctx<T>* c) {
     c->acc_nsteps += c->stat[i].n_steps;
     c->acc_ndiv += c->stat[i].numerical_error;
   }
+#pragma omp parallel for schedule(static)
   for (int64_t k = 0; k < c->D * c->N; ++k) {
     c->acc_sum[k] += c->th[k];
     c->acc_sumsq[k] += c->th[k] * c->th[k];
@@ -1088,6 +1147,7 @@ void da_reset(Ctx<T>* c) {  // reset!(das) (src/adaptation/stepsize.jl:40-53)
 
 template <class T>
 void da_adapt(Ctx<T>* c, const T* alpha_ext = nullptr) {  // adapt_stepsize! (src/adaptation/stepsize.jl:178-210), per chain
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < c->N; ++i) {
     T alpha = alpha_ext ? alpha_ext[i] : c->stat[i].acceptance_rate;
     int32_t m = c->da_m[i] + 1;
@@ -1116,6 +1176,7 @@ template <class T>
 void wv_push(Ctx<T>* c, const T* th_ext = nullptr) {  // push! (:141-149)
   c->wv_n += 1;
   T n = T(c->wv_n);
+#pragma omp parallel for schedule(static)
   for (int64_t k = 0; k < c->D * c->N; ++k) {
     T delta = (th_ext ? th_ext[k] : c->th[k]) - c->wv_mu[k];
     c->wv_mu[k] = c->wv_mu[k] + delta / n;
@@ -1127,6 +1188,7 @@ template <class T>
 void wv_update(Ctx<T>* c) {  // update! (:60-62) + get_estimation (:152-157)
   if (c->wv_n < c->wv_nmin) return;
   T n = T(c->wv_n), e = T(1e-3);
+#pragma omp parallel for schedule(static)
   for (int64_t k = 0; k < c->D * c->N; ++k) c->wv_var[k] = n / ((n + 5) * (n - 1)) * c->wv_M[k] + e * (5 / (n + 5));
 }
 
@@ -1589,10 +1651,18 @@ int32_t ahmco_uturn(int32_t criterion, int64_t D, const double* thl, const doubl
   cfg.criterion = criterion;
   NutsEnv<double> e{nullptr, nullptr, &m, &cfg, nullptr, 0};
   BinaryTree<double> t;
-  t.zleft.th.assign(thl, thl + D); t.zleft.r.assign(rl, rl + D);
-  t.zright.th.assign(thr, thr + D); t.zright.r.assign(rr, rr + D);
+  auto zl = std::make_shared<PhasePoint<double>>(), zr = std::make_shared<PhasePoint<double>>();
+  zl->th.assign(thl, thl + D); zl->r.assign(rl, rl + D);
+  zr->th.assign(thr, thr + D); zr->r.assign(rr, rr + D);
+  t.zleft = zl; t.zright = zr;
   t.rho.assign(rho, rho + D);
-  return uturn(e, t, t, t).dynamic ? 1 : 0;
+  if (criterion != AHMC_TC_STRICT) return uturn(e, t, t, t).dynamic ? 1 : 0;
+  // the left/right subtrees of test/trajectory.jl:84-93: (z0, z0, rho - z1.r) and (z1, z1, rho - z0.r)
+  BinaryTree<double> tl, tr;
+  tl.zleft = t.zleft; tl.zright = t.zleft; tr.zleft = t.zright; tr.zright = t.zright;
+  tl.rho.resize(D); tr.rho.resize(D);
+  for (int64_t d = 0; d < D; ++d) { tl.rho[d] = rho[d] - rr[d]; tr.rho[d] = rho[d] - rl[d]; }
+  return uturn(e, t, tl, tr).dynamic ? 1 : 0;
 }
 // multinomial sampler combine: returns ℓw and writes whether the first candidate is kept
 double ahmco_multinomial_combine(double lw1, double lw2, double randexp, int32_t* keep_first) {

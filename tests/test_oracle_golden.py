@@ -1,0 +1,295 @@
+"""Pin the CPU oracle against every known-answer / identity test the reference's own suite holds for
+the hot path.  Values come from tests/golden/reference_kats.json, which
+tests/golden/make_reference_kats.py parses out of the reference's test sources.  CPU only.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ahmc_amd as A
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_kats.json"), encoding="utf-8") as f:
+    KATS = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def dll(oracle):
+    d = oracle.dll
+    d.ahmco_logaddexp.restype = C.c_double
+    d.ahmco_logaddexp.argtypes = [C.c_double, C.c_double]
+    d.ahmco_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+    d.ahmco_uniform.restype = C.c_double
+    d.ahmco_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    d.ahmco_normal.restype = C.c_double
+    d.ahmco_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    d.ahmco_tree_combine.argtypes = [C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_double,
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    d.ahmco_termination_mul.restype = C.c_int32
+    d.ahmco_termination_mul.argtypes = [C.c_int32] * 4
+    d.ahmco_temper_factor.restype = C.c_double
+    d.ahmco_temper_factor.argtypes = [C.c_double, C.c_int64, C.c_int32, C.c_int64]
+    d.ahmco_uturn.restype = C.c_int32
+    d.ahmco_uturn.argtypes = [C.c_int32, C.c_int64] + [C.c_void_p] * 5
+    d.ahmco_multinomial_combine.restype = C.c_double
+    d.ahmco_multinomial_combine.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int32)]
+    d.ahmco_slice_combine.restype = C.c_int32
+    d.ahmco_slice_combine.argtypes = [C.c_int64, C.c_int64, C.c_double]
+    return d
+
+
+def test_philox_known_answers(dll):
+    """Random123 kat_vectors for philox4x32-10 (the RNG specification shared with the HIP engine)"""
+    out = (C.c_uint32 * 4)()
+    cases = [
+        ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    for ctr, key, expect in cases:
+        dll.ahmco_philox(*ctr, *key, out)
+        assert tuple(out) == expect
+
+
+def test_rng_streams_are_uniform_and_normal(dll):
+    u = np.array([dll.ahmco_uniform(12345, c, 3, 1, 0) for c in range(20000)])
+    assert 0 < u.min() and u.max() < 1
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    z = np.array([dll.ahmco_normal(12345, 7, 3, 0, d) for d in range(20000)])
+    assert abs(z.mean()) < 0.03 and abs(z.var() - 1) < 0.05
+    assert abs(np.mean(z ** 4) - 3) < 0.3
+    # streams are functions of (seed, chain, iteration, purpose, slot) only
+    assert dll.ahmco_uniform(1, 2, 3, 1, 4) == dll.ahmco_uniform(1, 2, 3, 1, 4)
+    assert dll.ahmco_uniform(1, 2, 3, 1, 4) != dll.ahmco_uniform(1, 2, 4, 1, 4)
+
+
+def test_stan_window_schedule(oracle):
+    k = KATS["stan_windows"]  # test/adaptation.jl:148-151
+    ws, we, splits = A.stan_windows(k["n_adapts"], k["init_buffer"], k["term_buffer"], k["window_size"], lib=oracle)
+    assert (ws, we, splits) == (k["window_start"], k["window_end"], k["window_splits"])
+    # "buffer > n_adapts" (test/adaptation.jl:162-169) must not fail
+    ws, we, splits = A.stan_windows(100, lib=oracle)
+    assert splits == [] and we == 50
+
+
+def test_temper_schedule(dll):
+    k = KATS["temper"]  # test/integrator.jl:89-106
+    for case in k["cases"]:
+        f = dll.ahmco_temper_factor(k["alpha"], case["i"], int(case["is_half"]), case["n_steps"])
+        assert f == case["factor"]
+
+
+def test_binary_tree_combine(dll):
+    k = KATS["binary_tree_combine"]  # test/trajectory.jl:231-246
+    sa, n, dh = C.c_double(), C.c_int64(), C.c_double()
+    t1, t2, t4 = k["t1"], k["t2"], k["t4"]
+    dll.ahmco_tree_combine(t1["sum_alpha"], t1["n_alpha"], t1["dH_max"], t2["sum_alpha"], t2["n_alpha"], t2["dH_max"],
+                           C.byref(sa), C.byref(n), C.byref(dh))
+    assert abs(sa.value - k["t3"]["sum_alpha"]) <= k["t3"]["atol"]
+    assert n.value == k["t3"]["n_alpha"] and dh.value == k["t3"]["dH_max"]
+    dll.ahmco_tree_combine(t1["sum_alpha"], t1["n_alpha"], t1["dH_max"], t4["sum_alpha"], t4["n_alpha"], t4["dH_max"],
+                           C.byref(sa), C.byref(n), C.byref(dh))
+    assert dh.value == k["t5"]["dH_max"]
+
+
+def test_termination_truth_table(dll):
+    k = KATS["termination"]  # test/trajectory.jl:199-229
+    for d, n, expect in k["single"]:
+        assert bool(dll.ahmco_termination_mul(d, n, 0, 0)) == expect
+    for d1, n1, d2, n2, expect in k["product"]:
+        assert bool(dll.ahmco_termination_mul(d1, n1, d2, n2)) == expect
+
+
+def test_tree_sampler_combine(dll):
+    k = KATS["sampler_combine"]  # test/trajectory.jl:143-177
+    keep = C.c_int32()
+    lw = dll.ahmco_multinomial_combine(np.log(k["w1"]), np.log(k["w2"]), 1.0, C.byref(keep))
+    assert np.isclose(lw, np.log(k["w1"] + k["w2"]))  # @test s3.ℓw ≈ log(w1 + w2)
+    assert np.isclose(dll.ahmco_logaddexp(np.log(100.0), np.log(150.0)), np.log(250.0))
+    n = 100000
+    rng = np.random.default_rng(1234)
+    e = rng.exponential(size=n)
+    second = 0
+    for x in e:
+        dll.ahmco_multinomial_combine(np.log(k["w1"]), np.log(k["w2"]), x, C.byref(keep))
+        second += 1 - keep.value
+    assert abs(second / n - k["w2"] / (k["w1"] + k["w2"])) < k["rtol"] * k["w2"] / (k["w1"] + k["w2"])
+    u = rng.random(size=n)
+    second = sum(1 - dll.ahmco_slice_combine(k["n1"], k["n2"], x) for x in u)
+    assert abs(second / n - k["n2"] / (k["n1"] + k["n2"])) < k["rtol"] * k["n2"] / (k["n1"] + k["n2"])
+
+
+def test_logaddexp_edge_cases(dll):
+    inf = float("inf")
+    assert dll.ahmco_logaddexp(-inf, -inf) == -inf
+    assert dll.ahmco_logaddexp(-inf, 1.5) == 1.5
+    assert dll.ahmco_logaddexp(inf, inf) == inf
+    assert np.isnan(dll.ahmco_logaddexp(float("nan"), 0.0))
+    assert np.isclose(dll.ahmco_logaddexp(0.0, 0.0), np.log(2.0))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_energy_identities(oracle, rng, dtype):
+    """test/hamiltonian.jl:54-79: neg_energy and ∂H∂r for Unit / Diag / Dense metrics"""
+    D = KATS["common"]["D"]
+    for _ in range(10):
+        th, r = rng.normal(size=D).astype(dtype), rng.normal(size=D).astype(dtype)
+        e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(dtype, D), A.IsoGaussian(D)), 1, dtype=dtype, lib=oracle)
+        e.set_position(th, r)
+        assert -e.phasepoint().lk.value == pytest.approx(np.sum(r.astype(np.float64) ** 2) / 2, rel=1e-6)
+        Minv = (np.ones(D) + np.abs(rng.normal(size=D))).astype(dtype)
+        e = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(Minv), A.IsoGaussian(D)), 1, dtype=dtype, lib=oracle)
+        e.set_position(th, r)
+        assert -e.phasepoint().lk.value == pytest.approx(float(r @ np.diag(Minv) @ r) / 2, rel=1e-5)
+        # ∂H∂r = M⁻¹ .* r shows up as the position update of one leapfrog step from a flat gradient point
+        m = rng.normal(size=(D, D))
+        Md = (m.T @ m + np.eye(D)).astype(dtype)
+        e = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Md), A.IsoGaussian(D)), 1, dtype=dtype, lib=oracle)
+        e.set_position(th, r)
+        assert -e.phasepoint().lk.value == pytest.approx(float(r @ Md @ r) / 2, rel=1e-5)
+
+
+def test_phasepoint_nonfinite_becomes_minus_inf(oracle):
+    """test/hamiltonian.jl:15-52: NaN / Inf log-density values are stored as -Inf; length mismatch → ArgumentError"""
+    h = A.Hamiltonian(A.UnitEuclideanMetric((1,)), A.ExternalTarget(1, lambda th: (np.zeros(1), np.zeros((1, 1)))))
+    for bad in (np.nan, np.inf):
+        e = A.Engine(h, 1, lib=oracle)
+        arrs = [np.array([bad]), np.array([bad]), np.array([bad]), np.array([0.0])]  # θ, r, ℓπ, -∇ℓπ (kept alive)
+        e._call("ahmc_set_phasepoint", *[A.capi.as_ptr(a) for a in arrs])
+        z = e.phasepoint()
+        assert z.lp.value[0] == -np.inf and z.lk.value[0] == -np.inf
+    with pytest.raises(A.ArgumentError):
+        e.set_position(np.zeros((2, 1)))
+
+
+def test_uturn_criteria_agree_along_trajectories(oracle, dll):
+    """test/trajectory.jl:249-325: Classic ≡ Generalised ≡ StrictGeneralised ≡ hand-written U-turn
+    tests along 50-step leapfrog trajectories (ϵ = 0.1, D = 5, unit metric, standard Gaussian)"""
+    D = KATS["common"]["D"]
+    for seed in (12, 77, 130, 201):
+        g = np.random.default_rng(seed)
+        e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric((D,)), A.IsoGaussian(D)), 1, lib=oracle)
+        e.set_integrator(A.Leapfrog(0.1))
+        e.set_position(g.normal(size=D), g.normal(size=D))
+        traj = [e.phasepoint()]
+        for _ in range(49):
+            e.step(1)
+            traj.append(e.phasepoint())
+        th = np.array([z.theta for z in traj])
+        r = np.array([z.r for z in traj])
+        rho = np.cumsum(r, axis=0)
+        n_turn = 0
+        for i in range(1, 50):
+            z0t, z0r, z1t, z1r, rh = (np.ascontiguousarray(x) for x in (th[0], r[0], th[i], r[i], rho[i]))
+            d01 = z0t - z1t
+            hand = bool((np.dot(-d01, -z0r) >= 0) or (np.dot(d01, z1r) >= 0))
+            hand_gen = bool((np.dot(rh, -z0r) >= 0) or (np.dot(-rh, z1r) >= 0))
+            res = [bool(dll.ahmco_uturn(c, D, *(x.ctypes.data for x in (z0t, z0r, z1t, z1r, rh)))) for c in (0, 1, 2)]
+            assert hand == hand_gen == res[0] == res[1] == res[2], (seed, i)
+            n_turn += hand
+        assert 0 < n_turn < 49
+
+
+def test_step_loop_equals_step_n_and_reversibility(oracle, rng):
+    """test/integrator.jl:17-32 on the oracle, plus time reversibility of the leapfrog"""
+    D, N = 5, 7
+    h = A.Hamiltonian(A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N)))), A.IsoGaussian(D))
+    a, b = A.Engine(h, N, lib=oracle), A.Engine(h, N, lib=oracle)
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for e in (a, b):
+        e.set_integrator(A.Leapfrog(0.1))
+        e.set_position(th, r)
+    for _ in range(10):
+        a.step(1)
+    b.step(10)
+    np.testing.assert_allclose(a.phasepoint().theta, b.phasepoint().theta, atol=KATS["common"]["DETATOL"])
+    np.testing.assert_array_equal(a.phasepoint().theta, b.phasepoint().theta)
+    b.step(-10)
+    np.testing.assert_allclose(b.phasepoint().theta, th, atol=1e-12)
+    np.testing.assert_allclose(b.phasepoint().r, r, atol=1e-12)
+
+
+def test_harmonic_oscillator_bound(oracle):
+    """test/integrator.jl:108-153: ϵ = 0.01, 10 000 steps, radius and H within 2e-3 of their mean"""
+    k = KATS["harmonic_oscillator"]
+    h = A.Hamiltonian(A.UnitEuclideanMetric((1,)), A.DiagGaussian([0.0], [1.0]))
+    e = A.Engine(h, 1, lib=oracle)
+    e.set_integrator(A.Leapfrog(k["eps"]))
+    g = np.random.default_rng(5)
+    e.set_position(g.normal(size=1), g.normal(size=1))
+    qs, ps, Hs = [], [], []
+    for _ in range(k["n_steps"]):
+        e.step(1)
+        z = e.phasepoint()
+        qs.append(z.theta[0]); ps.append(z.r[0]); Hs.append(-(z.lp.value + z.lk.value))
+    qs, ps, Hs = (np.array(x)[k["burn"]:] for x in (qs, ps, Hs))
+    rs = np.sqrt(qs ** 2 + ps ** 2)
+    assert np.all(np.abs(rs - rs.mean()) < k["bound"]) and np.all(np.abs(Hs - Hs.mean()) < k["bound"])
+
+
+def test_same_seed_same_transition(oracle, rng):
+    """test/trajectory.jl:125-141 ("Passing RNG"): same seed ⇒ identical NUTS transition, also with jitter"""
+    D = KATS["common"]["D"]
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D,)), A.IsoGaussian(D))
+    th0 = rng.normal(size=D)
+    for lf in (A.Leapfrog(0.3), A.JitteredLeapfrog(0.3, 1.0)):
+        k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+        for seed in (1234, 5678, 90):
+            out = []
+            for _ in range(2):
+                e = A.Engine(h, 1, rng=seed, lib=oracle)
+                e.set_integrator(lf)
+                e.set_position(th0)
+                e.transition(k)
+                out.append(e.phasepoint())
+            np.testing.assert_array_equal(out[0].theta, out[1].theta)
+            np.testing.assert_array_equal(out[0].r, out[1].r)
+
+
+def test_constants_match_reference_sources():
+    k = KATS["constants"]
+    assert (k["max_depth"], k["delta_max"]) == (10, 1000.0)
+    assert (k["da_gamma"], k["da_t0"], k["da_kappa"]) == (0.05, 10.0, 0.75)
+    assert (k["welford_eps"], k["welford_shrink"], k["welford_n_min"]) == (1e-3, 5, 10)
+    assert A.GeneralisedNoUTurn().max_depth == k["max_depth"] and A.GeneralisedNoUTurn().delta_max == k["delta_max"]
+
+
+@pytest.mark.parametrize("metricT", [A.UnitEuclideanMetric, A.DiagEuclideanMetric])
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
+def test_sampler_vec_statistical(oracle, metricT, TS):
+    """test/sampler-vec.jl:36-43 on the oracle: 5 chains × D = 5, ϵ = 0.1, 10 steps;
+    mean(samples) ≈ 0 with atol RNDATOL·n_chains = 2.5 (4 000 samples here instead of 20 000)"""
+    k = KATS["sampler_vec"]
+    D, N = KATS["common"]["D"], k["n_chains"]
+    h = A.Hamiltonian(metricT((D, N)), A.IsoGaussian(D))
+    kern = A.HMCKernel(A.Trajectory(TS, A.Leapfrog(np.full(N, k["eps"])), A.FixedNSteps(k["n_steps"])))
+    samples, stats = A.sample(100, h, kern, np.random.default_rng(100).random((D, N)), 4000, lib=oracle)
+    m = np.mean(samples, axis=0)
+    assert m.shape == (D, N) and np.all(np.abs(m) < k["atol"])
+    assert np.all(np.abs(m) < 0.5)
+    assert abs(np.var(np.stack(samples[500:])) - 1) < 0.15
+
+
+def test_adaptors_statistical(oracle):
+    """test/sampler-vec.jl:46-66 on the oracle: all four adaptors keep mean ≈ 0; adapted variance ≈ truth"""
+    D, N = 5, 5
+    metric = A.DiagEuclideanMetric((D, N))
+    s = np.array([0.5, 1.0, 2.0, 1.0, 0.7])
+    h = A.Hamiltonian(metric, A.DiagGaussian(np.zeros(D), s))
+    lf = A.Leapfrog(np.full(N, 0.1))
+    kern = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+    th0 = np.random.default_rng(100).random((D, N))
+    for ad in (A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf),
+               A.NaiveHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)),
+               A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf))):
+        samples, stats = A.sample(100, h, kern, th0, 1500, ad, 700, lib=oracle)
+        m = np.mean(samples[700:], axis=0)
+        assert np.all(np.abs(m) < 2.5) and np.all(np.abs(m) < 0.6 * s[:, None] + 0.2)
+        assert stats[0]["is_adapt"] and not stats[-1]["is_adapt"]
+        acc = np.mean([st["acceptance_rate"].mean() for st in stats[700:]])
+        if not isinstance(ad, A.MassMatrixAdaptor):
+            assert 0.6 < acc < 0.95
