@@ -3,7 +3,7 @@
 `CLib(path)` binds every entry point of the header on one shared library.  The product
 library is advancedhmc.jl_amd/csrc/libahmc_hip.so (HIP, gfx950) and is the ONLY library this
 package ever opens by itself: `load_hip_library()` raises if it has not been built — there is
-no CPU fallback.  (tests/ bind the same `CLib` class onto oracle/libahmc_oracle.so to obtain the
+no CPU fallback.  (tests/ bind the same `CLib` class onto the CPU checker built under oracle/ to obtain the
 checker; that path is never taken from inside the package.)
 """
 from __future__ import annotations

@@ -47,13 +47,29 @@ def build_engine(A, lib, D, N, seed, chain_offset, stream=0, device=0):
     return eng, kernel
 
 
-def cpu_baseline(A, D, n_adapt, steps, seed, chains):
+def usable_cores():
+    """CPU cores this process may actually use: min(visible CPUs, cgroup-v2 CPU quota).  The GPU
+    boxes show 256 logical CPUs but run the container under `cpu.max 1600000 100000` (16 cores);
+    oversubscribing the quota only adds throttling (measured: 32 threads 1.5e7, 256 threads 3e6)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(A, D, n_adapt, steps, seed, chains, threads):
     """The CPU oracle (scalar restatement of the reference, OpenMP over chains) on a bounded
-    sample of the same workload, timed on this host's cores."""
+    sample of the same workload, timed on this host's usable cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import build_oracle  # test infrastructure: used here only as the timed CPU baseline
 
     lib = A.CLib(build_oracle.build())
+    lib.dll.ahmco_set_num_threads.restype = int
+    threads = lib.dll.ahmco_set_num_threads(int(threads))
     eng, kernel = build_engine(A, lib, D, chains, seed, 0)
     eng.run(kernel, n_adapt, n_adapt)
     eng.run(kernel, 1, 0)
@@ -62,7 +78,7 @@ def cpu_baseline(A, D, n_adapt, steps, seed, chains):
     dt = time.perf_counter() - t0
     acc = eng.accum(moments=False)
     eng.close()
-    return acc["total_n_steps"] / dt, dt
+    return acc["total_n_steps"] / dt, dt, threads
 
 
 def main():
@@ -127,20 +143,18 @@ def main():
     n_leap = acc["total_n_steps"]
     tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
     tn = torch.tensor([float(n_leap), float(acc["n_divergent"])], dtype=torch.float64, device=f"cuda:{local_rank}")
-    # per-dimension pooled moments of this shard; gathered over RCCL at the end
-    n_draws = acc["n_transitions"] * N
-    mom = torch.tensor(np.stack([acc["sum_theta"].sum(axis=1), acc["sumsq_theta"].sum(axis=1)]) / n_draws,
-                       dtype=torch.float64, device=f"cuda:{local_rank}")
+    # per-dimension pooled moments of this shard; the final gather over RCCL —
+    # the same host code the 2-rank gloo test exercises (advancedhmc.jl_amd/shard.py)
+    from ahmc_amd.shard import gather_moments, pooled_moments
+
+    mom_np, n_draws = pooled_moments(acc["sum_theta"], acc["sumsq_theta"], acc["n_transitions"] * N)
+    mom = torch.tensor(mom_np, dtype=torch.float64, device=f"cuda:{local_rank}")
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tn, op=dist.ReduceOp.SUM)
-        gathered = [torch.empty_like(mom) for _ in range(world)]
-        dist.all_gather(gathered, mom)
-        mom = torch.stack(gathered).mean(dim=0)
+    mean, var, _ = gather_moments(dist, mom, n_draws, f"cuda:{local_rank}")
     dt_max = float(tt.item())
     total_leap = float(tn[0].item())
-    mean = mom[0].cpu().numpy()
-    var = mom[1].cpu().numpy() - mean ** 2
 
     if rank == 0:
         B_lf = algorithmic_bytes_per_leapfrog(D, True, 8)
@@ -168,25 +182,26 @@ def main():
                 "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_nuts<double,64,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "k_nuts<double,32,4,linw>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_leapfrog": B_lf, "avg_launch_ms": per_launch_s * 1e3,
             },
         }
         if not args.no_cpu_baseline:
             try:
-                cores = os.cpu_count() or 1
-                # bounded sample sized to the host: 128 chains per core (capped at the GPU's own N),
-                # the same adaptation, then `cpu_steps` timed sampling transitions (~10-20 s in all)
-                cpu_chains = args.cpu_chains or min(N, 128 * cores)
+                cores = usable_cores()
+                # bounded sample sized to the host: 256 chains per usable core (capped at the GPU's own
+                # N), the same adaptation, then `cpu_steps` timed sampling transitions (~10-30 s in all)
+                cpu_chains = args.cpu_chains or min(N, 256 * cores)
                 cpu_steps = args.cpu_steps
                 t_all = time.perf_counter()
-                v, cdt = cpu_baseline(A, D, args.adapt, cpu_steps, args.seed, cpu_chains)
+                v, cdt, cores = cpu_baseline(A, D, args.adapt, cpu_steps, args.seed, cpu_chains, cores)
                 out["cpu_baseline"] = {
                     "value": v, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
                     "sample": f"{cpu_chains} chains x D={D}, same kernel/adaptor, {cpu_steps} timed transitions "
                               f"({cdt:.1f} s) after {args.adapt} adaptation steps ({time.perf_counter() - t_all:.1f} s in all); "
-                              "C++ restatement of the reference (oracle/), OpenMP over chains on all host cores, not Julia",
+                              f"C++ restatement of the reference (oracle/), OpenMP over chains, {cores} threads = the container's "
+                              f"CPU quota ({os.cpu_count()} logical CPUs visible), not Julia",
                 }
             except Exception as ex:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}

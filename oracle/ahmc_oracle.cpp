@@ -1306,6 +1306,16 @@ int32_t ahmc_sync(ahmc_ctx* ctx) { return ctx ? AHMC_OK : AHMC_ERR_ARGUMENT; }
 void* ahmc_stream(ahmc_ctx*) { return nullptr; }
 
 // oracle-only switch: reproduce the reference's matrix-mode batch coupling (Q1)
+// oracle-only: number of OpenMP threads used by the batch loops (bench.py sizes it to the cgroup CPU quota)
+int32_t ahmco_set_num_threads(int32_t n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 int32_t ahmco_set_ref_compat(ahmc_ctx* ctx, int32_t on) {
   FOR_CTX(ctx, { c->ref_compat = on != 0; return AHMC_OK; });
 }

@@ -1,0 +1,173 @@
+"""CPU-only checks of the boundary: the product library exports the whole C ABI of
+include/ahmc_hip.h (no compute call is made without a GPU), the header and the ctypes table agree,
+and the host-side mirror validates arguments the way the reference does (exercised on the oracle,
+which implements the same ABI).
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import ahmc_amd as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ahmc_hip.h")
+
+
+def header_functions():
+    src = open(HEADER, encoding="utf-8").read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(ahmc_[a-z_0-9]+)\s*\(", src)) - {"ahmc_ctx", "ahmc_kernel_cfg"}
+
+
+def test_header_and_binding_table_agree():
+    assert header_functions() == set(A.capi.SIGNATURES)
+
+
+def test_hip_library_builds_and_exports_every_symbol():
+    """`build()` cross-compiles for gfx950 without a GPU; every header symbol must resolve."""
+    so = A.build_hip_library()
+    assert os.path.exists(so)
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (ahmc_[a-z_0-9]+)$", out, flags=re.M))
+    assert header_functions() <= exported
+    # the code object is gfx950 and nothing else (no dual paths)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if os.path.exists(objdump):
+        txt = subprocess.run([objdump, "--offloading", so], capture_output=True, text=True).stdout
+        archs = set(re.findall(r"gfx[0-9a-f]+", txt))
+        assert archs == {"gfx950"}, archs
+
+
+def test_hip_library_loads_without_gpu():
+    """dlopen + ABI/version/backend queries only — no context is created"""
+    import torch  # noqa: F401  (HIP runtime of the process must be torch's copy)
+
+    lib = A.CLib(A.hip_library_path())
+    assert lib.backend == "hip:gfx950"
+    assert lib.dll.ahmc_abi_version() == A.capi.AHMC_ABI_VERSION
+    ws, we, splits = A.stan_windows(1000, lib=lib)  # pure host logic of the product library
+    assert (ws, we, splits) == (76, 950, [100, 150, 250, 450, 950])
+
+
+def test_product_loader_has_no_fallback(monkeypatch, tmp_path):
+    monkeypatch.setenv("AHMC_HIP_LIB", str(tmp_path / "missing.so"))
+    monkeypatch.setattr(A.capi, "_HIP_LIB", None)
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        A.load_hip_library()
+    # the oracle is refused as a product library
+    monkeypatch.setenv("AHMC_HIP_LIB", os.path.join(ROOT, "oracle", "libahmc_oracle.so"))
+    monkeypatch.setattr(A.capi, "_HIP_LIB", None)
+    with pytest.raises(ImportError, match="expected the HIP engine"):
+        A.load_hip_library()
+    monkeypatch.setattr(A.capi, "_HIP_LIB", None)
+
+
+def test_package_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "advancedhmc.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert "libahmc_oracle" not in text and "oracle/ahmc_oracle" not in text, f
+
+
+# ---- argument validation mirrors the reference's errors (oracle-backed: same ABI, same host code) ----
+def test_argument_errors(oracle):
+    D, N = 5, 4
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
+    e = A.Engine(h, N, lib=oracle)
+    with pytest.raises(A.ArgumentError):  # @argcheck length(θ) == length(r) … (src/hamiltonian.jl:94)
+        e.set_position(np.zeros((D + 1, N)))
+    with pytest.raises(A.ArgumentError):  # step-size vector of the wrong length
+        e.set_integrator(A.Leapfrog(np.full(N + 1, 0.1)))
+    with pytest.raises(A.AHMCError):  # transition before a phase point exists
+        e.transition(A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(0.1), A.FixedNSteps(3))))
+    with pytest.raises(A.ArgumentError):  # AxesMismatch (src/hamiltonian.jl:55-57)
+        e.set_metric(A.DiagEuclideanMetric(np.ones(D + 2)))
+    with pytest.raises(A.ArgumentError):  # metric / target dimension mismatch
+        A.Hamiltonian(A.UnitEuclideanMetric((D + 1, N)), A.IsoGaussian(D))
+    e.set_position(np.zeros((D, N)))
+    with pytest.raises(A.ArgumentError):  # static kernels have no SliceTS
+        e.transition(A.HMCKernel(A.Trajectory(A.SliceTS, A.Leapfrog(0.1), A.FixedNSteps(3))))
+    with pytest.raises(A.ArgumentError):  # FixedIntegrationTime needs a scalar ϵ (src/trajectory.jl:241-243, Q6)
+        e.set_integrator(A.Leapfrog(np.full(N, 0.1)))
+        e.transition(A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(np.full(N, 0.1)), A.FixedIntegrationTime(1.0))))
+    with pytest.raises(A.ArgumentError):  # length(rngs) == n_chains (src/utilities.jl:13)
+        A.Engine(h, N, rng=[A.PhiloxRNG(1)] * (N + 1), lib=oracle)
+    with pytest.raises(AssertionError):  # src/sampler.jl:172
+        A.sample(1, h, A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(0.1), A.FixedNSteps(3))), np.zeros((D, N)), 10,
+                 drop_warmup=True, lib=oracle)
+    with pytest.raises(A.ArgumentError):
+        A.Engine(h, N, dtype=np.float16, lib=oracle)
+
+
+def test_vector_theta_and_stat_fields(oracle):
+    """scalar-chain mode (θ a Vector) and the stat field names pinned by test/sampler.jl:12-46"""
+    D = 5
+    h = A.Hamiltonian(A.DiagEuclideanMetric(D), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(0.2), A.GeneralisedNoUTurn()))
+    samples, stats = A.sample(3, h, k, np.zeros(D), 30, A.StanHMCAdaptor(A.MassMatrixAdaptor(h.metric), A.StepSizeAdaptor(0.8, k.tau.integrator)), 20,
+                              lib=oracle)
+    assert samples[0].shape == (D,) and len(samples) == 30
+    nuts_fields = {"n_steps", "is_accept", "acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error",
+                   "max_hamiltonian_energy_error", "tree_depth", "numerical_error", "step_size", "nom_step_size", "is_adapt"}
+    assert set(stats[0]) == nuts_fields
+    assert stats[0]["is_adapt"] and not stats[-1]["is_adapt"]
+    eb = A.EBFMI([s["hamiltonian_energy"] for s in stats])
+    assert np.all(np.isfinite(eb))
+
+
+def test_float32_eltype_preserved(oracle):
+    """test/constructors.jl:131-157: Float32 in → Float32 out"""
+    D, N = 4, 3
+    h = A.Hamiltonian(A.UnitEuclideanMetric(np.float32, (D, N)), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(0.1), A.FixedNSteps(4)))
+    samples, stats = A.sample(0, h, k, np.zeros((D, N), dtype=np.float32), 5, lib=oracle)
+    assert samples[0].dtype == np.float32 and stats[0]["acceptance_rate"].dtype == np.float32
+
+
+def test_external_target_split_step(oracle, rng):
+    """lf_pre / lf_post around a caller-side gradient == the fused built-in step (src/integrator.jl:231-243)"""
+    D, N = 6, 9
+    Minv = np.asfortranarray(0.5 + rng.random((D, N)))
+    fn = lambda th: (np.sum(-(np.log(2 * np.pi) + th ** 2) / 2, axis=0), -th)  # noqa: E731
+    ext = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(Minv), A.ExternalTarget(D, fn)), N, lib=oracle)
+    ref = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(Minv), A.IsoGaussian(D)), N, lib=oracle)
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for e in (ext, ref):
+        e.set_integrator(A.TemperedLeapfrog(np.full(N, 0.07), 1.1))
+        e.set_position(th, r)
+        e.step(6)
+    za, zb = ext.phasepoint(), ref.phasepoint()
+    np.testing.assert_allclose(za.theta, zb.theta, rtol=1e-13)
+    np.testing.assert_allclose(za.r, zb.r, rtol=1e-13)
+    np.testing.assert_allclose(za.lk.value, zb.lk.value, rtol=1e-13)
+    ext.step(-3)
+    ref.step(-3)
+    np.testing.assert_allclose(ext.phasepoint().theta, ref.phasepoint().theta, rtol=1e-12, atol=1e-14)
+
+
+def test_ref_compat_batch_early_exit(oracle):
+    """Q1 (src/integrator.jl:252-258): in matrix mode the reference stops ALL chains at the first
+    step where ANY chain is non-finite; per-chain semantics (the engine's, = the reference's scalar
+    path) let the healthy chains finish.  Documented difference, shown on the oracle."""
+    D, N = 3, 4
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
+    th = np.zeros((D, N))
+    th[:, 2] = 1e200  # chain 2 overflows on its first step
+    r = np.ones((D, N))
+    res = {}
+    oracle.dll.ahmco_set_ref_compat.argtypes = [C.c_void_p, C.c_int32]
+    for compat in (0, 1):
+        e = A.Engine(h, N, lib=oracle)
+        oracle.dll.ahmco_set_ref_compat(e._ctx, compat)
+        e.set_integrator(A.Leapfrog(0.1))
+        e.set_position(th, r)
+        e.step(5)
+        res[compat] = e.phasepoint().theta
+    assert np.allclose(res[1][:, 0], 0.1, atol=1e-3)      # stopped after ONE step
+    assert np.allclose(res[0][:, 0], np.sin(0.5), atol=1e-2)  # five steps of the unit oscillator
