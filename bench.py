@@ -33,6 +33,19 @@ def algorithmic_bytes_per_leapfrog(D, diag, itemsize):
     return (6 * D + (D if diag else 0)) * itemsize + 4 * itemsize
 
 
+def measured_traffic(D, N):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, separate rocprofv3 passes: profiles/r1_hbm_traffic.json).  bench.py cannot run
+    rocprofv3 on itself, so the committed measurement is reported — only for the workload it was
+    taken on; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+            t = json.load(f)
+        return t["hbm_bytes_per_launch"] if (D, N) == (128, 65536) else None
+    except Exception:
+        return None
+
+
 def build_engine(A, lib, D, N, seed, chain_offset, stream=0, device=0):
     metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
     h = A.Hamiltonian(metric, A.IsoGaussian(D))
@@ -183,7 +196,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_nuts<double,32,4,linw>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(D, N),
                 "algorithmic_bytes_per_leapfrog": B_lf, "avg_launch_ms": per_launch_s * 1e3,
             },
         }

@@ -1,0 +1,229 @@
+# AdvancedHMCMI355XExt.jl — the reference-side binding of libahmc_hip.so (include/ahmc_hip.h).
+#
+# A package extension in the style of ext/AdvancedHMCCUDAExt.jl (which specialises `refresh` and
+# `mh_accept_ratio` on `CuArray`, :6-34).  This one specialises the WHOLE transition on a device
+# handle type, so that `sample(rng, h, κ, θ, n, adaptor, n_adapts)` (src/sampler.jl:159-248) and
+# `AbstractMCMC.step` (src/abstractmcmc.jl:131-207) keep their signatures and run every
+# transition + adapt! of the sampler-vec path as chain-batched HIP kernels.
+#
+# NOT EXECUTED in the build environment (no Julia there): it documents the `ccall` layer a
+# maintainer adds; the Python mirror in advancedhmc.jl_amd/api.py drives the same ABI in the tests.
+module AdvancedHMCMI355XExt
+
+using AdvancedHMC
+using AdvancedHMC: Hamiltonian, HMCKernel, Trajectory, PhasePoint, DualValue, Transition,
+    AbstractMetric, UnitEuclideanMetric, DiagEuclideanMetric, Leapfrog, JitteredLeapfrog,
+    TemperedLeapfrog, FixedNSteps, FixedIntegrationTime, EndPointTS, MultinomialTS, SliceTS,
+    ClassicNoUTurn, GeneralisedNoUTurn, StrictGeneralisedNoUTurn, FullMomentumRefreshment,
+    PartialMomentumRefreshment, step_size, nom_step_size
+using AdvancedHMC.Adaptation: AbstractAdaptor, NoAdaptation, StepSizeAdaptor, MassMatrixAdaptor,
+    NaiveHMCAdaptor, StanHMCAdaptor
+using Random: AbstractRNG
+
+const LIB = get(ENV, "AHMC_HIP_LIB", "libahmc_hip.so")
+
+# --- enums of include/ahmc_hip.h -----------------------------------------------------------------
+const F32, F64 = Cint(0), Cint(1)
+const METRIC_UNIT, METRIC_DIAG = Cint(0), Cint(1)
+const TARGET_ISO_GAUSS, TARGET_DIAG_GAUSS, TARGET_FUNNEL, TARGET_HIER_GAUSS = Cint.(0:3)
+const TARGET_EXTERNAL = Cint(5)
+const TS_ENDPOINT, TS_MULTINOMIAL, TS_SLICE = Cint.(0:2)
+const TC_CLASSIC, TC_GENERALISED, TC_STRICT = Cint.(0:2)
+const ADAPT_NONE, ADAPT_STEPSIZE, ADAPT_MASSMATRIX, ADAPT_NAIVE, ADAPT_STAN = Cint.(0:4)
+
+struct AHMCError <: Exception
+    code::Int
+    msg::String
+end
+
+function check(ctx, code)
+    code == 0 && return nothing
+    msg = unsafe_string(ccall((:ahmc_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
+    code == 1 && throw(ArgumentError(msg))   # AHMC_ERR_ARGUMENT ↔ Julia ArgumentError
+    throw(AHMCError(code, msg))
+end
+
+"Built-in log-density families the kernels evaluate in registers (AHMC_TARGET_*)."
+abstract type DeviceTarget end
+struct IsoGaussian <: DeviceTarget end
+struct DiagGaussian{T} <: DeviceTarget
+    m::Vector{T}
+    s::Vector{T}
+end
+struct Funnel <: DeviceTarget end
+struct HierGaussian <: DeviceTarget end
+
+"""
+    MI355XChains{T}
+
+Device-resident phase point of N chains: the handle type the extension dispatches on (the role
+`CuArray` plays in ext/AdvancedHMCCUDAExt.jl).  Owns one `ahmc_ctx`.
+"""
+mutable struct MI355XChains{T<:AbstractFloat}
+    ctx::Ptr{Cvoid}
+    D::Int
+    N::Int
+    function MI355XChains{T}(D::Int, N::Int; device::Int=0) where {T}
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        code = ccall((:ahmc_create, LIB), Cint, (Cint, Cint, Int64, Int64, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
+                     device, T === Float32 ? F32 : F64, D, N, C_NULL, ref)
+        code == 0 || throw(AHMCError(code, unsafe_string(ccall((:ahmc_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL))))
+        z = new{T}(ref[], D, N)
+        finalizer(z -> ccall((:ahmc_destroy, LIB), Cint, (Ptr{Cvoid},), z.ctx), z)
+        return z
+    end
+end
+
+# --- configuration ----------------------------------------------------------------------------------
+set_target!(z::MI355XChains, ::IsoGaussian) =
+    check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), z.ctx, TARGET_ISO_GAUSS, C_NULL, 0))
+set_target!(z::MI355XChains, ::Funnel) =
+    check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), z.ctx, TARGET_FUNNEL, C_NULL, 0))
+set_target!(z::MI355XChains, ::HierGaussian) =
+    check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), z.ctx, TARGET_HIER_GAUSS, C_NULL, 0))
+function set_target!(z::MI355XChains{T}, t::DiagGaussian) where {T}
+    p = T[t.m; t.s]
+    check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{T}, Int64), z.ctx, TARGET_DIAG_GAUSS, p, length(p)))
+end
+
+set_metric!(z::MI355XChains, ::UnitEuclideanMetric) =
+    check(z.ctx, ccall((:ahmc_set_metric, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), z.ctx, METRIC_UNIT, C_NULL, 0))
+function set_metric!(z::MI355XChains{T}, m::DiagEuclideanMetric) where {T}
+    M = convert(Array{T}, m.M⁻¹)   # (D,) or (D, N): column-major, passed as is
+    check(z.ctx, ccall((:ahmc_set_metric, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{T}, Int64), z.ctx, METRIC_DIAG, M, length(M)))
+end
+
+function set_integrator!(z::MI355XChains{T}, lf) where {T}
+    ϵ = T.(vcat(nom_step_size(lf)))
+    check(z.ctx, ccall((:ahmc_set_stepsize, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Int64), z.ctx, ϵ, length(ϵ)))
+    kind, param = lf isa JitteredLeapfrog ? (Cint(1), Float64(lf.jitter)) :
+                  lf isa TemperedLeapfrog ? (Cint(2), Float64(lf.α)) : (Cint(0), 0.0)
+    check(z.ctx, ccall((:ahmc_set_integrator, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble), z.ctx, kind, param))
+end
+
+seed!(z::MI355XChains, seed::Integer; chain_offset=0, iteration=0) =
+    check(z.ctx, ccall((:ahmc_seed, LIB), Cint, (Ptr{Cvoid}, UInt64, UInt64, UInt64, UInt64), z.ctx, seed, chain_offset, 1, iteration))
+
+# phasepoint(h, θ, r) (src/hamiltonian.jl:115-119): θ::Matrix{T} is passed zero-copy via pointer(θ)
+function set_position!(z::MI355XChains{T}, θ::AbstractMatrix{T}) where {T}
+    size(θ) == (z.D, z.N) || throw(ArgumentError("θ has size $(size(θ)), expected $((z.D, z.N))"))
+    check(z.ctx, ccall((:ahmc_set_position, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), z.ctx, θ, C_NULL))
+end
+
+function AdvancedHMC.PhasePoint(z::MI355XChains{T}) where {T}
+    θ, r, g = (Matrix{T}(undef, z.D, z.N) for _ in 1:3)
+    ℓπ, ℓκ = Vector{T}(undef, z.N), Vector{T}(undef, z.N)
+    check(z.ctx, ccall((:ahmc_get_phasepoint, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}), z.ctx, θ, r, ℓπ, g, ℓκ))
+    return PhasePoint(θ, r, DualValue(ℓπ, g), DualValue(ℓκ, similar(g)))
+end
+
+function getstat(z::MI355XChains{T}, field::Integer, ::Type{S}) where {T,S}
+    out = Vector{S}(undef, z.N)
+    check(z.ctx, ccall((:ahmc_get_stat, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{S}), z.ctx, field, out))
+    return out
+end
+
+sampler_code(::Type{EndPointTS}) = TS_ENDPOINT
+sampler_code(::Type{<:MultinomialTS}) = TS_MULTINOMIAL
+sampler_code(::Type{<:SliceTS}) = TS_SLICE
+criterion_code(::ClassicNoUTurn) = TC_CLASSIC
+criterion_code(::GeneralisedNoUTurn) = TC_GENERALISED
+criterion_code(::StrictGeneralisedNoUTurn) = TC_STRICT
+
+# --- the hook: transition(rng, h, κ::HMCKernel, z) (src/sampler.jl:48-58) ----------------------------
+# static HMC
+function AdvancedHMC.transition(
+    ::Union{AbstractRNG,AbstractVector{<:AbstractRNG}}, h::Hamiltonian,
+    κ::HMCKernel{<:FullMomentumRefreshment,<:Trajectory{TS,I,<:FixedNSteps}}, z::MI355XChains{T},
+) where {TS,I,T}
+    set_integrator!(z, κ.τ.integrator)
+    check(z.ctx, ccall((:ahmc_hmc_transition, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cint),
+                       z.ctx, κ.τ.termination_criterion.L, 0.0, sampler_code(TS)))
+    tstat = (
+        n_steps=κ.τ.termination_criterion.L,
+        is_accept=getstat(z, 1, Int32) .!= 0,
+        acceptance_rate=getstat(z, 2, T),
+        log_density=getstat(z, 3, T),
+        hamiltonian_energy=getstat(z, 4, T),
+        hamiltonian_energy_error=getstat(z, 5, T),
+        numerical_error=any(getstat(z, 8, Int32) .!= 0),
+        step_size=getstat(z, 9, T),
+        nom_step_size=getstat(z, 10, T),
+    )
+    return Transition(z, tstat)
+end
+
+# NUTS, for all chains at once (the reference's dynamic transition is scalar-only, src/trajectory.jl:677-681)
+function AdvancedHMC.transition(
+    ::Union{AbstractRNG,AbstractVector{<:AbstractRNG}}, h::Hamiltonian,
+    κ::HMCKernel{<:FullMomentumRefreshment,<:Trajectory{TS,I,TC}}, z::MI355XChains{T},
+) where {TS,I,TC<:AdvancedHMC.DynamicTerminationCriterion,T}
+    tc = κ.τ.termination_criterion
+    set_integrator!(z, κ.τ.integrator)
+    check(z.ctx, ccall((:ahmc_nuts_transition, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint),
+                       z.ctx, tc.max_depth, Float64(tc.Δ_max), criterion_code(tc), sampler_code(TS)))
+    tstat = (
+        n_steps=getstat(z, 0, Int32),
+        is_accept=trues(z.N),
+        acceptance_rate=getstat(z, 2, T),
+        log_density=getstat(z, 3, T),
+        hamiltonian_energy=getstat(z, 4, T),
+        hamiltonian_energy_error=getstat(z, 5, T),
+        max_hamiltonian_energy_error=getstat(z, 6, T),
+        tree_depth=getstat(z, 7, Int32),
+        numerical_error=getstat(z, 8, Int32) .!= 0,
+        step_size=getstat(z, 9, T),
+        nom_step_size=getstat(z, 10, T),
+    )
+    return Transition(z, tstat)
+end
+
+# --- adapt!(h, κ, adaptor, i, n_adapts, z, α) (src/sampler.jl:72-90) ---------------------------------
+adaptor_code(::NoAdaptation) = ADAPT_NONE
+adaptor_code(::StepSizeAdaptor) = ADAPT_STEPSIZE
+adaptor_code(::MassMatrixAdaptor) = ADAPT_MASSMATRIX
+adaptor_code(::NaiveHMCAdaptor) = ADAPT_NAIVE
+adaptor_code(::StanHMCAdaptor) = ADAPT_STAN
+
+function adaptor_init!(z::MI355XChains, a::AbstractAdaptor, δ::Real)
+    ib, tb, ws = a isa StanHMCAdaptor ? (a.init_buffer, a.term_buffer, a.window_size) : (75, 50, 25)
+    check(z.ctx, ccall((:ahmc_adaptor_init, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint, Cint),
+                       z.ctx, adaptor_code(a), Float64(δ), ib, tb, ws))
+end
+
+function AdvancedHMC.Adaptation.adapt!(
+    h::Hamiltonian, κ::HMCKernel, adaptor::AbstractAdaptor, i::Int, n_adapts::Int, z::MI355XChains, α,
+)
+    # θ = NULL and α = NULL: adapt on the context's own position and last acceptance rates
+    check(z.ctx, ccall((:ahmc_adapt, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}), z.ctx, i, n_adapts, C_NULL, C_NULL))
+    return h, κ, i <= n_adapts
+end
+
+"""
+    sample_device(seed, h, κ, θ, n_samples, adaptor, n_adapts; drop_warmup=false)
+
+The whole loop of src/sampler.jl:182-228 in ONE library call (`ahmc_sample`): no host
+synchronisation between transitions.  Returns the kept draws as a (D, N, n_keep) array.
+"""
+function sample_device(seed::Integer, h::Hamiltonian, κ::HMCKernel, θ::Matrix{T}, n_samples::Int,
+                       adaptor::AbstractAdaptor=NoAdaptation(), n_adapts::Int=min(div(n_samples, 10), 1_000);
+                       target::DeviceTarget=IsoGaussian(), δ=0.8, drop_warmup::Bool=false) where {T}
+    D, N = size(θ)
+    z = MI355XChains{T}(D, N)
+    set_target!(z, target); set_metric!(z, h.metric); set_integrator!(z, κ.τ.integrator)
+    seed!(z, seed); set_position!(z, θ); adaptor_init!(z, adaptor, δ)
+    tc = κ.τ.termination_criterion
+    nuts = tc isa AdvancedHMC.DynamicTerminationCriterion
+    # struct ahmc_kernel_cfg { int32 nuts, sampler, criterion, max_depth; double delta_max; int64 L; double lambda, refresh_alpha; }
+    cfg = Ref((Cint(nuts), sampler_code(typeof(κ.τ).parameters[1]), nuts ? criterion_code(tc) : Cint(0),
+               Cint(nuts ? tc.max_depth : 0), nuts ? Float64(tc.Δ_max) : 0.0, Int64(nuts ? 0 : tc.L), 0.0,
+               κ.refreshment isa PartialMomentumRefreshment ? Float64(κ.refreshment.α) : 0.0))
+    n_keep = n_samples - (drop_warmup ? n_adapts : 0)
+    out = Array{T}(undef, D, N, n_keep)
+    check(z.ctx, ccall((:ahmc_sample, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{T}),
+                       z.ctx, cfg, n_samples, n_adapts, drop_warmup, out))
+    check(z.ctx, ccall((:ahmc_sync, LIB), Cint, (Ptr{Cvoid},), z.ctx))
+    return out
+end
+
+end # module
