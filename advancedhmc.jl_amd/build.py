@@ -1,43 +1,80 @@
 """Build the HIP engine in-tree: hipcc --offload-arch=gfx950 → csrc/libahmc_hip.so.
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
-git-ignored but travels with the repo snapshot to the GPU box."""
+git-ignored but travels with the repo snapshot to the GPU box.
+
+Translation units (compiled in parallel, objects cached under csrc/build/):
+  ahmc_api.hip                      host side of the C ABI + the target-independent kernels
+  ahmc_inst.hip  × {f32,f64} × {iso,diag,funnel,hier}
+                                    the kernels that evaluate a built-in log-density family, which is
+                                    a compile-time parameter (see ahmc_inst.hpp)
+"""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 OUT = os.path.join(CSRC, "libahmc_hip.so")
-SOURCES = ["ahmc_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-parameter"]
+INCLUDE = os.path.join(_HERE, "..", "include")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-parameter"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".hpp", ".cuh"))]
-    deps.append(os.path.join(_HERE, "..", "include", "ahmc_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+def _units():
+    units = [("api", "ahmc_api.hip", [])]
+    for tname, tdef in (("f32", "float"), ("f64", "double")):
+        for tk in range(4):
+            units.append((f"inst_{tname}_t{tk}", "ahmc_inst.hip", [f"-DAHMC_INST_T={tdef}", f"-DAHMC_INST_TK={tk}"]))
+    return units
+
+
+def _sources_digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(INCLUDE, "ahmc_hip.h"), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
 
 
 def build_hip_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+    digest = _sources_digest()
+    stamp = os.path.join(OBJ, "digest.txt")
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == digest:
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the HIP engine (and there is no fallback)")
-    cmd = [hipcc, *FLAGS, "-I", os.path.join(_HERE, "..", "include"), *[os.path.join(CSRC, s) for s in SOURCES],
-           "-o", OUT]
-    if verbose:
-        print(" ".join(cmd))
+    os.makedirs(OBJ, exist_ok=True)
+
+    def compile_one(unit):
+        name, src, defs = unit
+        obj = os.path.join(OBJ, name + ".o")
+        cmd = [hipcc, *FLAGS, *defs, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {name}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        if verbose:
+            print("compiled", name)
+        return obj
+
+    units = _units()
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(compile_one, units))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", OUT]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
-    if verbose and res.stderr:
-        print(res.stderr)
+        raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    with open(stamp, "w") as f:
+        f.write(digest)
+    if verbose:
+        print("linked", OUT)
     return OUT

@@ -3,8 +3,7 @@
 // methods do, and enqueues the kernels of ahmc_kernels.hpp.  No CPU compute path exists here:
 // every numerical result comes from a kernel.
 #include "ahmc_hip.h"
-#include "ahmc_kernels.hpp"
-#include "ahmc_nuts.hpp"
+#include "ahmc_inst.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -138,13 +137,9 @@ int dev_alloc(Ctx<T>* c, U** ptr, size_t n) {
   return AHMC_OK;
 }
 
-// Thread geometries (G lanes per chain, E elements per lane) with compiled kernels.
-// The per-chain scalar work of NUTS (energies, weights, RNG, transcendental functions) costs one
-// wave instruction no matter how many chains share the wave, so the default packs as many chains
-// per wave as the register file allows: E = 8 (64 B per lane for Float64) from D = 32 up.
-#define AHMC_GEOMETRIES(X) \
-  X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(8, 8) X(16, 8) X(32, 8) X(64, 8) X(8, 4) X(16, 4) X(32, 4) X(64, 4) X(64, 2)
-
+// (G, E) for a given D; the compiled geometries are listed in ahmc_inst.hpp (AHMC_GEOMETRIES).
+// The per-chain scalar work of NUTS costs one wave instruction no matter how many chains share the
+// wave, so the table packs several chains per wave; E = 4 is the measured optimum for Float64.
 inline bool pick_geometry(int64_t D, int& G, int& E) {
   if (D <= 4) { G = 4; E = 1; }
   else if (D <= 8) { G = 4; E = 2; }
@@ -167,14 +162,6 @@ inline bool pick_geometry(int64_t D, int& G, int& E) {
   return true;
 }
 
-// call f(std::integral_constant<int,G>{}, std::integral_constant<int,E>{}) for the context's geometry
-template <class F>
-void with_geometry(int G, int E, F&& f) {
-#define AHMC_GEO_CASE(g, e) \
-  if (G == g && E == e) { f(std::integral_constant<int, g>{}, std::integral_constant<int, e>{}); return; }
-  AHMC_GEOMETRIES(AHMC_GEO_CASE)
-#undef AHMC_GEO_CASE
-}
 
 template <class T>
 KP<T> make_kp(Ctx<T>* c) {
@@ -221,10 +208,7 @@ int check_builtin(Ctx<T>* c, const char* what) {
 template <class T>
 int launch_fill_caches(Ctx<T>* c) {
   KP<T> p = make_kp(c);
-  with_geometry(c->G, c->E, [&](auto g, auto e) {
-    hipLaunchKernelGGL((k_fill_caches<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0,
-                       c->stream, p);
-  });
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::fill_caches(c->G, c->E, group_grid(c), c->stream, p); });
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -282,12 +266,8 @@ int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, size_t& smem, int& n_lds_sl
   const size_t scalar_bytes = (size_t)NUTS_NSC * NLEV * CPW * sizeof(T) + (size_t)NUTS_NSI * NLEV * CPW * sizeof(int);
   const int64_t n_chunks = (c->N + CPW - 1) / CPW;
   int occ = 0;  // single-wave workgroups per CU
-  hipError_t e = hipSuccess;
-  with_geometry(c->G, c->E, [&](auto g, auto ee) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, decltype(g)::value, decltype(ee)::value, LINW>, 64,
-                                                     scalar_bytes);
-  });
-  if (e != hipSuccess || occ < 1) occ = 4;
+  with_target(c->target_kind, [&](auto tk) { occ = Inst<T, decltype(tk)::value>::nuts_occupancy(c->G, c->E, LINW, scalar_bytes); });
+  if (occ < 1) occ = 4;
   if (occ > 32) occ = 32;
   const char* ov = getenv("AHMC_NUTS_WAVES_PER_CU");
   if (ov && atoi(ov) > 0) occ = atoi(ov);
@@ -301,11 +281,7 @@ int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, size_t& smem, int& n_lds_sl
   smem = (size_t)n_lds_slots * slot_bytes + scalar_bytes;
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] k_nuts<%s,%d,%d,linw=%d>: occupancy %d waves/CU, %d/%d vector slots in LDS, %zu B LDS/wave, %lld waves\n", sizeof(T) == 8 ? "f64" : "f32", c->G, c->E, (int)LINW, occ, n_lds_slots, n_slots, smem, (long long)n_chunks);
-  with_geometry(c->G, c->E, [&](auto g, auto ee) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nuts<T, decltype(g)::value, decltype(ee)::value, LINW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  });
-  (void)hipGetLastError();
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, LINW, smem); });
   blocks = (int)n_chunks;
   size_t need = (size_t)blocks * (size_t)(n_slots - n_lds_slots) * slot_bytes + 256;
   if (need > c->scratch_bytes) {
@@ -328,9 +304,7 @@ int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
   if (rc) return rc;
   p.scratch = c->scratch;
   p.n_lds_levels = n_lds_slots;
-  with_geometry(c->G, c->E, [&](auto g, auto e) {
-    hipLaunchKernelGGL((k_nuts<T, decltype(g)::value, decltype(e)::value, LINW>), dim3(blocks), dim3(64), smem, c->stream, p);
-  });
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts(c->G, c->E, LINW, (unsigned)blocks, smem, c->stream, p); });
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -358,6 +332,9 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.n_chunks = (unsigned int)((c->N + CPW - 1) / CPW);
   p.redo = c->redo;
   static const bool no_linw = getenv("AHMC_NUTS_LOGW") != nullptr;
+  // transition prologue (src/sampler.jl:54-57): jitter + refresh(rng, refreshment, h, z) for all chains
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::refresh(c->G, c->E, group_grid(c), c->stream, p); });
+  HIPCHK(hipGetLastError());
   if (sampler == AHMC_TS_MULTINOMIAL && !no_linw) {
     // fast pass: multinomial weights in the linear domain; chains that came near overflow are
     // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
@@ -402,9 +379,7 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refr
   p.sampler = sampler;
   p.refresh_alpha = (T)refresh_alpha;
   p.accum = accum ? 1 : 0;
-  with_geometry(c->G, c->E, [&](auto g, auto e) {
-    hipLaunchKernelGGL((k_hmc<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p);
-  });
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::hmc(c->G, c->E, group_grid(c), c->stream, p); });
   HIPCHK(hipGetLastError());
   c->iteration += 1;
   return AHMC_OK;
@@ -784,9 +759,7 @@ int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
     if (rc) return rc;
     KP<T> p = make_kp(c);
     p.refresh_alpha = (T)alpha;
-    with_geometry(c->G, c->E, [&](auto g, auto e) {
-      hipLaunchKernelGGL((k_refresh<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p);
-    });
+    with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::refresh(c->G, c->E, group_grid(c), c->stream, p); });
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   });
@@ -799,9 +772,7 @@ int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
     if (rc) return rc;
     KP<T> p = make_kp(c);
     p.n_steps = n_steps;
-    with_geometry(c->G, c->E, [&](auto g, auto e) {
-      hipLaunchKernelGGL((k_leapfrog<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p);
-    });
+    with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::leapfrog(c->G, c->E, group_grid(c), c->stream, p); });
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   });
@@ -892,9 +863,7 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
     p.init_eps = (T)initial_step_size;
     p.max_iters = max_n_iters;
     T* out = c->eps_cur;
-    with_geometry(c->G, c->E, [&](auto g, auto e) {
-      hipLaunchKernelGGL((k_find_eps<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0, c->stream, p, out);
-    });
+    with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::find_eps(c->G, c->E, group_grid(c), c->stream, p, out); });
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->eps_nom, c->eps_cur, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
     c->eps_scalar = false;

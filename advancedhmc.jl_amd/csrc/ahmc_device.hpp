@@ -228,22 +228,22 @@ struct TargetP {
 
 #define AHMC_LOG2PI 1.8378770664093454835606594728112
 
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E], T (&grad)[E], int lane, int d0) {
   const T log2pi = (T)AHMC_LOG2PI;
   const int D = tp.D;
   T part = 0;
-  switch (tp.kind) {
-    case 0: {  // AHMC_TARGET_ISO_GAUSS (test/common.jl:40-44, m = 0, s = 1)
+  {  // the target family is a compile-time parameter: a 4-way run-time switch costs 36 VGPRs in k_nuts
+    if constexpr (TK == 0) {  // AHMC_TARGET_ISO_GAUSS (test/common.jl:40-44, m = 0, s = 1)
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         bool ok = d0 + e < D;
         part += ok ? -(log2pi + th[e] * th[e]) / 2 : T(0);
         grad[e] = ok ? th[e] : T(0);
       }
-      break;
+
     }
-    case 1: {  // AHMC_TARGET_DIAG_GAUSS: params = m[D], s[D]
+    if constexpr (TK == 1) {  // AHMC_TARGET_DIAG_GAUSS: params = m[D], s[D]
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         bool ok = d0 + e < D;
@@ -254,9 +254,9 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
         part += ok ? -(log2pi + 2 * log(s) + diff * diff / s2) / 2 : T(0);
         grad[e] = ok ? -(diff / s2) : T(0);
       }
-      break;
+
     }
-    case 2: {  // AHMC_TARGET_FUNNEL (research/notebooks/geweke_test.ipynb cell 4)
+    if constexpr (TK == 2) {  // AHMC_TARGET_FUNNEL (research/notebooks/geweke_test.ipynb cell 4)
       T y = group_bcast<G>(th[0], 0);
       T ssp = 0;
 #pragma unroll
@@ -275,9 +275,9 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
         T gv = (d == 0) ? -(-y / 9 - nm1 / 2 + ss * ey / 2) : th[e] * ey;
         grad[e] = (d < D) ? gv : T(0);
       }
-      break;
+
     }
-    case 3: {  // AHMC_TARGET_HIER_GAUSS: θ = (μ, log τ, x...)
+    if constexpr (TK == 3) {  // AHMC_TARGET_HIER_GAUSS: θ = (μ, log τ, x...)
       T mu = group_bcast<G>(th[0], 0);
       T lt = (E >= 2) ? group_bcast<G>(th[E >= 2 ? 1 : 0], 0) : group_bcast<G>(th[0], 1);
       T s[2] = {0, 0};
@@ -303,9 +303,9 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
         else gv = (th[e] - mu) * itau2;
         grad[e] = (d < D) ? gv : T(0);
       }
-      break;
+
     }
-    default: {
+    if constexpr (TK < 0 || TK > 3) {
 #pragma unroll
       for (int e = 0; e < E; ++e) grad[e] = Lim<T>::nan();
       part = Lim<T>::nan();
@@ -359,7 +359,7 @@ __device__ __forceinline__ T kinetic_partial(const T (&r)[E], const T (&minv)[E]
 
 // One leapfrog step of step i of n (tempering indices) with signed step size eps:
 //   r -= ϵ/2 g ; θ += ϵ M⁻¹ r ; (ℓπ, g) = ∂H∂θ(θ) ; r -= ϵ/2 g ; ℓκ = -½ rᵀM⁻¹r ; sanitise
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp,
                                               const LeapfrogP<T>& lf, int lane, int d0, int64_t i, int64_t n) {
   temper(lf, z.r, i, true, n);
@@ -369,7 +369,7 @@ __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E]
 #pragma unroll
   for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
   T red[2];
-  red[0] = target_eval<T, G, E>(tp, z.th, z.g, lane, d0);
+  red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
   temper(lf, z.r, i, false, n);
@@ -380,10 +380,10 @@ __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E]
 }
 
 // phasepoint(h, θ, r): fill the caches at the current (θ, r) (src/hamiltonian.jl:115-119)
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __device__ __forceinline__ void fill_caches(Point<T, E>& z, const T (&minv)[E], const TargetP<T>& tp, int lane, int d0) {
   T red[2];
-  red[0] = target_eval<T, G, E>(tp, z.th, z.g, lane, d0);
+  red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
   red[1] = kinetic_partial(z.r, minv);
   group_allsum<G>(red);
   z.lp = sanitize(red[0]);

@@ -1,0 +1,69 @@
+// ahmc_inst.hip — one translation unit per (AHMC_INST_T, AHMC_INST_TK): the kernels of that element
+// type and log-density family for every thread geometry.  Built 8 times by build.py.
+#include <type_traits>
+
+#include "ahmc_inst.hpp"
+#include "ahmc_nuts.hpp"
+
+#ifndef AHMC_INST_T
+#error "compile with -DAHMC_INST_T=float|double -DAHMC_INST_TK=0..3"
+#endif
+
+namespace ahmc {
+
+#define GEO_LAUNCH(KERNEL, ...)                                                                       \
+  with_geometry(G, E, [&](auto g, auto e) {                                                            \
+    hipLaunchKernelGGL((KERNEL<T, decltype(g)::value, decltype(e)::value, TK>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+  })
+
+template <class T, int TK>
+void Inst<T, TK>::fill_caches(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p) { GEO_LAUNCH(k_fill_caches, p); }
+template <class T, int TK>
+void Inst<T, TK>::refresh(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p) { GEO_LAUNCH(k_refresh, p); }
+template <class T, int TK>
+void Inst<T, TK>::leapfrog(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p) { GEO_LAUNCH(k_leapfrog, p); }
+template <class T, int TK>
+void Inst<T, TK>::hmc(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p) { GEO_LAUNCH(k_hmc, p); }
+template <class T, int TK>
+void Inst<T, TK>::find_eps(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p, T* eps_out) {
+  GEO_LAUNCH(k_find_eps, p, eps_out);
+}
+
+template <class T, int TK>
+int Inst<T, TK>::nuts_occupancy(int G, int E, bool linw, size_t smem) {
+  int occ = 0;
+  hipError_t err = hipErrorInvalidValue;
+  with_geometry(G, E, [&](auto g, auto e) {
+    constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
+    if (linw) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, true, TK>, 64, smem);
+    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, false, TK>, 64, smem);
+  });
+  return err == hipSuccess ? occ : 0;
+}
+
+template <class T, int TK>
+void Inst<T, TK>::nuts_set_smem(int G, int E, bool linw, size_t smem) {
+  with_geometry(G, E, [&](auto g, auto e) {
+    constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
+    if (linw)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nuts<T, GG, EE, true, TK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    else
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nuts<T, GG, EE, false, TK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  (void)hipGetLastError();
+}
+
+template <class T, int TK>
+void Inst<T, TK>::nuts(int G, int E, bool linw, unsigned grid, size_t smem, hipStream_t s, const KP<T>& p) {
+  with_geometry(G, E, [&](auto g, auto e) {
+    constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
+    if (linw) hipLaunchKernelGGL((k_nuts<T, GG, EE, true, TK>), dim3(grid), dim3(64), smem, s, p);
+    else hipLaunchKernelGGL((k_nuts<T, GG, EE, false, TK>), dim3(grid), dim3(64), smem, s, p);
+  });
+}
+
+template struct Inst<AHMC_INST_T, AHMC_INST_TK>;
+
+}  // namespace ahmc

@@ -1,0 +1,60 @@
+// ahmc_inst.hpp — launch table of the target-dependent kernels.
+//
+// The built-in log-density family is a COMPILE-TIME parameter of every kernel that evaluates it
+// (a 4-way run-time switch costs 36 VGPRs in k_nuts), so each (element type, family) pair gets its
+// own translation unit (ahmc_inst.hip compiled 8 times, in parallel, by build.py) that explicitly
+// instantiates Inst<T, TK>; the host API (ahmc_api.hip) only sees these declarations.
+#pragma once
+
+#include "ahmc_kernels.hpp"
+
+namespace ahmc {
+
+// Thread geometries (G lanes per chain, E elements per lane) with compiled kernels.
+#define AHMC_GEOMETRIES(X) X(4, 1) X(4, 2) X(4, 4) X(8, 4) X(16, 4) X(32, 4) X(64, 4) X(64, 8) X(64, 2)
+
+// call f(std::integral_constant<int,G>{}, std::integral_constant<int,E>{}) for a run-time geometry
+template <class F>
+inline void with_geometry(int G, int E, F&& f) {
+#define AHMC_GEO_CASE(g, e) \
+  if (G == g && E == e) { f(std::integral_constant<int, g>{}, std::integral_constant<int, e>{}); return; }
+  AHMC_GEOMETRIES(AHMC_GEO_CASE)
+#undef AHMC_GEO_CASE
+}
+
+constexpr int AHMC_N_TARGETS = 4;  // iso, diag, funnel, hier (AHMC_TARGET_* 0..3)
+
+template <class T, int TK>
+struct Inst {
+  static void fill_caches(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  static void refresh(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  static void leapfrog(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  static void hmc(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  static void find_eps(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p, T* eps_out);
+  static int nuts_occupancy(int G, int E, bool linw, size_t smem);  // single-wave workgroups per CU
+  static void nuts_set_smem(int G, int E, bool linw, size_t smem);
+  static void nuts(int G, int E, bool linw, unsigned grid, size_t smem, hipStream_t s, const KP<T>& p);
+};
+
+#define AHMC_DECLARE_INST(T) \
+  extern template struct Inst<T, 0>; extern template struct Inst<T, 1>; \
+  extern template struct Inst<T, 2>; extern template struct Inst<T, 3>;
+
+#ifndef AHMC_INST_T  // the host API only links against the instantiations
+AHMC_DECLARE_INST(float)
+AHMC_DECLARE_INST(double)
+#endif
+
+// run f(std::integral_constant<int,TK>{}) for a run-time target kind 0..3
+template <class F>
+inline void with_target(int kind, F&& f) {
+  switch (kind) {
+    case 0: f(std::integral_constant<int, 0>{}); break;
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    default: break;
+  }
+}
+
+}  // namespace ahmc

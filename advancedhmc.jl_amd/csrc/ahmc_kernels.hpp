@@ -71,6 +71,11 @@ struct KP {
   T init_eps;
   int max_iters;
 };
+// LDS / scratch layout of k_nuts (ahmc_nuts.hpp), needed by the host launch plan as well
+constexpr int NUTS_NSC = 3;      // T scalars per pending level: w, Σα, ΔH_max
+constexpr int NUTS_NSI = 2;      // int scalars per pending level: nα, candidate leaf index
+constexpr int NUTS_DORMANT = 6;  // vector slots OTH_TH, OTH_R, OTH_G, TREE_A, Z0_R, Z0_G
+
 template <class T, int G, int E>
 struct Geo {
   static constexpr int CPW = 64 / G;  // chains per wave
@@ -171,7 +176,7 @@ __device__ __forceinline__ void accumulate(const KP<T>& p, int64_t c, int d0, in
 // ------------------------------------------------------------------------------------------------
 // phasepoint(h, θ, r) for arrays already in the context (ahmc_set_position)
 // ------------------------------------------------------------------------------------------------
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __global__ __launch_bounds__(256) void k_fill_caches(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void k_fill_caches(KP<T> p) {
   load_minv<T, E>(p, c, d0, minv);
   load_vec<T, E>(z.th, p.th(), c * p.D, d0, p.D, T(0));
   load_vec<T, E>(z.r, p.r(), c * p.D, d0, p.D, T(0));
-  fill_caches<T, G, E>(z, minv, p.tp, lane, d0);
+  fill_caches<T, G, E, TK>(z, minv, p.tp, lane, d0);
   store_vec<T, E>(z.g, p.g(), c * p.D, d0, p.D);
   if (lane == 0) {
     p.lp()[c] = z.lp;
@@ -204,18 +209,20 @@ __global__ __launch_bounds__(256) void k_kinetic(KP<T> p) {
 }
 
 // refresh(rng, refreshment, h, z)
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __global__ __launch_bounds__(256) void k_refresh(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
   Point<T, E> z;
   T minv[E];
   load_minv<T, E>(p, c, d0, minv);
+  load_vec<T, E>(z.r, p.r(), c * p.D, d0, p.D, T(0));  // α r + sqrt(1-α²) ξ needs the old momentum
   load_vec<T, E>(z.th, p.th(), c * p.D, d0, p.D, T(0));
-  load_vec<T, E>(z.r, p.r(), c * p.D, d0, p.D, T(0));
   Rng rng = make_rng(p, c);
+  const T eps = chain_eps(p, rng, c);  // jitter(rng, lf) (src/integrator.jl:140-156)
   draw_momentum<T, E>(p, rng, RNG_MOMENTUM, c, d0, z.r, p.refresh_alpha);
-  fill_caches<T, G, E>(z, minv, p.tp, lane, d0);
+  if (lane == 0) p.eps_cur()[c] = eps;
+  fill_caches<T, G, E, TK>(z, minv, p.tp, lane, d0);
   store_point<T, E>(p, c, d0, lane, z);
 }
 
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void k_refresh(KP<T> p) {
 // step(lf, h, z, n_steps) fused: src/integrator.jl:216-265.  Each chain stops after its own
 // first non-finite point (the reference's scalar-chain behaviour; Q1 in DESIGN.md).
 // ------------------------------------------------------------------------------------------------
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __global__ __launch_bounds__(256) void k_leapfrog(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void k_leapfrog(KP<T> p) {
   bool alive = true;
   for (int64_t i = 1; i <= n; ++i) {
     if (alive) {
-      leapfrog_step<T, G, E>(z, minv, eps, p.tp, p.lf, lane, d0, i, n);
+      leapfrog_step<T, G, E, TK>(z, minv, eps, p.tp, p.lf, lane, d0, i, n);
       alive = is_finite(z.lp) && is_finite(z.lk);
     }
   }
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256) void k_lf_post(KP<T> p, int fwd, int64_t i, in
 // energies, the categorical index is drawn exactly as randcat does (src/utilities.jl:51-59),
 // pass 2 re-integrates to the selected point (bitwise the same arithmetic) — no (L+1)·D store.
 // ------------------------------------------------------------------------------------------------
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
   Rng rng = make_rng(p, c);
   const T eps = chain_eps(p, rng, c);
   draw_momentum<T, E>(p, rng, RNG_MOMENTUM, c, d0, z0.r, p.refresh_alpha);
-  fill_caches<T, G, E>(z0, minv, p.tp, lane, d0);
+  fill_caches<T, G, E, TK>(z0, minv, p.tp, lane, d0);
   const T H0 = -(z0.lp + z0.lk);
   const int64_t L = p.L;
   bool is_accept;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
     bool alive = true;
     for (int64_t i = 1; i <= L; ++i) {
       if (alive) {
-        leapfrog_step<T, G, E>(z, minv, eps, p.tp, p.lf, lane, d0, i, L);
+        leapfrog_step<T, G, E, TK>(z, minv, eps, p.tp, p.lf, lane, d0, i, L);
         alive = is_finite(z.lp) && is_finite(z.lk);
       }
     }
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
     bool alive = true;
     for (int64_t i = 1; i <= n_bwd; ++i) {
       if (alive) {
-        leapfrog_step<T, G, E>(z, minv, -eps, p.tp, p.lf, lane, d0, i, n_bwd);
+        leapfrog_step<T, G, E, TK>(z, minv, -eps, p.tp, p.lf, lane, d0, i, n_bwd);
         got_bwd = i;
         Hs[n_bwd - i] = -(z.lp + z.lk);  // every lane of the group writes the same value and
                                          // later reads back only what it wrote itself
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
     alive = true;
     for (int64_t i = 1; i <= n_fwd; ++i) {
       if (alive) {
-        leapfrog_step<T, G, E>(z, minv, eps, p.tp, p.lf, lane, d0, i, n_fwd);
+        leapfrog_step<T, G, E, TK>(z, minv, eps, p.tp, p.lf, lane, d0, i, n_fwd);
         got_fwd = i;
         Hs[n_bwd + i] = -(z.lp + z.lk);
         alive = is_finite(z.lp) && is_finite(z.lk);
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
     const int64_t steps = sel >= n_bwd ? sel - n_bwd : n_bwd - sel;
     const T e2 = sel >= n_bwd ? eps : -eps;
     const int64_t ntot = sel >= n_bwd ? n_fwd : n_bwd;
-    for (int64_t i = 1; i <= steps; ++i) leapfrog_step<T, G, E>(z, minv, e2, p.tp, p.lf, lane, d0, i, ntot);
+    for (int64_t i = 1; i <= steps; ++i) leapfrog_step<T, G, E, TK>(z, minv, e2, p.tp, p.lf, lane, d0, i, ntot);
     Hprop = -(z.lp + z.lk);
   }
   // accept_phasepoint! + momentum flip (src/trajectory.jl:281-283)
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
 // ------------------------------------------------------------------------------------------------
 // find_good_stepsize for every chain (src/trajectory.jl:753-837), incl. the Q3 quirk
 // ------------------------------------------------------------------------------------------------
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __global__ __launch_bounds__(256) void k_find_eps(KP<T> p, T* eps_out) {
   AHMC_GEOMETRY();
   if (!active) return;
@@ -418,14 +425,14 @@ __global__ __launch_bounds__(256) void k_find_eps(KP<T> p, T* eps_out) {
   load_vec<T, E>(z0.th, p.th(), c * p.D, d0, p.D, T(0));
   Rng rng = make_rng(p, c);
   draw_momentum<T, E>(p, rng, RNG_FINDEPS, c, d0, z0.r, T(0));
-  fill_caches<T, G, E>(z0, minv, p.tp, lane, d0);
+  fill_caches<T, G, E, TK>(z0, minv, p.tp, lane, d0);
   const T H = -(z0.lp + z0.lk);
   LeapfrogP<T> plain;
   plain.kind = 0;
   plain.sqrt_alpha = 1;
   auto A = [&](T e) {
     Point<T, E> z = z0;
-    leapfrog_step<T, G, E>(z, minv, e, p.tp, plain, lane, d0, 1, 1);
+    leapfrog_step<T, G, E, TK>(z, minv, e, p.tp, plain, lane, d0, 1, 1);
     return -(z.lp + z.lk);
   };
   const T log_a_min = 2 * log(T(0.5)), log_a_cross = log(T(0.5)), log_a_max = log(T(0.75));

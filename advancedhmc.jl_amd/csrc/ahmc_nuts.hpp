@@ -28,9 +28,6 @@
 
 namespace ahmc {
 
-constexpr int NUTS_NSC = 3;    // T scalars per level: w, Σα, ΔH_max
-constexpr int NUTS_NSI = 2;    // int scalars per level: nα, candidate leaf index
-constexpr int NUTS_DORMANT = 6;  // OTH_TH, OTH_R, OTH_G, TREE_A, Z0_R, Z0_G
 constexpr double LINW_LIMIT = 600.0;  // exp(600)·2^10 leaves is still far from the Float64 overflow; Float32 uses 60
 enum { SL_OTH_TH = 0, SL_OTH_R = 1, SL_OTH_G = 2, SL_TREE_A = 3, SL_Z0_R = 4, SL_Z0_G = 5 };
 
@@ -96,7 +93,7 @@ struct Slots {
 };
 
 // the vector half of a leapfrog step (no energies): used to re-integrate to the candidate
-template <class T, int G, int E>
+template <class T, int G, int E, int TK>
 __device__ __forceinline__ void leapfrog_core(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp,
                                               const LeapfrogP<T>& lf, int lane, int d0) {
   temper(lf, z.r, 1, true, 1);
@@ -105,7 +102,7 @@ __device__ __forceinline__ void leapfrog_core(Point<T, E>& z, const T (&minv)[E]
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
 #pragma unroll
   for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
-  (void)target_eval<T, G, E>(tp, z.th, z.g, lane, d0);
+  (void)target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
   temper(lf, z.r, 1, false, 1);
@@ -135,7 +132,7 @@ struct DrawStream {
   __device__ __forceinline__ double randexp() { return -log(uniform()); }
 };
 
-template <class T, int G, int E, bool LINW>
+template <class T, int G, int E, bool LINW, int TK>
 __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
   constexpr int CPW = 64 / G;
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
@@ -181,16 +178,19 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
     if (__builtin_amdgcn_ballot_w64(active) == 0) return;  // nothing to do for this wave (redo pass: the common case)
     const int64_t cc = active ? c : 0;  // inactive groups shadow chain 0 and never write
 
-    // ---- transition prologue (src/sampler.jl:54-57): jitter, fresh momentum, caches ----
+    // ---- the start point z0 = refresh(…) was prepared by k_refresh (jitter, fresh momentum, caches:
+    // src/sampler.jl:54-57) in the launch before this one: keeping the f64 Box–Muller out of this
+    // kernel saves ~25 VGPRs at its register peak ----
     Point<T, E> cur;
     T minv[E];
     load_minv<T, E>(p, cc, d0, minv);
     load_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D, T(0));
-    if (p.refresh_alpha != T(0)) load_vec<T, E>(cur.r, p.r(), cc * p.D, d0, p.D, T(0));
+    load_vec<T, E>(cur.r, p.r(), cc * p.D, d0, p.D, T(0));
+    load_vec<T, E>(cur.g, p.g(), cc * p.D, d0, p.D, T(0));
+    cur.lp = p.lp()[cc];
+    cur.lk = p.lk()[cc];
     Rng rng = make_rng(p, cc);
-    const T eps = chain_eps(p, rng, cc);
-    draw_momentum<T, E>(p, rng, RNG_MOMENTUM, cc, d0, cur.r, p.refresh_alpha);
-    fill_caches<T, G, E>(cur, minv, p.tp, lane, d0);
+    const T eps = p.eps_cur()[cc];
     const T H0 = -(cur.lp + cur.lk);
     DrawStream ds;
     ds.init(rng);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
         int merged = 0;
         if (alive) {
           // leaf: one leapfrog step in direction v (:638-647)
-          leapfrog_step<T, G, E>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+          leapfrog_step<T, G, E, TK>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
           pos_cur += v;
           const T ne = cur.lp + cur.lk;  // neg_energy(z′)
           const T dH = -ne - H0;
@@ -428,13 +428,13 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
       for (int s = 0;; ++s) {
         const bool go = s < steps;
         if (__builtin_amdgcn_ballot_w64(go) == 0) break;
-        if (go) leapfrog_core<T, G, E>(zc, minv, es, p.tp, p.lf, lane, d0);
+        if (go) leapfrog_core<T, G, E, TK>(zc, minv, es, p.tp, p.lf, lane, d0);
       }
       if (active && redo) {
         if (lane == 0) p.redo[ce] = 1;  // left untouched: the log-domain kernel redoes this chain
       } else if (active) {
         if (p.redo_only && lane == 0) p.redo[ce] = 0;
-        fill_caches<T, G, E>(zc, minv, p.tp, lane, d0);  // ℓπ, -∇ℓπ, ℓκ of the candidate
+        fill_caches<T, G, E, TK>(zc, minv, p.tp, lane, d0);  // ℓπ, -∇ℓπ, ℓκ of the candidate
         store_point<T, E>(p, ce, d0, lane, zc);
         const T H = -(zc.lp + zc.lk);
         if (lane == 0) {
