@@ -96,6 +96,8 @@ struct Ctx : CtxBase {
   T* scratch = nullptr;
   size_t scratch_bytes = 0;
   unsigned int* queue = nullptr;
+  T* znorm = nullptr;  // standard normals of the momentum draws of one k_nuts launch
+  size_t znorm_elems = 0;
   int32_t* redo = nullptr;  // per-chain "redo in the log domain" flags of the NUTS fast pass
   int nuts_blocks = 0;
   // static multinomial
@@ -118,7 +120,7 @@ struct Ctx : CtxBase {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
-                    da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo};
+                    da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -258,7 +260,7 @@ int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
 //   many vector slots (hottest first: pending levels 0,1,2,…, then the dormant ones) live in LDS;
 //   the rest go to a per-wave region of global scratch.
 template <class T, bool LINW>
-int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, size_t& smem, int& n_lds_slots) {
+int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, int& wpb, size_t& smem, int& n_lds_slots) {
   const int CPW = 64 / c->G;
   const int NLEV = max_depth > 1 ? max_depth - 1 : 1;
   const int n_slots = 2 * NLEV + NUTS_DORMANT;
@@ -282,8 +284,14 @@ int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, size_t& smem, int& n_lds_sl
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] k_nuts<%s,%d,%d,linw=%d>: occupancy %d waves/CU, %d/%d vector slots in LDS, %zu B LDS/wave, %lld waves\n", sizeof(T) == 8 ? "f64" : "f32", c->G, c->E, (int)LINW, occ, n_lds_slots, n_slots, smem, (long long)n_chunks);
   with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, LINW, smem); });
-  blocks = (int)n_chunks;
-  size_t need = (size_t)blocks * (size_t)(n_slots - n_lds_slots) * slot_bytes + 256;
+  // waves per workgroup (AHMC_NUTS_WPB): measured on cfg2, leapfrog/s for 1 / 2 / 4 waves per workgroup =
+  // 8.4e8 / 7.0e8 / 5.6e8 — a workgroup holds its LDS and registers until its slowest wave ends
+  static const int wpb_env = getenv("AHMC_NUTS_WPB") ? atoi(getenv("AHMC_NUTS_WPB")) : 1;
+  wpb = std::max(1, std::min(4, wpb_env));
+  blocks = (int)((n_chunks + wpb - 1) / wpb);
+  smem *= (size_t)wpb;
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, LINW, smem); });
+  size_t need = (size_t)blocks * wpb * (size_t)(n_slots - n_lds_slots) * slot_bytes + 256;
   if (need > c->scratch_bytes) {
     if (c->scratch) {
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -298,20 +306,20 @@ int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, size_t& smem, int& n_lds_sl
 
 template <class T, bool LINW>
 int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
-  int blocks = 0, n_lds_slots = 0;
+  int blocks = 0, n_lds_slots = 0, wpb = 1;
   size_t smem = 0;
-  int rc = plan_nuts<T, LINW>(c, max_depth, blocks, smem, n_lds_slots);
+  int rc = plan_nuts<T, LINW>(c, max_depth, blocks, wpb, smem, n_lds_slots);
   if (rc) return rc;
   p.scratch = c->scratch;
   p.n_lds_levels = n_lds_slots;
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts(c->G, c->E, LINW, (unsigned)blocks, smem, c->stream, p); });
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts(c->G, c->E, LINW, (unsigned)blocks, wpb, smem, c->stream, p); });
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
 
 template <class T>
 int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha,
-                    bool accum) {
+                    bool accum, int n_trans = 1, T* samples_dev = nullptr) {
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
   int rc = check_builtin(c, "nuts_transition");
   if (rc) return rc;
@@ -332,9 +340,23 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.n_chunks = (unsigned int)((c->N + CPW - 1) / CPW);
   p.redo = c->redo;
   static const bool no_linw = getenv("AHMC_NUTS_LOGW") != nullptr;
-  // transition prologue (src/sampler.jl:54-57): jitter + refresh(rng, refreshment, h, z) for all chains
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::refresh(c->G, c->E, group_grid(c), c->stream, p); });
-  HIPCHK(hipGetLastError());
+  // standard normals of the n_trans momentum refreshes (rand_momentum, src/metric.jl:290-309)
+  {
+    const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
+    if (need > c->znorm_elems) {
+      if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
+      c->znorm = nullptr;
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->znorm), need * sizeof(T)));
+      c->znorm_elems = need;
+    }
+    const int64_t pairs = ((c->D + 1) / 2) * c->N * (int64_t)n_trans;
+    const unsigned grid = (unsigned)std::min<int64_t>((pairs + 255) / 256, (int64_t)c->n_cu * 32);
+    hipLaunchKernelGGL((k_normals<T>), dim3(grid), dim3(256), 0, c->stream, p, c->znorm, n_trans);
+    HIPCHK(hipGetLastError());
+  }
+  p.n_trans = n_trans;
+  p.znorm = c->znorm;
+  p.samples_out = samples_dev;
   if (sampler == AHMC_TS_MULTINOMIAL && !no_linw) {
     // fast pass: multinomial weights in the linear domain; chains that came near overflow are
     // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
@@ -348,7 +370,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
     rc = launch_nuts<T, false>(c, p, max_depth);
   }
   if (rc) return rc;
-  c->iteration += 1;
+  c->iteration += (uint64_t)n_trans;
   return AHMC_OK;
 }
 
@@ -902,12 +924,34 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
     T* so = static_cast<T*>(samples_out);
     bool reset_done = false;
     const size_t nb = sizeof(T) * c->D * c->N;
-    for (int64_t i = 1; i <= n_samples; ++i) {  // src/sampler.jl:182-228
+    // can k_nuts write the kept draws itself?  (device buffer, or none requested)
+    bool so_on_device = false;
+    if (so) {
+      hipPointerAttribute_t at;
+      so_on_device = hipPointerGetAttributes(&at, so) == hipSuccess && at.type == hipMemoryTypeDevice;
+      (void)hipGetLastError();
+    }
+    static const int batch_env = getenv("AHMC_NUTS_BATCH") ? atoi(getenv("AHMC_NUTS_BATCH")) : 16;
+    const int64_t batch = std::max(1, batch_env);
+    for (int64_t i = 1; i <= n_samples;) {  // src/sampler.jl:182-228
       const bool keep = !drop_warmup || i > n_adapts;
       if (keep && !reset_done) {
         int rc0 = reset_accum(c);
         if (rc0) return rc0;
         reset_done = true;
+      }
+      const bool adapting = c->adapt_kind != AHMC_ADAPT_NONE && i <= n_adapts;
+      if (cfg->nuts && !adapting && keep && (!so || so_on_device)) {
+        // chains are independent and nothing is adapted any more: run a batch of transitions per
+        // launch (no per-transition barrier; see the note on tree-size tails in ahmc_nuts.hpp)
+        const int64_t k = std::min<int64_t>(batch, n_samples - i + 1);
+        const int64_t j = i - (drop_warmup ? n_adapts : 0);
+        int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, true,
+                                 (int)k, so ? so + (size_t)(j - 1) * c->D * c->N : nullptr);
+        if (rc) return rc;
+        c->acc_ntrans += k;
+        i += k;
+        continue;
       }
       int rc = cfg->nuts ? nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, keep)
                          : hmc_transition(c, cfg->L, cfg->lambda, cfg->sampler, cfg->refresh_alpha, keep);
@@ -921,6 +965,7 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
           HIPCHK(hipMemcpyAsync(so + (size_t)(j - 1) * c->D * c->N, c->th, nb, hipMemcpyDefault, c->stream));
         }
       }
+      ++i;
     }
     return AHMC_OK;
   });

@@ -56,11 +56,11 @@ void Inst<T, TK>::nuts_set_smem(int G, int E, bool linw, size_t smem) {
 }
 
 template <class T, int TK>
-void Inst<T, TK>::nuts(int G, int E, bool linw, unsigned grid, size_t smem, hipStream_t s, const KP<T>& p) {
+void Inst<T, TK>::nuts(int G, int E, bool linw, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
   with_geometry(G, E, [&](auto g, auto e) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    if (linw) hipLaunchKernelGGL((k_nuts<T, GG, EE, true, TK>), dim3(grid), dim3(64), smem, s, p);
-    else hipLaunchKernelGGL((k_nuts<T, GG, EE, false, TK>), dim3(grid), dim3(64), smem, s, p);
+    if (linw) hipLaunchKernelGGL((k_nuts<T, GG, EE, true, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
+    else hipLaunchKernelGGL((k_nuts<T, GG, EE, false, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
   });
 }
 

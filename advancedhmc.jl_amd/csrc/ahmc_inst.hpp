@@ -11,7 +11,7 @@
 namespace ahmc {
 
 // Thread geometries (G lanes per chain, E elements per lane) with compiled kernels.
-#define AHMC_GEOMETRIES(X) X(4, 1) X(4, 2) X(4, 4) X(8, 4) X(16, 4) X(32, 4) X(64, 4) X(64, 8) X(64, 2)
+#define AHMC_GEOMETRIES(X) X(4, 1) X(4, 2) X(4, 4) X(8, 4) X(16, 4) X(32, 4) X(64, 4) X(64, 8) X(64, 2) X(16, 8) X(32, 8)
 
 // call f(std::integral_constant<int,G>{}, std::integral_constant<int,E>{}) for a run-time geometry
 template <class F>
@@ -33,7 +33,7 @@ struct Inst {
   static void find_eps(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p, T* eps_out);
   static int nuts_occupancy(int G, int E, bool linw, size_t smem);  // single-wave workgroups per CU
   static void nuts_set_smem(int G, int E, bool linw, size_t smem);
-  static void nuts(int G, int E, bool linw, unsigned grid, size_t smem, hipStream_t s, const KP<T>& p);
+  static void nuts(int G, int E, bool linw, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
 };
 
 #define AHMC_DECLARE_INST(T) \

@@ -63,6 +63,9 @@ struct KP {
   int n_lds_levels;     // number of vector slots held in LDS (hottest first)
   int32_t* redo;        // per-chain flag: linear-domain weights came near overflow → redo in log domain
   int redo_only;        // 1: process only the flagged chains
+  int n_trans;          // transitions per launch of k_nuts
+  const T* znorm;       // (n_trans, D, N) standard normals of the momentum draws (k_normals)
+  T* samples_out;       // optional (n_trans, D, N) device buffer receiving θ after every transition
   // static HMC
   int64_t L;
   T* hmc_H;  // (L+1, N) energies for MultinomialTS
@@ -129,6 +132,29 @@ __device__ __forceinline__ void draw_momentum(const KP<T>& p, const Rng& rng, ui
     T s = sqrt(1 - alpha * alpha);
 #pragma unroll
     for (int e = 0; e < E; ++e) z[e] = alpha * r[e] + s * z[e];
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) r[e] = (d0 + e < p.D) ? z[e] : T(0);
+}
+
+// the same refresh with the standard normals read from memory (written by k_normals)
+template <class T, int E>
+__device__ __forceinline__ void momentum_from_normals(const KP<T>& p, const T* __restrict__ zsrc, int64_t c, int d0,
+                                                      T (&r)[E]) {
+  T z[E];
+  load_vec<T, E>(z, zsrc, c * p.D, d0, p.D, T(0));
+  if (p.minv) {
+    T sq[E];
+    load_vec<T, E>(sq, p.sqrt_minv, p.minv_per_chain ? c * p.D : 0, d0, p.D, T(1));
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] = z[e] / sq[e];  // r ./= sqrtM⁻¹
+  }
+  if (p.refresh_alpha != T(0)) {  // PartialMomentumRefreshment: α r + sqrt(1-α²) ξ, r = the stored momentum
+    T ro[E];
+    load_vec<T, E>(ro, p.r(), c * p.D, d0, p.D, T(0));
+    const T s = sqrt(1 - p.refresh_alpha * p.refresh_alpha);
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] = p.refresh_alpha * ro[e] + s * z[e];
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) r[e] = (d0 + e < p.D) ? z[e] : T(0);
@@ -535,6 +561,27 @@ __global__ __launch_bounds__(256) void k_adapt_wv(AdaptP<T> a) {
   }
   a.wv_mu[k] = mu;
   a.wv_M[k] = M;
+}
+
+// standard normals of the momentum draws of `n_trans` consecutive transitions: element d of chain c
+// at transition kt = Box–Muller half (d & 1) of Philox block (chain, iteration+kt, MOMENTUM, d >> 1)
+template <class T>
+__global__ __launch_bounds__(256) void k_normals(KP<T> p, T* __restrict__ out, int n_trans) {
+  const int64_t pairs_per_chain = (p.D + 1) / 2;
+  const int64_t total = pairs_per_chain * p.N * n_trans;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t kt = i / (pairs_per_chain * p.N);
+    const int64_t rem = i - kt * pairs_per_chain * p.N;
+    const int64_t c = rem / pairs_per_chain;
+    const int pair = (int)(rem - c * pairs_per_chain);
+    Rng rng = make_rng(p, c);
+    rng.iter = p.iteration + (uint32_t)kt;
+    double a, b;
+    rng.normal_pair(RNG_MOMENTUM, (uint32_t)pair, a, b);
+    T* dst = out + (kt * p.N + c) * p.D + 2 * pair;
+    dst[0] = (T)a;
+    if (2 * pair + 1 < p.D) dst[1] = (T)b;
+  }
 }
 
 template <class T>

@@ -133,7 +133,7 @@ struct DrawStream {
 };
 
 template <class T, int G, int E, bool LINW, int TK>
-__global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
+__global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
   constexpr int CPW = 64 / G;
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
   constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
   const int nwaves = blockDim.x >> 6;
   const int wib = threadIdx.x >> 6;
   const int lane64 = threadIdx.x & 63;
-  const int lane = lane64 & (G - 1);
-  const int gi = lane64 / G;
-  const int d0 = lane * E;
+  int lane = lane64 & (G - 1);
+  int gi = lane64 / G;
+  int d0 = lane * E;
   const int NLEV = p.max_depth > 1 ? p.max_depth - 1 : 1;  // pending levels 0 .. NLEV-1
   const int n_slots = 2 * NLEV + NUTS_DORMANT;
   const int n_lds_slots = p.n_lds_levels;  // (re-used field) number of vector slots held in LDS
@@ -170,27 +170,43 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
   // One chunk of 64/G chains per wave, one wave per workgroup: the hardware dispatcher is the work
   // queue.  (A persistent per-wave loop over chunks was measured first: it makes every prologue and
   // epilogue value loop-invariant, the compiler hoists them all and the kernel needs 230+ VGPRs.)
-  {
-    const unsigned int chunk = blockIdx.x * nwaves + wib;
-    if (chunk >= p.n_chunks) return;
-    const int64_t c = (int64_t)chunk * CPW + gi;
-    const bool active = c < p.N && (p.redo_only == 0 || p.redo[c < p.N ? c : 0] != 0);
-    if (__builtin_amdgcn_ballot_w64(active) == 0) return;  // nothing to do for this wave (redo pass: the common case)
-    const int64_t cc = active ? c : 0;  // inactive groups shadow chain 0 and never write
+  //
+  // The wave runs p.n_trans consecutive transitions of its chains before it exits.  Tree sizes
+  // are heavy-tailed (cfg2 after adaptation: mean 31 leaves, but every transition has a chain with
+  // 700-1000 leaves, a strictly serial ~2.3 ms); with one transition per launch the whole GPU waits
+  // for that chain each time.  Chains are independent, so batching transitions removes the
+  // per-transition barrier and the tail is paid once per launch.
+  const unsigned int chunk = blockIdx.x * nwaves + wib;
+  if (chunk >= p.n_chunks) return;
+  const int64_t c = (int64_t)chunk * CPW + gi;
+  int64_t cc = c < p.N ? c : 0;  // out-of-range groups shadow chain 0 and never write
+  // redo pass: only the chains flagged by the linear-domain pass, from the transition they bailed at
+  const int kt0 = p.redo_only ? p.redo[cc] - 1 : 0;
+  bool active = c < p.N && kt0 >= 0;
+  if (__builtin_amdgcn_ballot_w64(active) == 0) return;  // (redo pass: the common case)
+  T minv[E];
+  load_minv<T, E>(p, cc, d0, minv);
+  T th_cur[E];  // the chain's position, carried in registers from one transition to the next
+  load_vec<T, E>(th_cur, p.th(), cc * p.D, d0, p.D, T(0));
 
-    // ---- the start point z0 = refresh(…) was prepared by k_refresh (jitter, fresh momentum, caches:
-    // src/sampler.jl:54-57) in the launch before this one: keeping the f64 Box–Muller out of this
+  for (int kt = 0; kt < p.n_trans; ++kt) {
+    // Make the per-lane indices opaque once per transition: otherwise every address and every
+    // constant derived from them is loop-invariant w.r.t. this loop, gets hoisted out of it and
+    // stays live through the whole tree (measured: +50 VGPRs, one wave per SIMD less).
+    asm volatile("" : "+v"(cc), "+v"(d0), "+v"(lane), "+v"(gi), "+v"(sl.lane_off));
+    const bool on = active && kt >= kt0;
+    if (__builtin_amdgcn_ballot_w64(on) == 0) continue;
+    // ---- transition prologue (src/sampler.jl:54-57): jitter, fresh momentum, caches.  The standard
+    // normals come from k_normals (same Philox stream): keeping the f64 Box–Muller out of this
     // kernel saves ~25 VGPRs at its register peak ----
     Point<T, E> cur;
-    T minv[E];
-    load_minv<T, E>(p, cc, d0, minv);
-    load_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D, T(0));
-    load_vec<T, E>(cur.r, p.r(), cc * p.D, d0, p.D, T(0));
-    load_vec<T, E>(cur.g, p.g(), cc * p.D, d0, p.D, T(0));
-    cur.lp = p.lp()[cc];
-    cur.lk = p.lk()[cc];
+    copy_vec(cur.th, th_cur);
     Rng rng = make_rng(p, cc);
-    const T eps = p.eps_cur()[cc];
+    rng.iter = p.iteration + (uint32_t)kt;
+    const T eps = chain_eps(p, rng, cc);
+    momentum_from_normals<T, E>(p, p.znorm + (int64_t)kt * p.D * p.N, cc, d0, cur.r);
+    fill_caches<T, G, E, TK>(cur, minv, p.tp, lane, d0);
+    if (on && kt > 0) store_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D);  // θ0 of this transition (re-integration, redo)
     const T H0 = -(cur.lp + cur.lk);
     DrawStream ds;
     ds.init(rng);
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
     bool numerical = false;
     bool redo = false;  // LINW only: a weight came too close to overflow
     int depth = 0;
-    bool done = !active;
+    bool done = !on;
 
     for (int jw = 0; jw < p.max_depth; ++jw) {  // doubling loop (:691-723), wave-uniform
       if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
@@ -423,17 +439,19 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
       load_vec<T, E>(zc.th, p.th(), ce * p.D, d0, p.D, T(0));
       sl.load(DORM + SL_Z0_R, zc.r);
       sl.load(DORM + SL_Z0_G, zc.g);
-      const int steps = active ? (ck_tree < 0 ? -ck_tree : ck_tree) : 0;
+      const int steps = on ? (ck_tree < 0 ? -ck_tree : ck_tree) : 0;
       const T es = ck_tree < 0 ? -eps : eps;
       for (int s = 0;; ++s) {
         const bool go = s < steps;
         if (__builtin_amdgcn_ballot_w64(go) == 0) break;
         if (go) leapfrog_core<T, G, E, TK>(zc, minv, es, p.tp, p.lf, lane, d0);
       }
-      if (active && redo) {
-        if (lane == 0) p.redo[ce] = 1;  // left untouched: the log-domain kernel redoes this chain
-      } else if (active) {
-        if (p.redo_only && lane == 0) p.redo[ce] = 0;
+      if (on && redo) {
+        // stop here: the log-domain kernel resumes this chain at transition kt (its θ0 is in p.th)
+        if (lane == 0) p.redo[ce] = kt + 1;
+        active = false;
+      } else if (on) {
+        if (p.redo_only && lane == 0 && kt == p.n_trans - 1) p.redo[ce] = 0;
         fill_caches<T, G, E, TK>(zc, minv, p.tp, lane, d0);  // ℓπ, -∇ℓπ, ℓκ of the candidate
         store_point<T, E>(p, ce, d0, lane, zc);
         const T H = -(zc.lp + zc.lk);
@@ -450,9 +468,11 @@ __global__ __launch_bounds__(64) void k_nuts(KP<T> p) {
           p.st_numerr()[ce] = numerical ? 1 : 0;
         }
         accumulate<T, E>(p, ce, d0, lane, zc.th, na_tree, numerical ? 1 : 0);
+        if (p.samples_out) store_vec<T, E>(zc.th, p.samples_out + (int64_t)kt * p.D * p.N, ce * p.D, d0, p.D);
+        copy_vec(th_cur, zc.th);
       }
     }
-  }  // (single pass: one chunk of chains per wave)
+  }  // transitions of this launch
 #undef S_W
 #undef S_SA
 #undef S_DH
