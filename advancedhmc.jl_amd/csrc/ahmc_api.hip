@@ -259,16 +259,16 @@ int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
 //   occupancy (waves/CU) comes from the register budget; the LDS left per wave then decides how
 //   many vector slots (hottest first: pending levels 0,1,2,…, then the dormant ones) live in LDS;
 //   the rest go to a per-wave region of global scratch.
-template <class T, bool LINW>
-int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, int& wpb, size_t& smem, int& n_lds_slots) {
+template <class T, int MODE>
+int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, size_t& smem, int& n_lds_slots) {
   const int CPW = 64 / c->G;
   const int NLEV = max_depth > 1 ? max_depth - 1 : 1;
-  const int n_slots = 2 * NLEV + NUTS_DORMANT;
+  const int n_slots = (criterion == AHMC_TC_STRICT ? 3 : 2) * NLEV + NUTS_DORMANT;
   const size_t slot_bytes = (size_t)64 * c->E * sizeof(T);
   const size_t scalar_bytes = (size_t)NUTS_NSC * NLEV * CPW * sizeof(T) + (size_t)NUTS_NSI * NLEV * CPW * sizeof(int);
   const int64_t n_chunks = (c->N + CPW - 1) / CPW;
   int occ = 0;  // single-wave workgroups per CU
-  with_target(c->target_kind, [&](auto tk) { occ = Inst<T, decltype(tk)::value>::nuts_occupancy(c->G, c->E, LINW, scalar_bytes); });
+  with_target(c->target_kind, [&](auto tk) { occ = Inst<T, decltype(tk)::value>::nuts_occupancy(c->G, c->E, MODE, scalar_bytes); });
   if (occ < 1) occ = 4;
   if (occ > 32) occ = 32;
   const char* ov = getenv("AHMC_NUTS_WAVES_PER_CU");
@@ -282,15 +282,15 @@ int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, int& wpb, size_t& smem, int
   if (ovs) n_lds_slots = std::max(0, std::min(n_slots, atoi(ovs)));
   smem = (size_t)n_lds_slots * slot_bytes + scalar_bytes;
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
-  if (dbg) fprintf(stderr, "[ahmc] k_nuts<%s,%d,%d,linw=%d>: occupancy %d waves/CU, %d/%d vector slots in LDS, %zu B LDS/wave, %lld waves\n", sizeof(T) == 8 ? "f64" : "f32", c->G, c->E, (int)LINW, occ, n_lds_slots, n_slots, smem, (long long)n_chunks);
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, LINW, smem); });
+  if (dbg) fprintf(stderr, "[ahmc] k_nuts<%s,%d,%d,mode=%d>: occupancy %d waves/CU, %d/%d vector slots in LDS, %zu B LDS/wave, %lld waves\n", sizeof(T) == 8 ? "f64" : "f32", c->G, c->E, MODE, occ, n_lds_slots, n_slots, smem, (long long)n_chunks);
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, MODE, smem); });
   // waves per workgroup (AHMC_NUTS_WPB): measured on cfg2, leapfrog/s for 1 / 2 / 4 waves per workgroup =
   // 8.4e8 / 7.0e8 / 5.6e8 — a workgroup holds its LDS and registers until its slowest wave ends
   static const int wpb_env = getenv("AHMC_NUTS_WPB") ? atoi(getenv("AHMC_NUTS_WPB")) : 1;
   wpb = std::max(1, std::min(4, wpb_env));
   blocks = (int)((n_chunks + wpb - 1) / wpb);
   smem *= (size_t)wpb;
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, LINW, smem); });
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, MODE, smem); });
   size_t need = (size_t)blocks * wpb * (size_t)(n_slots - n_lds_slots) * slot_bytes + 256;
   if (need > c->scratch_bytes) {
     if (c->scratch) {
@@ -304,15 +304,16 @@ int plan_nuts(Ctx<T>* c, int max_depth, int& blocks, int& wpb, size_t& smem, int
   return AHMC_OK;
 }
 
-template <class T, bool LINW>
+template <class T, int MODE>
 int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
+  const int criterion = p.criterion;
   int blocks = 0, n_lds_slots = 0, wpb = 1;
   size_t smem = 0;
-  int rc = plan_nuts<T, LINW>(c, max_depth, blocks, wpb, smem, n_lds_slots);
+  int rc = plan_nuts<T, MODE>(c, max_depth, criterion, blocks, wpb, smem, n_lds_slots);
   if (rc) return rc;
   p.scratch = c->scratch;
   p.n_lds_levels = n_lds_slots;
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts(c->G, c->E, LINW, (unsigned)blocks, wpb, smem, c->stream, p); });
+  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts(c->G, c->E, MODE, (unsigned)blocks, wpb, smem, c->stream, p); });
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -325,8 +326,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   if (rc) return rc;
   if (sampler != AHMC_TS_MULTINOMIAL && sampler != AHMC_TS_SLICE)
     return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
-  if (criterion == AHMC_TC_STRICT) return fail(c, AHMC_ERR_UNSUPPORTED, "StrictGeneralisedNoUTurn has no HIP kernel yet");
-  if (criterion != AHMC_TC_CLASSIC && criterion != AHMC_TC_GENERALISED)
+  if (criterion != AHMC_TC_CLASSIC && criterion != AHMC_TC_GENERALISED && criterion != AHMC_TC_STRICT)
     return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
   if (max_depth < 1 || max_depth > 24) return fail(c, AHMC_ERR_ARGUMENT, "max_depth must be in 1..24");
   KP<T> p = make_kp(c);
@@ -357,17 +357,22 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.n_trans = n_trans;
   p.znorm = c->znorm;
   p.samples_out = samples_dev;
-  if (sampler == AHMC_TS_MULTINOMIAL && !no_linw) {
-    // fast pass: multinomial weights in the linear domain; chains that came near overflow are
-    // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
+  if (sampler == AHMC_TS_MULTINOMIAL && criterion == AHMC_TC_GENERALISED) {
+    if (!no_linw) {
+      // fast pass: multinomial weights in the linear domain; chains that came near overflow are
+      // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
+      p.redo_only = 0;
+      rc = launch_nuts<T, 0>(c, p, max_depth);
+      if (rc) return rc;
+      p.redo_only = 1;
+      rc = launch_nuts<T, 1>(c, p, max_depth);
+    } else {
+      p.redo_only = 0;
+      rc = launch_nuts<T, 1>(c, p, max_depth);
+    }
+  } else {  // SliceTS, Classic / Strict criteria: the general instantiation
     p.redo_only = 0;
-    rc = launch_nuts<T, true>(c, p, max_depth);
-    if (rc) return rc;
-    p.redo_only = 1;
-    rc = launch_nuts<T, false>(c, p, max_depth);
-  } else {
-    p.redo_only = 0;
-    rc = launch_nuts<T, false>(c, p, max_depth);
+    rc = launch_nuts<T, 2>(c, p, max_depth);
   }
   if (rc) return rc;
   c->iteration += (uint64_t)n_trans;

@@ -30,37 +30,37 @@ void Inst<T, TK>::find_eps(int G, int E, unsigned grid, hipStream_t s, const KP<
 }
 
 template <class T, int TK>
-int Inst<T, TK>::nuts_occupancy(int G, int E, bool linw, size_t smem) {
+int Inst<T, TK>::nuts_occupancy(int G, int E, int mode, size_t smem) {
   int occ = 0;
   hipError_t err = hipErrorInvalidValue;
   with_geometry(G, E, [&](auto g, auto e) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    if (linw) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, true, TK>, 64, smem);
-    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, false, TK>, 64, smem);
+    if (mode == 0) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 0, TK>, 64, smem);
+    else if (mode == 1) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 1, TK>, 64, smem);
+    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 2, TK>, 64, smem);
   });
   return err == hipSuccess ? occ : 0;
 }
 
 template <class T, int TK>
-void Inst<T, TK>::nuts_set_smem(int G, int E, bool linw, size_t smem) {
+void Inst<T, TK>::nuts_set_smem(int G, int E, int mode, size_t smem) {
   with_geometry(G, E, [&](auto g, auto e) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    if (linw)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nuts<T, GG, EE, true, TK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    else
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nuts<T, GG, EE, false, TK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const void* f = mode == 0   ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 0, TK>)
+                    : mode == 1 ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 1, TK>)
+                                : reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 2, TK>);
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
   (void)hipGetLastError();
 }
 
 template <class T, int TK>
-void Inst<T, TK>::nuts(int G, int E, bool linw, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
+void Inst<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
   with_geometry(G, E, [&](auto g, auto e) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    if (linw) hipLaunchKernelGGL((k_nuts<T, GG, EE, true, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
-    else hipLaunchKernelGGL((k_nuts<T, GG, EE, false, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
+    if (mode == 0) hipLaunchKernelGGL((k_nuts<T, GG, EE, 0, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
+    else if (mode == 1) hipLaunchKernelGGL((k_nuts<T, GG, EE, 1, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
+    else hipLaunchKernelGGL((k_nuts<T, GG, EE, 2, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
   });
 }
 

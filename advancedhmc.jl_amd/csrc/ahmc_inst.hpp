@@ -31,9 +31,9 @@ struct Inst {
   static void leapfrog(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
   static void hmc(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
   static void find_eps(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p, T* eps_out);
-  static int nuts_occupancy(int G, int E, bool linw, size_t smem);  // single-wave workgroups per CU
-  static void nuts_set_smem(int G, int E, bool linw, size_t smem);
-  static void nuts(int G, int E, bool linw, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
+  static int nuts_occupancy(int G, int E, int mode, size_t smem);  // single-wave workgroups per CU
+  static void nuts_set_smem(int G, int E, int mode, size_t smem);
+  static void nuts(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
 };
 
 #define AHMC_DECLARE_INST(T) \

@@ -77,7 +77,7 @@ struct KP {
 // LDS / scratch layout of k_nuts (ahmc_nuts.hpp), needed by the host launch plan as well
 constexpr int NUTS_NSC = 3;      // T scalars per pending level: w, Σα, ΔH_max
 constexpr int NUTS_NSI = 2;      // int scalars per pending level: nα, candidate leaf index
-constexpr int NUTS_DORMANT = 6;  // vector slots OTH_TH, OTH_R, OTH_G, TREE_A, Z0_R, Z0_G
+constexpr int NUTS_DORMANT = 7;  // vector slots OTH_TH, OTH_R, OTH_G, TREE_A, Z0_R, Z0_G, START_R (strict)
 
 template <class T, int G, int E>
 struct Geo {

@@ -29,7 +29,7 @@
 namespace ahmc {
 
 constexpr double LINW_LIMIT = 600.0;  // exp(600)·2^10 leaves is still far from the Float64 overflow; Float32 uses 60
-enum { SL_OTH_TH = 0, SL_OTH_R = 1, SL_OTH_G = 2, SL_TREE_A = 3, SL_Z0_R = 4, SL_Z0_G = 5 };
+enum { SL_OTH_TH = 0, SL_OTH_R = 1, SL_OTH_G = 2, SL_TREE_A = 3, SL_Z0_R = 4, SL_Z0_G = 5, SL_START_R = 6 };
 
 template <class T, int E>
 struct Chunking {
@@ -132,7 +132,11 @@ struct DrawStream {
   __device__ __forceinline__ double randexp() { return -log(uniform()); }
 };
 
-template <class T, int G, int E, bool LINW, int TK>
+// MODE 0: multinomial + generalised, linear-domain weights (the default fast path)
+// MODE 1: multinomial + generalised, log-domain weights (redo pass for chains flagged by MODE 0)
+// MODE 2: any sampler / criterion chosen at run time, log-domain weights (the run-time variants
+//         cost registers: with them in the fast kernel (32,4) loses a wave per SIMD)
+template <class T, int G, int E, int MODE, int TK>
 __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
   constexpr int CPW = 64 / G;
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
@@ -145,7 +149,11 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
   int gi = lane64 / G;
   int d0 = lane * E;
   const int NLEV = p.max_depth > 1 ? p.max_depth - 1 : 1;  // pending levels 0 .. NLEV-1
-  const int n_slots = 2 * NLEV + NUTS_DORMANT;
+  constexpr bool LINW = MODE == 0;
+  constexpr bool GENERAL = MODE == 2;
+  const bool strict = GENERAL && p.criterion == 2;
+  const int NV = strict ? 3 : 2;  // vectors per pending level: A, RF (, RL)
+  const int n_slots = NV * NLEV + NUTS_DORMANT;
   const int n_lds_slots = p.n_lds_levels;  // (re-used field) number of vector slots held in LDS
   // LDS carve-up: [nwaves][n_lds_slots][SLOT_ELEMS] T | [nwaves][NSC][NLEV][CPW] T | [nwaves][NSI][NLEV][CPW] int
   T* lds_vec = reinterpret_cast<T*>(smem) + (size_t)wib * n_lds_slots * SLOT_ELEMS;
@@ -163,9 +171,9 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
   sl.glb = p.scratch + wave_slot * (int64_t)(n_slots - n_lds_slots) * SLOT_ELEMS;
   sl.n_lds = n_lds_slots;
   sl.lane_off = (unsigned)lane64 * CH;
-  const int DORM = 2 * NLEV;  // first dormant slot
-  const bool classic = p.criterion == 0;
-  const bool slice = p.sampler == 2;
+  const int DORM = NV * NLEV;  // first dormant slot
+  const bool classic = GENERAL && p.criterion == 0;
+  const bool slice = GENERAL && p.sampler == 2;
 
   // One chunk of 64/G chains per wave, one wave per workgroup: the hardware dispatcher is the work
   // queue.  (A persistent per-wave loop over chunks was measured first: it makes every prologue and
@@ -257,6 +265,9 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
           cur_is_left = vleft;
         }
       }
+      if (strict && __builtin_amdgcn_ballot_w64(!done) != 0) {
+        if (!done) sl.store(DORM + SL_START_R, cur.r);  // r of the edge the subtree grows from
+      }
       // ---- build the subtree of 2^jw leaves (:626-675) ----
       const uint32_t nleaf = 1u << jw;
       bool alive = !done;      // still adding leaves to this subtree
@@ -307,8 +318,8 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
           if (__builtin_amdgcn_ballot_w64(m) == 0) break;
           if (m) {
             T A_p[E], RF_p[E];
-            sl.load(2 * lvl, A_p);
-            sl.load(2 * lvl + 1, RF_p);
+            sl.load(NV * lvl, A_p);
+            sl.load(NV * lvl + 1, RF_p);
             const T w_p = S_W(lvl);
             // combine(rng, sampler′, sampler′′): `first` = the half built first (:178-195)
             bool keep_first;
@@ -327,10 +338,10 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
             na_c = S_NA(lvl) + na_c;
             const T dh_p = S_DH(lvl);
             dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
-            // isterminated(tc, h, tree′) on the merged subtree (:551-570)
-            T dots[2] = {0, 0};
+            // isterminated(tc, h, tree′, tleft, tright) on the merged subtree (:551-617)
             if (classic) {
               // ends: first-built leaf (A_p, RF_p) and the current leaf; Δθ = θ_right − θ_left
+              T dots[2] = {0, 0};
 #pragma unroll
               for (int e = 0; e < E; ++e) {
                 T thl = v > 0 ? A_p[e] : cur.th[e], thr = v > 0 ? cur.th[e] : A_p[e];
@@ -342,7 +353,8 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
               }
               group_allsum<G>(dots);
               sub_term = (dots[0] >= 0) || (dots[1] >= 0);
-            } else {
+            } else if (!strict) {
+              T dots[2] = {0, 0};
 #pragma unroll
               for (int e = 0; e < E; ++e) {
                 A_c[e] = A_p[e] + A_c[e];  // ρ = ρ_left + ρ_right
@@ -351,6 +363,28 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
               }
               group_allsum<G>(dots);
               sub_term = (dots[0] <= 0) || (dots[1] <= 0);  // generalised_uturn_criterion (:619-621)
+            } else {
+              // StrictGeneralisedNoUTurn (:579-617).  F = the pending (first-built) half, S = the half
+              // just completed; in built order the two extra checks are symmetric in the direction:
+              //   (ρ_F + r_S.first ; ends F.first, S.first)   and   (r_F.last + ρ_S ; ends F.last, S.last)
+              T RL_p[E];
+              sl.load(NV * lvl + 2, RL_p);
+              T dots[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                const T rho = A_p[e] + A_c[e];
+                const T rho2 = A_p[e] + RF_c[e];
+                const T rho3 = RL_p[e] + A_c[e];
+                dots[0] += rho * (minv[e] * RF_p[e]);
+                dots[1] += rho * (minv[e] * cur.r[e]);
+                dots[2] += rho2 * (minv[e] * RF_p[e]);
+                dots[3] += rho2 * (minv[e] * RF_c[e]);
+                dots[4] += rho3 * (minv[e] * RL_p[e]);
+                dots[5] += rho3 * (minv[e] * cur.r[e]);
+                A_c[e] = rho;
+              }
+              group_allsum<G>(dots);
+              sub_term = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
             }
             copy_vec(RF_c, RF_p);
             merged = lvl + 1;
@@ -371,8 +405,9 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
           alive = false;
         } else if (alive && leaf < nleaf) {
           // park the finished level-nm subtree until its sibling is built
-          sl.store(2 * nm, A_c);
-          sl.store(2 * nm + 1, RF_c);
+          sl.store(NV * nm, A_c);
+          sl.store(NV * nm + 1, RF_c);
+          if (strict) sl.store(NV * nm + 2, cur.r);  // r of its last-built leaf
           S_W(nm) = w_c;
           S_SA(nm) = sa_c;
           S_DH(nm) = dh_c;
@@ -394,14 +429,14 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
         na_tree = na_tree + na_c;
         dh_tree = v < 0 ? maxabs(dh_c, dh_tree) : maxabs(dh_tree, dh_c);
         if constexpr (LINW) w_tree = w_tree + w_c; else w_tree = slice ? w_tree + w_c : logaddexp(w_tree, w_c);
-        // isterminated(tc, h, tree) on the whole tree; its edges are `cur` and the dormant one
-        T dots[2] = {0, 0};
+        // isterminated(tc, h, tree, tleft, tright) on the whole tree; its edges are `cur` and the dormant one
         bool turn;
         T oth_r[E];
         sl.load(DORM + SL_OTH_R, oth_r);
         if (classic) {
           T oth_th[E];
           sl.load(DORM + SL_OTH_TH, oth_th);
+          T dots[2] = {0, 0};
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             T thl = cur_is_left ? cur.th[e] : oth_th[e], thr = cur_is_left ? oth_th[e] : cur.th[e];
@@ -415,15 +450,39 @@ __global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
         } else {
           T A_tree[E];
           sl.load(DORM + SL_TREE_A, A_tree);
+          if (!strict) {
+            T dots[2] = {0, 0};
 #pragma unroll
-          for (int e = 0; e < E; ++e) {
-            A_tree[e] = A_tree[e] + A_c[e];
-            dots[0] += A_tree[e] * (minv[e] * cur.r[e]);
-            dots[1] += A_tree[e] * (minv[e] * oth_r[e]);
+            for (int e = 0; e < E; ++e) {
+              A_tree[e] = A_tree[e] + A_c[e];
+              dots[0] += A_tree[e] * (minv[e] * cur.r[e]);
+              dots[1] += A_tree[e] * (minv[e] * oth_r[e]);
+            }
+            group_allsum<G>(dots);
+            turn = (dots[0] <= 0) || (dots[1] <= 0);
+          } else {
+            // strict at the top: (ρ_tree + r_sub.first ; ends other edge, sub.first) and
+            //                    (r_start + ρ_sub ; ends start edge, current edge)
+            T rs[E];
+            sl.load(DORM + SL_START_R, rs);
+            T dots[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const T rho = A_tree[e] + A_c[e];
+              const T rho2 = A_tree[e] + RF_c[e];
+              const T rho3 = rs[e] + A_c[e];
+              dots[0] += rho * (minv[e] * cur.r[e]);
+              dots[1] += rho * (minv[e] * oth_r[e]);
+              dots[2] += rho2 * (minv[e] * oth_r[e]);
+              dots[3] += rho2 * (minv[e] * RF_c[e]);
+              dots[4] += rho3 * (minv[e] * rs[e]);
+              dots[5] += rho3 * (minv[e] * cur.r[e]);
+              A_tree[e] = rho;
+            }
+            group_allsum<G>(dots);
+            turn = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
           }
           sl.store(DORM + SL_TREE_A, A_tree);
-          group_allsum<G>(dots);
-          turn = (dots[0] <= 0) || (dots[1] <= 0);
         }
         if (sub_term || turn) done = true;
       }

@@ -208,7 +208,7 @@ def test_static_hmc_transitions(hip, oracle, rng, dtype, min_match, TS, metric):
 
 @pytest.mark.parametrize("dtype,min_match", [(np.float64, 0.999), (np.float32, 0.9)])
 @pytest.mark.parametrize("TS", [A.MultinomialTS, A.SliceTS])
-@pytest.mark.parametrize("TC", [A.GeneralisedNoUTurn, A.ClassicNoUTurn])
+@pytest.mark.parametrize("TC", [A.GeneralisedNoUTurn, A.ClassicNoUTurn, A.StrictGeneralisedNoUTurn])
 def test_nuts_transitions(hip, oracle, rng, dtype, min_match, TS, TC):
     """dynamic transition + build_tree (src/trajectory.jl:626-742): iterative kernel == recursion"""
     D, N = 10, 1024
