@@ -145,10 +145,10 @@ int dev_alloc(Ctx<T>* c, U** ptr, size_t n) {
 inline bool pick_geometry(int64_t D, int& G, int& E) {
   if (D <= 4) { G = 4; E = 1; }
   else if (D <= 8) { G = 4; E = 2; }
-  else if (D <= 16) { G = 4; E = 4; }
-  else if (D <= 32) { G = 8; E = 4; }
-  else if (D <= 64) { G = 16; E = 4; }
-  else if (D <= 128) { G = 32; E = 4; }   // measured on cfg2 (f64): (32,4) 8.1e8, (64,2) 7.0e8, (16,8) 5.9e8 leapfrog/s
+  else if (D <= 16) { G = 8; E = 2; }
+  else if (D <= 32) { G = 16; E = 2; }
+  else if (D <= 64) { G = 32; E = 2; }
+  else if (D <= 128) { G = 64; E = 2; }  // measured on cfg2 (f64, batched): (64,2) 1.41e9 at 3 waves/SIMD, (32,4) 1.33e9, (16,8) 0.90e9
   else if (D <= 256) { G = 64; E = 4; }
   else if (D <= 512) { G = 64; E = 8; }
   else return false;

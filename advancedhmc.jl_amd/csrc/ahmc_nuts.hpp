@@ -137,7 +137,7 @@ struct DrawStream {
 // MODE 2: any sampler / criterion chosen at run time, log-domain weights (the run-time variants
 //         cost registers: with them in the fast kernel (32,4) loses a wave per SIMD)
 template <class T, int G, int E, int MODE, int TK>
-__global__ __launch_bounds__(256) void k_nuts(KP<T> p) {
+__global__ __launch_bounds__(256, (E <= 2 && MODE != 2 ? 3 : (MODE == 2 ? 1 : 2))) void k_nuts(KP<T> p) {
   constexpr int CPW = 64 / G;
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
   constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)
