@@ -151,6 +151,12 @@ inline bool pick_geometry(int64_t D, int& G, int& E) {
   else if (D <= 128) { G = 64; E = 2; }  // measured on cfg2 (f64, batched): (64,2) 1.41e9 at 3 waves/SIMD, (32,4) 1.33e9, (16,8) 0.90e9
   else if (D <= 256) { G = 64; E = 4; }
   else if (D <= 512) { G = 64; E = 8; }
+  // multi-wave chains: one chain per workgroup of G/64 waves, reductions cross waves through LDS
+  // measured (hier Gaussian, f64, leapfrog/s): D=512 (64,8) 3.10e8 / (128,4) 3.07e8 / (256,2) 2.2e8;
+  // D=1024 (128,8) 1.33e8 / (256,4) 1.36e8; D=2048 (256,8) 5.8e7 / (512,4) 5.2e7
+  else if (D <= 1024) { G = 256; E = 4; }
+  else if (D <= 2048) { G = 256; E = 8; }
+  else if (D <= 4096) { G = 512; E = 8; }
   else return false;
   const char* ov = getenv("AHMC_GEOMETRY");  // "G,E" override for experiments
   if (ov) {
@@ -193,7 +199,8 @@ KP<T> make_kp(Ctx<T>* c) {
 }
 
 template <class T>
-unsigned group_grid(Ctx<T>* c) {  // blocks of 256 threads covering N groups of G lanes
+unsigned group_grid(Ctx<T>* c) {  // blocks of 256 threads covering N groups of G lanes (G > 64: one group per block)
+  if (c->G > 64) return (unsigned)c->N;
   int64_t threads = c->N * c->G;
   return (unsigned)((threads + 255) / 256);
 }
@@ -219,7 +226,7 @@ template <class T>
 int launch_kinetic(Ctx<T>* c) {
   KP<T> p = make_kp(c);
   with_geometry(c->G, c->E, [&](auto g, auto e) {
-    hipLaunchKernelGGL((k_kinetic<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(256), 0,
+    hipLaunchKernelGGL((k_kinetic<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(decltype(g)::value > 64 ? decltype(g)::value : 256), 0,
                        c->stream, p);
   });
   HIPCHK(hipGetLastError());
@@ -261,21 +268,23 @@ int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
 //   the rest go to a per-wave region of global scratch.
 template <class T, int MODE>
 int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, size_t& smem, int& n_lds_slots) {
-  const int CPW = 64 / c->G;
+  const int CPW = c->G >= 64 ? 1 : 64 / c->G;
+  const int NW = c->G > 64 ? c->G / 64 : 1;  // waves per chain (multi-wave groups: one chain per workgroup)
   const int NLEV = max_depth > 1 ? max_depth - 1 : 1;
   const int n_slots = (criterion == AHMC_TC_STRICT ? 3 : 2) * NLEV + NUTS_DORMANT;
   const size_t slot_bytes = (size_t)64 * c->E * sizeof(T);
   const size_t scalar_bytes = (size_t)NUTS_NSC * NLEV * CPW * sizeof(T) + (size_t)NUTS_NSI * NLEV * CPW * sizeof(int);
   const int64_t n_chunks = (c->N + CPW - 1) / CPW;
   int occ = 0;  // single-wave workgroups per CU
-  with_target(c->target_kind, [&](auto tk) { occ = Inst<T, decltype(tk)::value>::nuts_occupancy(c->G, c->E, MODE, scalar_bytes); });
+  with_target(c->target_kind, [&](auto tk) { occ = Inst<T, decltype(tk)::value>::nuts_occupancy(c->G, c->E, MODE, scalar_bytes * NW); });
+  occ *= NW;
   if (occ < 1) occ = 4;
   if (occ > 32) occ = 32;
   const char* ov = getenv("AHMC_NUTS_WAVES_PER_CU");
   if (ov && atoi(ov) > 0) occ = atoi(ov);
   const size_t lds_per_cu = 160 * 1024;
   size_t per_wave = lds_per_cu / (size_t)occ;
-  if (per_wave > 64 * 1024) per_wave = 64 * 1024;
+  if (per_wave > 64 * 1024 / (size_t)NW) per_wave = 64 * 1024 / (size_t)NW;  // <= 64 KB per workgroup
   per_wave = per_wave > scalar_bytes + 128 ? per_wave - scalar_bytes - 128 : 0;
   n_lds_slots = (int)std::min<size_t>((size_t)n_slots, per_wave / slot_bytes);
   const char* ovs = getenv("AHMC_NUTS_LDS_SLOTS");
@@ -287,8 +296,8 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   // waves per workgroup (AHMC_NUTS_WPB): measured on cfg2, leapfrog/s for 1 / 2 / 4 waves per workgroup =
   // 8.4e8 / 7.0e8 / 5.6e8 — a workgroup holds its LDS and registers until its slowest wave ends
   static const int wpb_env = getenv("AHMC_NUTS_WPB") ? atoi(getenv("AHMC_NUTS_WPB")) : 1;
-  wpb = std::max(1, std::min(4, wpb_env));
-  blocks = (int)((n_chunks + wpb - 1) / wpb);
+  wpb = NW > 1 ? NW : std::max(1, std::min(4, wpb_env));
+  blocks = NW > 1 ? (int)n_chunks : (int)((n_chunks + wpb - 1) / wpb);
   smem *= (size_t)wpb;
   with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, MODE, smem); });
   size_t need = (size_t)blocks * wpb * (size_t)(n_slots - n_lds_slots) * slot_bytes + 256;
@@ -336,7 +345,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.sampler = sampler;
   p.refresh_alpha = (T)refresh_alpha;
   p.accum = accum ? 1 : 0;
-  const int CPW = 64 / c->G;
+  const int CPW = c->G >= 64 ? 1 : 64 / c->G;
   p.n_chunks = (unsigned int)((c->N + CPW - 1) / CPW);
   p.redo = c->redo;
   static const bool no_linw = getenv("AHMC_NUTS_LOGW") != nullptr;
@@ -566,7 +575,7 @@ static int32_t create_impl(int32_t device, int32_t dtype, int64_t D, int64_t N, 
     return code;
   };
   if (!pick_geometry(D, c->G, c->E))
-    return bail("ahmc_create: D > 512 has no HIP kernel geometry yet (workgroup-per-chain path is future work)", AHMC_ERR_UNSUPPORTED);
+    return bail("ahmc_create: D > 4096 has no HIP kernel geometry", AHMC_ERR_UNSUPPORTED);
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e), AHMC_ERR_RUNTIME);
   hipDeviceProp_t prop;

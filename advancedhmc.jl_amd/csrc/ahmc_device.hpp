@@ -166,7 +166,7 @@ __device__ __forceinline__ double xor32_sum(double v) {
 
 // all-reduce (sum) of K independent values across the G lanes of each group
 template <int G, class T, int K>
-__device__ __forceinline__ void group_allsum(T (&v)[K]) {
+__device__ __forceinline__ void wave_allsum(T (&v)[K]) {
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group size");
   if constexpr (G >= 2) {
 #pragma unroll
@@ -193,6 +193,41 @@ __device__ __forceinline__ void group_allsum(T (&v)[K]) {
     for (int k = 0; k < K; ++k) v[k] = xor32_sum(v[k]);
   }
 }
+// Exchange buffer of the multi-wave groups (G = 128/256/512: one chain per workgroup of G/64 waves,
+// D up to 4096).  All waves of such a group execute identical control flow (every decision is taken
+// on values that are bit-identical in all lanes), so the barriers below are always reached together.
+__device__ __forceinline__ double* xwave_buf() {
+  __shared__ __attribute__((aligned(16))) double buf[8 * 8];
+  return buf;
+}
+
+// all-reduce (sum) of K values across the G lanes of each group; G > 64 = G/64 whole waves
+template <int G, class T, int K>
+__device__ __forceinline__ void group_allsum(T (&v)[K]) {
+  if constexpr (G <= 64) {
+    wave_allsum<G>(v);
+  } else {
+    static_assert(G == 128 || G == 256 || G == 512, "bad multi-wave group size");
+    static_assert(K <= 8, "at most 8 values per reduction");
+    constexpr int NW = G / 64;
+    wave_allsum<64>(v);
+    double* b = xwave_buf();
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) b[w * 8 + k] = (double)v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      T s = 0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) s += (T)b[ww * 8 + k];  // fixed order: same bits in every wave
+      v[k] = s;
+    }
+    __syncthreads();
+  }
+}
 template <int G, class T>
 __device__ __forceinline__ T group_sum1(T x) {
   T v[1] = {x};
@@ -203,14 +238,25 @@ __device__ __forceinline__ T group_sum1(T x) {
 // broadcast the value held by lane `src` (0..G-1) of the group to the whole group
 template <int G>
 __device__ __forceinline__ int group_bcast_i32(int v, int src) {
-  int base = (int)(__lane_id() & ~(unsigned)(G - 1));
+  int base = (int)(__lane_id() & ~(unsigned)((G > 64 ? 64 : G) - 1));
   return __builtin_amdgcn_ds_bpermute((base + src) << 2, v);
 }
+template <int G, class T>
+__device__ __forceinline__ T xwave_bcast(T v, int src) {
+  double* b = xwave_buf();
+  if ((int)threadIdx.x == src) b[0] = (double)v;
+  __syncthreads();
+  T r = (T)b[0];
+  __syncthreads();
+  return r;
+}
 template <int G> __device__ __forceinline__ float group_bcast(float v, int src) {
-  return __int_as_float(group_bcast_i32<G>(__float_as_int(v), src));
+  if constexpr (G > 64) return xwave_bcast<G>(v, src);
+  else return __int_as_float(group_bcast_i32<G>(__float_as_int(v), src));
 }
 template <int G> __device__ __forceinline__ double group_bcast(double v, int src) {
-  return __hiloint2double(group_bcast_i32<G>(__double2hiint(v), src), group_bcast_i32<G>(__double2loint(v), src));
+  if constexpr (G > 64) return xwave_bcast<G>(v, src);
+  else return __hiloint2double(group_bcast_i32<G>(__double2hiint(v), src), group_bcast_i32<G>(__double2loint(v), src));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ namespace ahmc {
 
 #define GEO_LAUNCH(KERNEL, ...)                                                                       \
   with_geometry(G, E, [&](auto g, auto e) {                                                            \
-    hipLaunchKernelGGL((KERNEL<T, decltype(g)::value, decltype(e)::value, TK>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+    hipLaunchKernelGGL((KERNEL<T, decltype(g)::value, decltype(e)::value, TK>), dim3(grid), dim3(decltype(g)::value > 64 ? decltype(g)::value : 256), 0, s, __VA_ARGS__); \
   })
 
 template <class T, int TK>
@@ -35,9 +35,9 @@ int Inst<T, TK>::nuts_occupancy(int G, int E, int mode, size_t smem) {
   hipError_t err = hipErrorInvalidValue;
   with_geometry(G, E, [&](auto g, auto e) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    if (mode == 0) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 0, TK>, 64, smem);
-    else if (mode == 1) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 1, TK>, 64, smem);
-    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 2, TK>, 64, smem);
+    if (mode == 0) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 0, TK>, (GG > 64 ? GG : 64), smem);
+    else if (mode == 1) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 1, TK>, (GG > 64 ? GG : 64), smem);
+    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 2, TK>, (GG > 64 ? GG : 64), smem);
   });
   return err == hipSuccess ? occ : 0;
 }

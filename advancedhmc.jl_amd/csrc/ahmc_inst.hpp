@@ -12,7 +12,8 @@ namespace ahmc {
 
 // Thread geometries (G lanes per chain, E elements per lane) with compiled kernels.
 #define AHMC_GEOMETRIES(X) \
-  X(4, 1) X(8, 1) X(16, 1) X(32, 1) X(64, 1) X(4, 2) X(8, 2) X(16, 2) X(32, 2) X(64, 2) X(32, 4) X(64, 4) X(64, 8)
+  X(4, 1) X(8, 1) X(16, 1) X(32, 1) X(64, 1) X(4, 2) X(8, 2) X(16, 2) X(32, 2) X(64, 2) X(32, 4) X(64, 4) X(64, 8) \
+  X(128, 4) X(256, 4) X(512, 4) X(128, 8) X(256, 8) X(512, 8)
 
 // call f(std::integral_constant<int,G>{}, std::integral_constant<int,E>{}) for a run-time geometry
 template <class F>

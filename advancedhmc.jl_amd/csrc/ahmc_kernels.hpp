@@ -193,7 +193,7 @@ __device__ __forceinline__ void accumulate(const KP<T>& p, int64_t c, int d0, in
 
 #define AHMC_GEOMETRY()                                   \
   const int lane64 = threadIdx.x & 63;                    \
-  const int lane = lane64 & (G - 1);                      \
+  const int lane = (int)(threadIdx.x & (G - 1));          \
   const int d0 = lane * E;                                \
   const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; \
   const bool active = c < p.N;                            \
@@ -203,7 +203,7 @@ __device__ __forceinline__ void accumulate(const KP<T>& p, int64_t c, int d0, in
 // phasepoint(h, θ, r) for arrays already in the context (ahmc_set_position)
 // ------------------------------------------------------------------------------------------------
 template <class T, int G, int E, int TK>
-__global__ __launch_bounds__(256) void k_fill_caches(KP<T> p) {
+__global__ __launch_bounds__(G > 256 ? G : 256) void k_fill_caches(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
   Point<T, E> z;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_fill_caches(KP<T> p) {
 
 // kinetic cache only (ahmc_set_phasepoint with caller-supplied ℓπ, -∇ℓπ; ahmc_lf_post)
 template <class T, int G, int E>
-__global__ __launch_bounds__(256) void k_kinetic(KP<T> p) {
+__global__ __launch_bounds__(G > 256 ? G : 256) void k_kinetic(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
   T minv[E], r[E];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_kinetic(KP<T> p) {
 
 // refresh(rng, refreshment, h, z)
 template <class T, int G, int E, int TK>
-__global__ __launch_bounds__(256) void k_refresh(KP<T> p) {
+__global__ __launch_bounds__(G > 256 ? G : 256) void k_refresh(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
   Point<T, E> z;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_refresh(KP<T> p) {
 // first non-finite point (the reference's scalar-chain behaviour; Q1 in DESIGN.md).
 // ------------------------------------------------------------------------------------------------
 template <class T, int G, int E, int TK>
-__global__ __launch_bounds__(256) void k_leapfrog(KP<T> p) {
+__global__ __launch_bounds__(G > 256 ? G : 256) void k_leapfrog(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
   Point<T, E> z;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_lf_post(KP<T> p, int fwd, int64_t i, in
 // pass 2 re-integrates to the selected point (bitwise the same arithmetic) — no (L+1)·D store.
 // ------------------------------------------------------------------------------------------------
 template <class T, int G, int E, int TK>
-__global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
+__global__ __launch_bounds__(G > 256 ? G : 256) void k_hmc(KP<T> p) {
   AHMC_GEOMETRY();
   if (!active) return;
   Point<T, E> z0, z;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_hmc(KP<T> p) {
 // find_good_stepsize for every chain (src/trajectory.jl:753-837), incl. the Q3 quirk
 // ------------------------------------------------------------------------------------------------
 template <class T, int G, int E, int TK>
-__global__ __launch_bounds__(256) void k_find_eps(KP<T> p, T* eps_out) {
+__global__ __launch_bounds__(G > 256 ? G : 256) void k_find_eps(KP<T> p, T* eps_out) {
   AHMC_GEOMETRY();
   if (!active) return;
   Point<T, E> z0;

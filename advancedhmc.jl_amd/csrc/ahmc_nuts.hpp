@@ -137,16 +137,16 @@ struct DrawStream {
 // MODE 2: any sampler / criterion chosen at run time, log-domain weights (the run-time variants
 //         cost registers: with them in the fast kernel (32,4) loses a wave per SIMD)
 template <class T, int G, int E, int MODE, int TK>
-__global__ __launch_bounds__(256, (E <= 2 && MODE != 2 ? 3 : (MODE == 2 ? 1 : 2))) void k_nuts(KP<T> p) {
-  constexpr int CPW = 64 / G;
+__global__ __launch_bounds__((G > 256 ? G : 256), (E <= 2 && MODE != 2 ? 3 : (MODE == 2 || E >= 8 ? 1 : 2))) void k_nuts(KP<T> p) {
+  constexpr int CPW = G >= 64 ? 1 : 64 / G;  // chains per wave (G > 64: one chain per workgroup of G/64 waves)
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
   constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nwaves = blockDim.x >> 6;
   const int wib = threadIdx.x >> 6;
   const int lane64 = threadIdx.x & 63;
-  int lane = lane64 & (G - 1);
-  int gi = lane64 / G;
+  int lane = (int)(threadIdx.x & (G - 1));
+  int gi = G >= 64 ? 0 : lane64 / G;
   int d0 = lane * E;
   const int NLEV = p.max_depth > 1 ? p.max_depth - 1 : 1;  // pending levels 0 .. NLEV-1
   constexpr bool LINW = MODE == 0;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, (E <= 2 && MODE != 2 ? 3 : (MODE == 2 ? 1 : 2)
   // 700-1000 leaves, a strictly serial ~2.3 ms); with one transition per launch the whole GPU waits
   // for that chain each time.  Chains are independent, so batching transitions removes the
   // per-transition barrier and the tail is paid once per launch.
-  const unsigned int chunk = blockIdx.x * nwaves + wib;
+  const unsigned int chunk = G > 64 ? blockIdx.x : blockIdx.x * nwaves + wib;
   if (chunk >= p.n_chunks) return;
   const int64_t c = (int64_t)chunk * CPW + gi;
   int64_t cc = c < p.N ? c : 0;  // out-of-range groups shadow chain 0 and never write

@@ -60,7 +60,8 @@ def assert_points_close(zg, zo, dtype, what=""):
     np.testing.assert_allclose(zg.lk.value, zo.lk.value, rtol=rt, atol=at * 10, err_msg=what + " lk")
 
 
-GEOM_D = [3, 5, 10, 24, 32, 50, 100, 128, 200, 300]  # covers every default thread geometry (G,E)
+GEOM_D = [3, 5, 10, 24, 32, 50, 100, 128, 200, 300, 600, 1500, 2048, 4096]  # every default thread geometry (G,E),
+# incl. the multi-wave chains (D > 512: one chain per workgroup of 2/4/8 waves; BASELINE configs[4] is D = 2048)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -250,6 +251,42 @@ def test_nuts_geometries_and_targets(hip, oracle, rng, D, target):
         n_div += int(sg["numerical_error"].sum())
     if target == "funnel":
         assert n_div > 0, "the funnel at eps=0.5 must produce divergent transitions (Δ_max test, :500-507)"
+
+
+@pytest.mark.parametrize("D,target", [(600, "hier"), (2048, "iso"), (2048, "funnel"), (3000, "diag")])
+def test_multiwave_chains(hip, oracle, rng, D, target):
+    """D > 512: a chain spans 2-8 wavefronts of one workgroup (cross-wave reductions through LDS).
+    Every transition kind on those geometries — BASELINE.json configs[4] is D = 2048."""
+    N = 24
+    dtype = np.float64
+    h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), make_target(target, D, rng))
+    eps = 0.3 * D ** -0.25
+    lf = A.Leapfrog(np.full(N, eps))
+    g, o = pair(hip, oracle, h, N, dtype, seed=3, lf=lf)
+    th = 0.5 * rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+        e.refresh()
+    assert_points_close(g.phasepoint(), o.phasepoint(), dtype, "refresh")
+    kernels = [
+        A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(6))),
+        A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.FixedNSteps(6))),
+        A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=6))),
+        A.HMCKernel(A.Trajectory(A.SliceTS, lf, A.StrictGeneralisedNoUTurn(max_depth=5))),
+        A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.ClassicNoUTurn(max_depth=5))),
+    ]
+    for k in kernels:
+        for it in range(2):
+            for e in (g, o):
+                e.transition(k)
+            sg, so = g.stats(), o.stats()
+            same = compare_transition_stats(sg, so, dtype, 0.95 if it == 0 else 0.5)
+            zg, zo = g.phasepoint(), o.phasepoint()
+            np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
+        for e in (g, o):  # re-synchronise the two engines for the next kernel
+            e.set_position(o.phasepoint().theta)
+    eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
+    assert np.mean(eg == eo) >= 0.95
 
 
 def test_max_depth_and_single_leaf(hip, oracle, rng):
