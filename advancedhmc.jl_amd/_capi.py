@@ -109,6 +109,7 @@ SIGNATURES = {
     "ahmc_sample": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i32, _vp]),
     "ahmc_get_accum": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
     "ahmc_reset_accum": (_i32, [_vp]),
+    "ahmc_get_info": (_i32, [_vp, _i32, C.POINTER(_i64)]),
 }
 
 

@@ -630,6 +630,14 @@ class Engine:
     def reset_accum(self):
         self._call("ahmc_reset_accum")
 
+    INFO = {"group_lanes": 0, "elems_per_lane": 1, "nuts_launches": 2, "nuts_batch": 3, "iteration": 4}
+
+    def info(self, key):
+        """engine introspection (ahmc_get_info): thread geometry, NUTS launch count / batch, iteration"""
+        v = C.c_int64()
+        self._call("ahmc_get_info", self.INFO[key], C.byref(v))
+        return v.value
+
 
 # ------------------------------------------------------------------------------------------------
 # free functions with the reference's names

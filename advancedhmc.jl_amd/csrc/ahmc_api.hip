@@ -115,6 +115,7 @@ struct Ctx : CtxBase {
   int64_t stan_i = 0;
   StanWindows windows;
   int n_cu = 256;
+  int64_t nuts_launches = 0;  // launches of the dominant NUTS kernel (MODE 0), for bench.py's per-launch roofline
 
   ~Ctx() override {
     (void)hipSetDevice(device);
@@ -373,6 +374,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
       p.redo_only = 0;
       rc = launch_nuts<T, 0>(c, p, max_depth);
       if (rc) return rc;
+      c->nuts_launches += 1;
       p.redo_only = 1;
       rc = launch_nuts<T, 1>(c, p, max_depth);
     } else {
@@ -386,6 +388,17 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   if (rc) return rc;
   c->iteration += (uint64_t)n_trans;
   return AHMC_OK;
+}
+
+template <class T>
+int64_t nuts_batch(Ctx<T>* c) {
+  // transitions per launch in the sampling phase: more = less tree-size tail per launch (cfg2:
+  // 8/16/32/64 -> 1.35/1.39/1.42/1.43e9 leapfrog/s); the pre-generated momentum normals take
+  // batch * D * N elements, kept under 4 GiB
+  static const int batch_env = getenv("AHMC_NUTS_BATCH") ? atoi(getenv("AHMC_NUTS_BATCH")) : 0;
+  if (batch_env > 0) return batch_env;
+  const int64_t cap = (int64_t)(4ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
+  return std::max<int64_t>(1, std::min<int64_t>(32, cap));
 }
 
 template <class T>
@@ -945,8 +958,7 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
       so_on_device = hipPointerGetAttributes(&at, so) == hipSuccess && at.type == hipMemoryTypeDevice;
       (void)hipGetLastError();
     }
-    static const int batch_env = getenv("AHMC_NUTS_BATCH") ? atoi(getenv("AHMC_NUTS_BATCH")) : 16;
-    const int64_t batch = std::max(1, batch_env);
+    const int64_t batch = nuts_batch(c);
     for (int64_t i = 1; i <= n_samples;) {  // src/sampler.jl:182-228
       const bool keep = !drop_warmup || i > n_adapts;
       if (keep && !reset_done) {
@@ -958,7 +970,10 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
       if (cfg->nuts && !adapting && keep && (!so || so_on_device)) {
         // chains are independent and nothing is adapted any more: run a batch of transitions per
         // launch (no per-transition barrier; see the note on tree-size tails in ahmc_nuts.hpp)
-        const int64_t k = std::min<int64_t>(batch, n_samples - i + 1);
+        // (split the remaining transitions evenly: 50 = 13+13+12+12, not 16+16+16+2 — a short
+        // last batch would pay the whole tree-size tail for two transitions)
+        const int64_t left = n_samples - i + 1, nb_left = (left + batch - 1) / batch;
+        const int64_t k = (left + nb_left - 1) / nb_left;
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
         int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, true,
                                  (int)k, so ? so + (size_t)(j - 1) * c->D * c->N : nullptr);
@@ -980,6 +995,21 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
         }
       }
       ++i;
+    }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
+  FOR_CTX(ctx, {
+    if (!out) return fail(c, AHMC_ERR_ARGUMENT, "get_info: out is NULL");
+    switch (what) {
+      case AHMC_INFO_GROUP_LANES: *out = c->G; break;
+      case AHMC_INFO_ELEMS_PER_LANE: *out = c->E; break;
+      case AHMC_INFO_NUTS_LAUNCHES: *out = c->nuts_launches; break;
+      case AHMC_INFO_NUTS_BATCH: *out = nuts_batch(c); break;
+      case AHMC_INFO_ITERATION: *out = (int64_t)c->iteration; break;
+      default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
     }
     return AHMC_OK;
   });

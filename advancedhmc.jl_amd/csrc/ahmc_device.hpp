@@ -121,7 +121,9 @@ template <class T> __device__ __forceinline__ T maxabs(T a, T b) { return fabs(a
 // no LDS traffic, no address VGPRs.  Every lane of the group ends with the same bits.
 // ------------------------------------------------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+  // every control used here reads a valid lane for every lane, so `old` is never taken: mov_dpp
+  // (old = undef, bound_ctrl) saves the two v_mov that initialise `old` per exchanged f64
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(dpp_i32<CTRL>(__float_as_int(v)));
@@ -164,10 +166,36 @@ __device__ __forceinline__ double xor32_sum(double v) {
   return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 
+// all-reduce of a PAIR of values across groups of 16/32/64 lanes in ~half the instructions of two
+// butterflies.  The first exchange is transposed — even lanes collect `a`, odd lanes collect `b`
+// — so every later stage moves one value instead of two; rotations inside the 16-lane row keep
+// the lane parity, the row pairs/halves are joined as before, and lanes 0 / 1 of the row are
+// broadcast back (row_newbcast).  Every lane ends with the bits of those two lanes.
+//   f64: 7 + 3 + 3 + 3 (+5 +5) + 4 = 30 VALU for G = 64, against 2 x 22.
+template <int G, class T>
+__device__ __forceinline__ void wave_allsum2(T& a, T& b) {
+  static_assert(G == 16 || G == 32 || G == 64, "pair reduction needs whole 16-lane rows");
+  const bool odd = (threadIdx.x & 1u) != 0;
+  const T keep = odd ? b : a, send = odd ? a : b;
+  T x = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);             // quad_perm [2,3,0,1]
+  x += dpp_mov<0x124>(x);            // row_ror:4
+  x += dpp_mov<0x128>(x);            // row_ror:8
+  if constexpr (G >= 32) x = xor16_sum(x);
+  if constexpr (G >= 64) x = xor32_sum(x);
+  a = dpp_mov<0x150>(x);  // row_newbcast:0
+  b = dpp_mov<0x151>(x);  // row_newbcast:1
+}
+
 // all-reduce (sum) of K independent values across the G lanes of each group
 template <int G, class T, int K>
 __device__ __forceinline__ void wave_allsum(T (&v)[K]) {
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group size");
+  if constexpr (G >= 16 && K % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k += 2) wave_allsum2<G>(v[k], v[k + 1]);
+    return;
+  }
   if constexpr (G >= 2) {
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] += dpp_mov<0xB1>(v[k]);  // quad_perm [1,0,3,2]

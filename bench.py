@@ -5,10 +5,19 @@ Workload (BASELINE.json configs[1]): D=128 isotropic Gaussi
 DiagEuclideanMetric (per-chain M⁻¹), NUTS(δ=0.8) = MultinomialTS + GeneralisedNoUTurn(max_depth
 10, Δ_max 1000) with StanHMCAdaptor, 65 536 chains per GPU, Float64, synthetic θ0 ~ U(0,1).
 
-A "step" is ONE NUTS transition of all chains (one launch of k_nuts).  Setup (untimed):
-find_good_stepsize + `--adapt` Stan-adaptation transitions.  Then W warm-up steps and exactly K
-timed steps, bracketed by barrier + synchronize; MAX over ranks; rank 0 prints one JSON line.
-`value` = Σ n_steps over all chains and ranks in the timed region ÷ that time.
+A "step" is ONE NUTS transition of all chains.  Setup (untimed): find_good_stepsize + `--adapt`
+Stan-adaptation transitions.  Then W warm-up steps and exactly K timed steps, bracketed by barrier
++ synchronize; MAX over ranks; rank 0 prints one JSON line.  `value` = Σ n_steps over all chains
+and ranks in the timed region ÷ that time.
+
+In the sampling phase the engine runs a batch of transitions per launch of the dominant kernel
+k_nuts (chains are independent, so there is no per-transition barrier; `nuts_batch` transitions,
+the K steps split evenly over ⌈K / nuts_batch⌉ launches).  The roofline object is per LAUNCH:
+algorithmic bytes of the leapfrogs one launch executes ÷ the launch's duration; the HIP events
+bracket the K steps on the engine's stream, i.e. the k_nuts launches plus two small helpers per
+launch (k_normals: the momentum normals; the log-domain redo pass, which almost always exits
+immediately) — `avg_launch_ms` therefore sits a few % above rocprofv3's k_nuts average
+(profiles/r1_kernel_stats.csv).
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); chains shard with no
 data-path collective (weak scaling, 65 536 chains per GPU, Philox chain offset = rank·N); the
@@ -41,7 +50,9 @@ def measured_traffic(D, N):
     try:
         with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
             t = json.load(f)
-        return t["hbm_bytes_per_launch"] if (D, N) == (128, 65536) else None
+        if (D, N) != (128, 65536):
+            return None
+        return t["hbm_bytes_per_launch"], t.get("transitions_per_launch")
     except Exception:
         return None
 
@@ -97,8 +108,8 @@ def cpu_baseline(A, D, n_adapt, steps, seed, chains, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--adapt", type=int, default=200, help="untimed Stan adaptation transitions")
@@ -144,6 +155,7 @@ def main():
     barrier()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    launches0 = eng.info("nuts_launches")
     t0 = time.perf_counter()
     ev0.record(stream)
     eng.run(kernel, args.steps, 0)  # K transitions, accumulators reset at the first one
@@ -171,8 +183,13 @@ def main():
 
     if rank == 0:
         B_lf = algorithmic_bytes_per_leapfrog(D, True, 8)
-        per_launch_s = (kernel_ms / 1e3) / args.steps
-        achieved = (n_leap / args.steps) * B_lf / per_launch_s / 1e9  # this rank's dominant kernel
+        n_launches = max(1, eng.info("nuts_launches") - launches0)
+        per_launch_s = (kernel_ms / 1e3) / n_launches
+        achieved = (n_leap / n_launches) * B_lf / per_launch_s / 1e9  # this rank's dominant kernel
+        traffic = measured_traffic(D, N)
+        if traffic is not None:  # measured per launch of `transitions_per_launch`; rescale to this run's launches
+            hbm, tpl = traffic
+            traffic = hbm * (args.steps / n_launches) / tpl if tpl else hbm
         out = {
             "metric": "leapfrog-steps/sec (whole node) at n_chains x D",
             "value": total_leap / dt_max,
@@ -195,9 +212,12 @@ def main():
                 "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_nuts<double,32,4,linw>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(D, N),
+                "bound": "hbm", "kernel": "k_nuts<double,%d,%d,mode 0,iso>" % (eng.info("group_lanes"), eng.info("elems_per_lane")),
+                "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_leapfrog": B_lf, "avg_launch_ms": per_launch_s * 1e3,
+                "launches": n_launches, "transitions_per_launch": args.steps / n_launches,
+                "leapfrogs_per_launch": n_leap / n_launches,
             },
         }
         if not args.no_cpu_baseline:

@@ -250,6 +250,17 @@ int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transit
                        int64_t* n_divergent, void* sum_theta, void* sumsq_theta);
 int32_t ahmc_reset_accum(ahmc_ctx* ctx);
 
+/* Engine introspection (no reference counterpart; used by bench.py to price the roofline per launch
+ * and by the tests to assert which thread geometry ran).                                        */
+typedef enum {
+  AHMC_INFO_GROUP_LANES = 0,      /* G: lanes per chain (G > 64: G/64 wavefronts per chain)        */
+  AHMC_INFO_ELEMS_PER_LANE = 1,   /* E: contiguous dimensions per lane                           */
+  AHMC_INFO_NUTS_LAUNCHES = 2,    /* launches of the dominant NUTS kernel since ahmc_create      */
+  AHMC_INFO_NUTS_BATCH = 3,       /* transitions per NUTS launch in the sampling phase           */
+  AHMC_INFO_ITERATION = 4         /* transitions done (the Philox iteration counter)             */
+} ahmc_info;
+int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1619,6 +1619,21 @@ int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
   FOR_CTX(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); return AHMC_OK; });
 }
 
+int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
+  FOR_CTX(ctx, {
+    if (!out) return fail(c, AHMC_ERR_ARGUMENT, "get_info: out is NULL");
+    switch (what) {  // the scalar oracle has no thread geometry: one "lane" holding the whole chain
+      case AHMC_INFO_GROUP_LANES: *out = 1; break;
+      case AHMC_INFO_ELEMS_PER_LANE: *out = c->D; break;
+      case AHMC_INFO_NUTS_LAUNCHES: *out = 0; break;
+      case AHMC_INFO_NUTS_BATCH: *out = 1; break;
+      case AHMC_INFO_ITERATION: *out = (int64_t)c->iteration; break;
+      default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
+    }
+    return AHMC_OK;
+  });
+}
+
 // ---- oracle-only probes used by the golden tests (pieces of src/trajectory.jl) ---------------
 double ahmco_logaddexp(double a, double b) { return logaddexp(a, b); }
 void ahmco_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
