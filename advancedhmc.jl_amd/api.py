@@ -630,7 +630,7 @@ class Engine:
     def reset_accum(self):
         self._call("ahmc_reset_accum")
 
-    INFO = {"group_lanes": 0, "elems_per_lane": 1, "nuts_launches": 2, "nuts_batch": 3, "iteration": 4}
+    INFO = {"group_lanes": 0, "elems_per_lane": 1, "nuts_launches": 2, "nuts_batch": 3, "iteration": 4, "nuts_kernel_ns": 5}
 
     def info(self, key):
         """engine introspection (ahmc_get_info): thread geometry, NUTS launch count / batch, iteration"""

@@ -116,6 +116,10 @@ struct Ctx : CtxBase {
   StanWindows windows;
   int n_cu = 256;
   int64_t nuts_launches = 0;  // launches of the dominant NUTS kernel (MODE 0), for bench.py's per-launch roofline
+  // HIP events around each of those launches (on this context's stream): bench.py prices the
+  // roofline on the kernel's own duration, the quantity rocprofv3's kernel trace reports
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_pending;
+  double nuts_kernel_ns = 0;
 
   ~Ctx() override {
     (void)hipSetDevice(device);
@@ -124,6 +128,8 @@ struct Ctx : CtxBase {
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
+    for (auto* v : {&ev_pool, &ev_pending})
+      for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -328,6 +334,21 @@ int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
   return AHMC_OK;
 }
 
+// fold the finished launch timings into nuts_kernel_ns (synchronises the stream)
+template <class T>
+int flush_nuts_events(Ctx<T>* c) {
+  if (c->ev_pending.empty()) return AHMC_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& e : c->ev_pending) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+    c->nuts_kernel_ns += (double)ms * 1e6;
+    c->ev_pool.push_back(e);
+  }
+  c->ev_pending.clear();
+  return AHMC_OK;
+}
+
 template <class T>
 int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha,
                     bool accum, int n_trans = 1, T* samples_dev = nullptr) {
@@ -372,7 +393,14 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
       // fast pass: multinomial weights in the linear domain; chains that came near overflow are
       // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
       p.redo_only = 0;
+      if (c->ev_pending.size() >= 1024) { rc = flush_nuts_events(c); if (rc) return rc; }
+      std::pair<hipEvent_t, hipEvent_t> ev;
+      if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+      else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
+      HIPCHK(hipEventRecord(ev.first, c->stream));
       rc = launch_nuts<T, 0>(c, p, max_depth);
+      HIPCHK(hipEventRecord(ev.second, c->stream));
+      c->ev_pending.push_back(ev);
       if (rc) return rc;
       c->nuts_launches += 1;
       p.redo_only = 1;
@@ -1009,6 +1037,12 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
       case AHMC_INFO_NUTS_LAUNCHES: *out = c->nuts_launches; break;
       case AHMC_INFO_NUTS_BATCH: *out = nuts_batch(c); break;
       case AHMC_INFO_ITERATION: *out = (int64_t)c->iteration; break;
+      case AHMC_INFO_NUTS_KERNEL_NS: {
+        int rc = flush_nuts_events(c);
+        if (rc) return rc;
+        *out = (int64_t)c->nuts_kernel_ns;
+        break;
+      }
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
     }
     return AHMC_OK;

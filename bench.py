@@ -13,11 +13,12 @@ and ranks in the timed region ÷ that time.
 In the sampling phase the engine runs a batch of transitions per launch of the dominant kernel
 k_nuts (chains are independent, so there is no per-transition barrier; `nuts_batch` transitions,
 the K steps split evenly over ⌈K / nuts_batch⌉ launches).  The roofline object is per LAUNCH:
-algorithmic bytes of the leapfrogs one launch executes ÷ the launch's duration; the HIP events
-bracket the K steps on the engine's stream, i.e. the k_nuts launches plus two small helpers per
-launch (k_normals: the momentum normals; the log-domain redo pass, which almost always exits
-immediately) — `avg_launch_ms` therefore sits a few % above rocprofv3's k_nuts average
-(profiles/r1_kernel_stats.csv).
+algorithmic bytes of the leapfrogs one launch executes ÷ the launch's duration, measured by HIP
+events the engine records around each k_nuts launch on its own stream (AHMC_INFO_NUTS_KERNEL_NS) —
+the same quantity rocprofv3's kernel trace reports for those launches (profiles/r1_kernel_stats.csv,
+"timed launches" rows; the `--stats` average also covers the single-transition launches of the
+adaptation phase).  `timed_region_ms_on_stream` is the whole K-step region incl. the helpers
+(k_normals, the log-domain redo pass).
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); chains shard with no
 data-path collective (weak scaling, 65 536 chains per GPU, Philox chain offset = rank·N); the
@@ -155,7 +156,7 @@ def main():
     barrier()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    launches0 = eng.info("nuts_launches")
+    launches0, kns0 = eng.info("nuts_launches"), eng.info("nuts_kernel_ns")
     t0 = time.perf_counter()
     ev0.record(stream)
     eng.run(kernel, args.steps, 0)  # K transitions, accumulators reset at the first one
@@ -184,7 +185,7 @@ def main():
     if rank == 0:
         B_lf = algorithmic_bytes_per_leapfrog(D, True, 8)
         n_launches = max(1, eng.info("nuts_launches") - launches0)
-        per_launch_s = (kernel_ms / 1e3) / n_launches
+        per_launch_s = (eng.info("nuts_kernel_ns") - kns0) / 1e9 / n_launches  # HIP events around k_nuts, engine stream
         achieved = (n_leap / n_launches) * B_lf / per_launch_s / 1e9  # this rank's dominant kernel
         traffic = measured_traffic(D, N)
         if traffic is not None:  # measured per launch of `transitions_per_launch`; rescale to this run's launches
@@ -217,6 +218,7 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_leapfrog": B_lf, "avg_launch_ms": per_launch_s * 1e3,
                 "launches": n_launches, "transitions_per_launch": args.steps / n_launches,
+                "timed_region_ms_on_stream": kernel_ms,
                 "leapfrogs_per_launch": n_leap / n_launches,
             },
         }

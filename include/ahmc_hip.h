@@ -257,7 +257,8 @@ typedef enum {
   AHMC_INFO_ELEMS_PER_LANE = 1,   /* E: contiguous dimensions per lane                           */
   AHMC_INFO_NUTS_LAUNCHES = 2,    /* launches of the dominant NUTS kernel since ahmc_create      */
   AHMC_INFO_NUTS_BATCH = 3,       /* transitions per NUTS launch in the sampling phase           */
-  AHMC_INFO_ITERATION = 4         /* transitions done (the Philox iteration counter)             */
+  AHMC_INFO_ITERATION = 4,        /* transitions done (the Philox iteration counter)             */
+  AHMC_INFO_NUTS_KERNEL_NS = 5    /* Σ device time of those launches, ns (HIP events; synchronises) */
 } ahmc_info;
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out);
 
