@@ -4,6 +4,7 @@
 // every numerical result comes from a kernel.
 #include "ahmc_hip.h"
 #include "ahmc_inst.hpp"
+#include "ahmc_dense.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -120,12 +121,19 @@ struct Ctx : CtxBase {
   // roofline on the kernel's own duration, the quantity rocprofv3's kernel trace reports
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_pending;
   double nuts_kernel_ns = 0;
+  // step-synchronous dense engine (ahmc_dense.hpp): M⁻¹, U⁻¹ (D,D); vector slots; per-chain tree state
+  T *dn_minv = nullptr, *dn_uinv = nullptr, *dn_W = nullptr, *dn_es = nullptr, *dn_RB = nullptr, *dn_VB = nullptr;
+  DChain<T>* dn_S = nullptr;
+  int* dn_active = nullptr;
+  size_t dn_slots = 0, dn_batch_elems = 0;
+  int64_t dn_global_steps = 0;
 
   ~Ctx() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
-                    da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm};
+                    da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
+                    dn_S, dn_active};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -216,21 +224,32 @@ template <class T>
 int check_builtin(Ctx<T>* c, const char* what) {
   if (c->target_kind == AHMC_TARGET_EXTERNAL)
     return fail(c, AHMC_ERR_STATE, std::string(what) + " needs a built-in target; with AHMC_TARGET_EXTERNAL use ahmc_lf_pre/ahmc_lf_post");
-  if (c->target_kind == AHMC_TARGET_DENSE_GAUSS)
-    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": AHMC_TARGET_DENSE_GAUSS has no HIP kernel yet");
+  if (dense_engine(c))
+    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + " is not implemented for DenseEuclideanMetric / AHMC_TARGET_DENSE_GAUSS");
   return AHMC_OK;
 }
 
 template <class T>
-int launch_fill_caches(Ctx<T>* c) {
+int launch_fill_caches_builtin(Ctx<T>* c) {
   KP<T> p = make_kp(c);
   with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::fill_caches(c->G, c->E, group_grid(c), c->stream, p); });
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
 
+#include "ahmc_dense_host.hpp"
+
+template <class T>
+int launch_fill_caches(Ctx<T>* c) {
+  return dense_engine(c) ? dn_fill_caches(c) : launch_fill_caches_builtin(c);
+}
+
 template <class T>
 int launch_kinetic(Ctx<T>* c) {
+  if (dense_engine(c)) {
+    int rc = dn_ensure(c, 2);
+    return rc ? rc : dn_velocity(c);
+  }
   KP<T> p = make_kp(c);
   with_geometry(c->G, c->E, [&](auto g, auto e) {
     hipLaunchKernelGGL((k_kinetic<T, decltype(g)::value, decltype(e)::value>), dim3(group_grid(c)), dim3(decltype(g)::value > 64 ? decltype(g)::value : 256), 0,
@@ -248,7 +267,13 @@ int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
     c->minv_n = 0;
     return AHMC_OK;
   }
-  if (kind == AHMC_METRIC_DENSE) return fail(c, AHMC_ERR_UNSUPPORTED, "DenseEuclideanMetric has no HIP kernel yet (SURVEY §8a: config 4 only)");
+  if (kind == AHMC_METRIC_DENSE) {
+    if (!minv) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: M⁻¹ pointer is NULL");
+    if (n != c->D * c->D) return fail(c, AHMC_ERR_ARGUMENT, "AxesMismatch: dense M⁻¹ must have D*D elements");
+    if (c->adapt_kind == AHMC_ADAPT_MASSMATRIX || c->adapt_kind == AHMC_ADAPT_NAIVE || c->adapt_kind == AHMC_ADAPT_STAN)
+      return fail(c, AHMC_ERR_UNSUPPORTED, "mass-matrix adaptation of a DenseEuclideanMetric is not implemented");
+    return dn_set_metric(c, minv);
+  }
   if (kind != AHMC_METRIC_DIAG) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: unknown metric kind");
   if (!minv) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: M⁻¹ pointer is NULL");
   if (n != c->D && n != c->D * c->N)
@@ -353,6 +378,12 @@ template <class T>
 int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha,
                     bool accum, int n_trans = 1, T* samples_dev = nullptr) {
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
+  if (dense_engine(c)) {
+    if (sampler != AHMC_TS_MULTINOMIAL && sampler != AHMC_TS_SLICE)
+      return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
+    if (max_depth < 1) return fail(c, AHMC_ERR_ARGUMENT, "max_depth must be >= 1");
+    return dn_nuts_transition(c, max_depth, delta_max, criterion, sampler, refresh_alpha, accum, n_trans, samples_dev);
+  }
   int rc = check_builtin(c, "nuts_transition");
   if (rc) return rc;
   if (sampler != AHMC_TS_MULTINOMIAL && sampler != AHMC_TS_SLICE)
@@ -432,7 +463,7 @@ int64_t nuts_batch(Ctx<T>* c) {
 template <class T>
 int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refresh_alpha, bool accum) {
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
-  int rc = check_builtin(c, "hmc_transition");
+  int rc = dense_engine(c) ? AHMC_OK : check_builtin(c, "hmc_transition");
   if (rc) return rc;
   if (sampler != AHMC_TS_ENDPOINT && sampler != AHMC_TS_MULTINOMIAL)
     return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
@@ -442,6 +473,7 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refr
     L = n < 1 ? 1 : n;
   }
   if (L < 0) L = -L;
+  if (dense_engine(c)) return dn_hmc_transition(c, L, sampler, refresh_alpha, accum);
   if (sampler == AHMC_TS_MULTINOMIAL) {
     size_t need = (size_t)(L + 1) * (size_t)c->N;
     if (need > c->hmc_H_elems) {
@@ -474,6 +506,8 @@ int reset_accum(Ctx<T>* c) {
 
 template <class T>
 int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
+  if (c->metric_kind == AHMC_METRIC_DENSE && (kind == AHMC_ADAPT_MASSMATRIX || kind == AHMC_ADAPT_NAIVE || kind == AHMC_ADAPT_STAN))
+    return fail(c, AHMC_ERR_UNSUPPORTED, "mass-matrix adaptation of a DenseEuclideanMetric is not implemented (StepSizeAdaptor is)");
   c->adapt_kind = kind;
   c->da_delta = delta;
   c->stan_init = ib; c->stan_term = tb; c->stan_window = ws;
@@ -732,9 +766,9 @@ int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n
 
 int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
   FOR_CTX(ctx, {
-    if (c->metric_kind != AHMC_METRIC_DIAG) return fail(c, AHMC_ERR_ARGUMENT, "get_metric: unit metric has no array");
+    if (c->metric_kind == AHMC_METRIC_UNIT) return fail(c, AHMC_ERR_ARGUMENT, "get_metric: unit metric has no array");
     if (n != c->minv_n) return fail(c, AHMC_ERR_ARGUMENT, "get_metric: size mismatch");
-    HIPCHK(hipMemcpyAsync(out, c->minv, sizeof(T) * n, hipMemcpyDefault, c->stream));
+    HIPCHK(hipMemcpyAsync(out, c->metric_kind == AHMC_METRIC_DENSE ? c->dn_minv : c->minv, sizeof(T) * n, hipMemcpyDefault, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AHMC_OK;
   });
@@ -786,7 +820,7 @@ int32_t ahmc_seed(ahmc_ctx* ctx, uint64_t seed, uint64_t chain_offset, uint64_t 
 int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r) {
   FOR_CTX(ctx, {
     if (!theta) return fail(c, AHMC_ERR_ARGUMENT, "set_position: theta is NULL");
-    int rc = check_builtin(c, "set_position");
+    int rc = dense_engine(c) ? dn_check(c, "set_position", 0) : check_builtin(c, "set_position");
     if (rc) return rc;
     const size_t nb = sizeof(T) * c->D * c->N;
     HIPCHK(hipMemcpyAsync(c->th, theta, nb, hipMemcpyDefault, c->stream));
@@ -832,6 +866,7 @@ int32_t ahmc_get_phasepoint(ahmc_ctx* ctx, void* theta, void* r, void* lp, void*
 int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
   FOR_CTX(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "refresh before set_position");
+    if (dense_engine(c)) return dn_refresh(c, alpha);
     int rc = check_builtin(c, "refresh_momentum");
     if (rc) return rc;
     KP<T> p = make_kp(c);
@@ -845,6 +880,7 @@ int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
 int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
   FOR_CTX(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "leapfrog before set_position");
+    if (dense_engine(c)) return dn_leapfrog(c, n_steps);
     int rc = check_builtin(c, "leapfrog");
     if (rc) return rc;
     KP<T> p = make_kp(c);
@@ -858,6 +894,7 @@ int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
 int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps) {
   FOR_CTX(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "lf_pre before set_phasepoint");
+    if (c->metric_kind == AHMC_METRIC_DENSE) return fail(c, AHMC_ERR_UNSUPPORTED, "lf_pre/lf_post are not implemented for DenseEuclideanMetric");
     KP<T> p = make_kp(c);
     const int64_t DN = c->D * c->N;
     hipLaunchKernelGGL((k_lf_pre<T>), dim3((unsigned)((DN + 255) / 256)), dim3(256), 0, c->stream, p, (int)fwd, i, n_steps);

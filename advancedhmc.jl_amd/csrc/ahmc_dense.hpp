@@ -1,0 +1,657 @@
+// ahmc_dense.hpp — the step-synchronous engine for DenseEuclideanMetric and the dense Gaussian
+// target (src/hamiltonian.jl:60-68,179-184, src/metric.jl:89-120,311-320).
+//
+// ∂H∂r = M⁻¹ r and ∇ℓπ = −Pθ couple all D elements of a chain, so a chain can no longer live in the
+// registers of one lane group.  What is shared instead is the D×D matrix: all chains multiply by
+// the same M⁻¹ / P, i.e. a GEMM (D×D)·(D×N) on the f64/f32 MFMA units.  The engine therefore keeps
+// the whole tree state of every chain in HBM and advances ALL chains by one leapfrog per "global
+// step":
+//     r −= ϵ/2 g → V = M⁻¹R (MFMA) → θ += ϵV → (ℓπ, g) (MFMA for the dense target) → r −= ϵ/2 g
+//     → V = M⁻¹R, ℓκ = −½ r·v (MFMA) → k_d_tree: one NUTS leaf + its merges per chain
+// k_d_tree is the iterative build_tree of ahmc_nuts.hpp turned into a resumable state machine (one
+// wave per chain, state in DChain + vector slots).  Chains run asynchronously through a batch of
+// transitions: a chain that ends a transition starts its next one in the same call (its fresh
+// momentum r = U⁻¹z and v = M⁻¹r were produced for the whole batch by two GEMMs up front), so the
+// only idle time is at the end of the batch.
+#pragma once
+
+#include "ahmc_kernels.hpp"
+#include "ahmc_nuts.hpp"
+
+namespace ahmc {
+
+// ------------------------------------------------------------------------------------------------
+// Y (D,N) = A (D,D) · X (D,N).  A symmetric (M⁻¹, P) or general (U⁻¹) column-major; X, Y column-major
+// (a chain per column).  64×64 output tile per 256-thread workgroup, 32×32 per wave as 2×2 MFMA
+// 16x16x4 tiles; K stepped by 16 through LDS with register-staged prefetch.
+// MFMA 16x16x4 operand layout (probed on gfx950, scripts/probe/mfma_layout.hip):
+//   a: A[i = lane%16][k = lane/16]   b: B[k = lane/16][j = lane%16]
+//   f64 acc[v]: C[i = lane/16 + 4v][j = lane%16]     f32 acc[v]: C[i = 4*(lane/16) + v][j = lane%16]
+// ------------------------------------------------------------------------------------------------
+template <class T> struct Mfma;
+template <> struct Mfma<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int v) { return (lane >> 4) + 4 * v; }
+};
+template <> struct Mfma<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int v) { return 4 * (lane >> 4) + v; }
+};
+
+constexpr int GB_M = 64, GB_N = 64, GB_K = 16, GB_PAD = 4;
+
+// TRANS_A: use Aᵀ (A[k + i*D] instead of A[i + k*D]) — for the general (non-symmetric) U⁻¹ both
+// orientations are needed nowhere else, so only the plain form is instantiated today.
+template <class T>
+__global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N) {
+  __shared__ T As[GB_K][GB_M + GB_PAD];
+  __shared__ T Bs[GB_K][GB_N + GB_PAD];
+  using M = Mfma<T>;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m0 = blockIdx.x * GB_M;
+  const int64_t n0 = (int64_t)blockIdx.y * GB_N;
+  const int wm = (w & 1) * 32, wn = (w >> 1) * 32;
+  typename M::acc_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = typename M::acc_t{0, 0, 0, 0};
+  T ra[4], rb[4];
+  const int ai = (tid & 31) * 2, ak = tid >> 5;  // A tile: rows ai, ai+1 of k-rows ak and ak+8
+  const int bn = tid >> 2, bk = (tid & 3) * 4;   // X tile: column bn, k-rows bk..bk+3
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = k0 + ak + 8 * q;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = m0 + ai + e;
+        ra[2 * q + e] = (k < D && i < D) ? A[i + (int64_t)k * D] : T(0);
+      }
+    }
+    const int64_t col = n0 + bn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + bk + e;
+      rb[e] = (col < N && k < D) ? X[k + col * D] : T(0);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) As[ak + 8 * q][ai + e] = ra[2 * q + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Bs[bk + e][bn] = rb[e];
+  };
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  for (int k0 = 0; k0 < D; k0 += GB_K) {
+    const bool more = k0 + GB_K < D;
+    if (more) load_tiles(k0 + GB_K);
+#pragma unroll
+    for (int ks = 0; ks < GB_K / 4; ++ks) {
+      const int kq = ks * 4 + (lane >> 4), l16 = lane & 15;
+      const T a0 = As[kq][wm + l16], a1 = As[kq][wm + 16 + l16];
+      const T b0 = Bs[kq][wn + l16], b1 = Bs[kq][wn + 16 + l16];
+      acc[0][0] = M::mma(a0, b0, acc[0][0]);
+      acc[0][1] = M::mma(a0, b1, acc[0][1]);
+      acc[1][0] = M::mma(a1, b0, acc[1][0]);
+      acc[1][1] = M::mma(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+    if (more) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int64_t col = n0 + wn + tj * 16 + (lane & 15);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = m0 + wm + ti * 16 + M::row(lane, v);
+        if (row < D && col < N) Y[row + col * D] = acc[ti][tj][v];
+      }
+    }
+}
+
+// out[c] = sanitize(scale · Σ_d a[d,c] b[d,c]); one wave per chain
+template <class T>
+__global__ __launch_bounds__(256) void k_d_coldot(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, T scale, int D, int64_t N) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= N) return;
+  T s[2] = {0, 0};
+  for (int d = lane; d < D; d += 64) s[0] += a[c * D + d] * b[c * D + d];
+  wave_allsum2<64>(s[0], s[1]);
+  if (lane == 0) out[c] = sanitize(scale * s[0]);
+}
+
+// r[:,c] −= es[c]/2 · g[:,c]  (es = signed step of the chain this global step; 0 = chain idle)
+template <class T>
+__global__ __launch_bounds__(256) void k_d_half(T* __restrict__ r, const T* __restrict__ g, const T* __restrict__ es, int D, int64_t N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)D * N) return;
+  const T e = es[idx / D];
+  if (e != T(0)) r[idx] = r[idx] - e / 2 * g[idx];
+}
+// θ[:,c] += es[c] · v[:,c]
+template <class T>
+__global__ __launch_bounds__(256) void k_d_pos(T* __restrict__ th, const T* __restrict__ v, const T* __restrict__ es, int D, int64_t N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)D * N) return;
+  const T e = es[idx / D];
+  if (e != T(0)) th[idx] = th[idx] + e * v[idx];
+}
+// v = M⁻¹ ⊙ r for Unit / Diag metrics used together with the dense target (minv may be null)
+template <class T>
+__global__ __launch_bounds__(256) void k_d_vdiag(const T* __restrict__ r, const T* __restrict__ minv, int per_chain, T* __restrict__ v, int D, int64_t N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)D * N) return;
+  v[idx] = minv ? minv[per_chain ? idx : idx % D] * r[idx] : r[idx];
+}
+// r = z ./ sqrtM⁻¹ (Diag) or r = z (Unit), n vectors of the batch at once
+template <class T>
+__global__ __launch_bounds__(256) void k_d_rdiag(const T* __restrict__ z, const T* __restrict__ sq, int per_chain, T* __restrict__ r, int D, int64_t N, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t j = idx % ((int64_t)D * N);
+  r[idx] = sq ? z[idx] / sq[per_chain ? j : j % D] : z[idx];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_set(T* __restrict__ out, const T* __restrict__ in, T scale, int64_t n) {  // out = scale·in (in may be null → scale)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = in ? scale * in[idx] : scale;
+}
+// jitter(rng, lf) (src/integrator.jl:140-156) → ϵ_cur
+template <class T>
+__global__ __launch_bounds__(256) void k_d_jitter(KP<T> p) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.N) return;
+  Rng rng = make_rng(p, c);
+  p.eps_cur()[c] = chain_eps(p, rng, c);
+}
+// es[c] = 0 once the chain's point is non-finite: step() stops at the first non-finite point
+// (src/integrator.jl:248-255), per chain
+template <class T>
+__global__ __launch_bounds__(256) void k_d_freeze(const T* __restrict__ lp, const T* __restrict__ lk, T* __restrict__ es, int64_t N) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  if (!(isfinite(lp[c]) && isfinite(lk[c]))) es[c] = T(0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-chain tree state of the dense engine
+// ------------------------------------------------------------------------------------------------
+constexpr int DN_MAXLEV = 16;  // pending levels = max_depth − 1
+enum { DPH_IDLE = 0, DPH_START = 1, DPH_RUN = 2 };
+// vector slots: T[slot][N][D]
+enum {
+  DS_CUR_V = 0,
+  DS_OTH_TH, DS_OTH_R, DS_OTH_G, DS_OTH_V,
+  DS_TREE_RHO,
+  DS_CAND_TH, DS_CAND_R, DS_CAND_G,
+  DS_SUB_RHO, DS_SUB_VF, DS_SUB_CTH, DS_SUB_CR, DS_SUB_CG,
+  DS_START_TH, DS_START_R, DS_START_G,  // static HMC: the start point (for rejected proposals)
+  DS_FIXED,
+  DS_PER_LEVEL = 5  // ρ, v_first, candidate θ, r, g
+};
+
+template <class T>
+struct DChain {
+  T H0, eps, w_tree, sa_tree, dh_tree, lu;
+  T cand_lp, cand_lk, sub_lp, sub_lk;  // energies of the tree-level / current-subtree candidates
+  T w_c, sa_c, dh_c;
+  T pw[DN_MAXLEV], psa[DN_MAXLEV], pdh[DN_MAXLEV], plp[DN_MAXLEV], plk[DN_MAXLEV];
+  int32_t pna[DN_MAXLEV];
+  int32_t phase, it, jw, leaf, v, cur_is_left, na_tree, na_c, depth, numerical;
+  uint32_t k;  // sequential draws consumed in this transition
+};
+
+template <class T>
+struct DP {  // dense-engine arguments (beside KP)
+  T* W;            // vector slots
+  DChain<T>* S;    // per-chain state
+  T* es;           // (N,) signed step of the next global step (0 = idle)
+  const T* RB;     // (n_trans, N, D) fresh momenta of the batch
+  const T* VB;     // (n_trans, N, D) M⁻¹ · RB
+  int n_trans;
+  int* n_active;   // device counter: chains that have not finished the batch
+};
+
+template <class T>
+__device__ __forceinline__ T* dslot(const DP<T>& q, const KP<T>& p, int slot, int64_t c) {
+  return q.W + ((int64_t)slot * p.N + c) * p.D;
+}
+template <class T>
+__device__ __forceinline__ void vcopy(T* __restrict__ dst, const T* __restrict__ src, int D, int lane) {
+  for (int d = lane; d < D; d += 64) dst[d] = src[d];
+}
+
+// One call = for every chain that is running: account for the leapfrog that has just completed
+// (leaf, merges, end of subtree, end of doubling, end of transition, start of the next transition)
+// and publish the signed step of its next leapfrog.  MultinomialTS / SliceTS with
+// GeneralisedNoUTurn; log-domain weights as the reference (src/trajectory.jl:144-206,626-742).
+template <class T>
+__global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= p.N) return;
+  DChain<T>& S = q.S[c];
+  if (S.phase == DPH_IDLE) return;
+  const int D = p.D;
+  const bool slice = p.sampler == 2;
+  T* th = p.th() + c * D;
+  T* r = p.r() + c * D;
+  T* g = p.g() + c * D;
+  T* V = dslot(q, p, DS_CUR_V, c);
+  Rng rng = make_rng(p, c);
+  DrawStream ds;
+  auto resume_draws = [&](uint32_t it, uint32_t k) {
+    rng.iter = p.iteration + it;
+    ds.init(rng);
+    ds.k = k;
+    if (k & 1u) ds.blk = rng.raw(RNG_TRANSITION, k >> 1);
+  };
+  // scalars are uniform across the wave: every lane computes them; lane 0 writes them back
+  int phase = S.phase, it = S.it;
+  bool start = phase == DPH_START;
+  T lp_start = start ? p.lp()[c] : T(0);  // ℓπ(θ) of the point the next transition starts from
+  if (!start) {
+    resume_draws((uint32_t)it, S.k);
+    const T H0 = S.H0, eps = S.eps;
+    const int v = S.v, jw = S.jw;
+    int leaf = S.leaf;
+    const uint32_t nleaf = 1u << jw;
+    const T lp = p.lp()[c], lk = p.lk()[c];
+    // ---- leaf (:638-647) ----
+    const T ne = lp + lk;
+    const T dH = -ne - H0;
+    T sa_c = exp(jl_min(T(0), -dH)), dh_c = dH, w_c;
+    int na_c = 1;
+    bool sub_term;
+    if (slice) {
+      w_c = (S.lu <= ne) ? T(1) : T(0);
+      sub_term = !(S.lu < p.delta_max + ne);
+    } else {
+      w_c = H0 + ne;
+      sub_term = !(-H0 < p.delta_max + ne);
+    }
+    bool numerical = S.numerical != 0 || sub_term;
+    T* s_rho = dslot(q, p, DS_SUB_RHO, c);
+    T* s_vf = dslot(q, p, DS_SUB_VF, c);
+    T* s_cth = dslot(q, p, DS_SUB_CTH, c);
+    T* s_cr = dslot(q, p, DS_SUB_CR, c);
+    T* s_cg = dslot(q, p, DS_SUB_CG, c);
+    for (int d = lane; d < D; d += 64) {
+      const T rd = r[d];
+      s_rho[d] = rd;
+      s_vf[d] = V[d];
+      s_cth[d] = th[d];
+      s_cr[d] = rd;
+      s_cg[d] = g[d];
+    }
+    T sub_lp = lp, sub_lk = lk;
+    // ---- merges: one per trailing zero bit of `leaf` (:649-673) ----
+    const int nm = __builtin_ctz((uint32_t)leaf);
+    int merged = 0;
+    for (int lvl = 0; lvl < nm && !sub_term; ++lvl) {
+      T* p_rho = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 0, c);
+      T* p_vf = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 1, c);
+      const T w_p = S.pw[lvl];
+      bool keep_first;
+      T w_new;
+      if (slice) {
+        w_new = w_p + w_c;
+        keep_first = w_new * (T)ds.uniform() < w_p;
+      } else {
+        w_new = logaddexp(w_p, w_c);
+        keep_first = w_new < w_p + (T)ds.randexp();
+      }
+      if (keep_first) {
+        const T* p_cth = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 2, c);
+        const T* p_cr = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 3, c);
+        const T* p_cg = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 4, c);
+        for (int d = lane; d < D; d += 64) {
+          s_cth[d] = p_cth[d];
+          s_cr[d] = p_cr[d];
+          s_cg[d] = p_cg[d];
+        }
+        sub_lp = S.plp[lvl];
+        sub_lk = S.plk[lvl];
+      }
+      w_c = w_new;
+      sa_c = S.psa[lvl] + sa_c;
+      na_c = S.pna[lvl] + na_c;
+      const T dh_p = S.pdh[lvl];
+      dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+      // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
+      T dots[2] = {0, 0};
+      for (int d = lane; d < D; d += 64) {
+        const T rho = p_rho[d] + s_rho[d];
+        const T vf = p_vf[d];
+        dots[0] += rho * vf;
+        dots[1] += rho * V[d];
+        s_rho[d] = rho;
+        s_vf[d] = vf;
+      }
+      wave_allsum2<64>(dots[0], dots[1]);
+      sub_term = (dots[0] <= 0) || (dots[1] <= 0);
+      merged = lvl + 1;
+    }
+    bool subtree_over = true;
+    if (sub_term) {
+      // enclosing unfinished subtrees still absorb the statistics of their first halves (:666)
+      const uint32_t pend = (((uint32_t)leaf - 1u) >> merged) << merged;
+      for (int qq = merged; (pend >> qq) != 0u; ++qq) {
+        if ((pend >> qq) & 1u) {
+          sa_c = S.psa[qq] + sa_c;
+          na_c = S.pna[qq] + na_c;
+          const T dh_p = S.pdh[qq];
+          dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+        }
+      }
+    } else if ((uint32_t)leaf < nleaf) {
+      // park the finished level-nm subtree until its sibling is built
+      T* p_rho = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 0, c);
+      T* p_vf = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 1, c);
+      T* p_cth = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 2, c);
+      T* p_cr = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 3, c);
+      T* p_cg = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 4, c);
+      for (int d = lane; d < D; d += 64) {
+        p_rho[d] = s_rho[d];
+        p_vf[d] = s_vf[d];
+        p_cth[d] = s_cth[d];
+        p_cr[d] = s_cr[d];
+        p_cg[d] = s_cg[d];
+      }
+      if (lane == 0) {
+        S.pw[nm] = w_c;
+        S.psa[nm] = sa_c;
+        S.pdh[nm] = dh_c;
+        S.pna[nm] = na_c;
+        S.plp[nm] = sub_lp;
+        S.plk[nm] = sub_lk;
+        S.leaf = leaf + 1;
+        S.numerical = numerical ? 1 : 0;
+        S.k = ds.k;
+      }
+      subtree_over = false;  // next leapfrog: same edge, same direction (es unchanged)
+    }
+    if (!subtree_over) return;
+
+    // ---- top level of the doubling loop (:708-722) ----
+    T w_tree = S.w_tree, sa_tree = S.sa_tree, dh_tree = S.dh_tree;
+    int na_tree = S.na_tree, depth = S.depth;
+    T cand_lp = S.cand_lp, cand_lk = S.cand_lk;
+    if (!sub_term) {
+      ++depth;
+      bool acc;  // mh_accept(rng, sampler, sampler′): biased progressive sampling (:202-206)
+      if (slice) acc = w_tree * (T)ds.uniform() < w_c;
+      else acc = w_tree < w_c + (T)ds.randexp();
+      if (acc) {
+        T* c_th = dslot(q, p, DS_CAND_TH, c);
+        T* c_r = dslot(q, p, DS_CAND_R, c);
+        T* c_g = dslot(q, p, DS_CAND_G, c);
+        for (int d = lane; d < D; d += 64) {
+          c_th[d] = s_cth[d];
+          c_r[d] = s_cr[d];
+          c_g[d] = s_cg[d];
+        }
+        cand_lp = sub_lp;
+        cand_lk = sub_lk;
+      }
+    }
+    sa_tree = sa_tree + sa_c;
+    na_tree = na_tree + na_c;
+    dh_tree = v < 0 ? maxabs(dh_c, dh_tree) : maxabs(dh_tree, dh_c);
+    w_tree = slice ? w_tree + w_c : logaddexp(w_tree, w_c);
+    // isterminated on the whole tree; its edges are `cur` and the dormant one
+    bool turn;
+    {
+      T* t_rho = dslot(q, p, DS_TREE_RHO, c);
+      const T* o_v = dslot(q, p, DS_OTH_V, c);
+      T dots[2] = {0, 0};
+      for (int d = lane; d < D; d += 64) {
+        const T rho = t_rho[d] + s_rho[d];
+        dots[0] += rho * V[d];
+        dots[1] += rho * o_v[d];
+        t_rho[d] = rho;
+      }
+      wave_allsum2<64>(dots[0], dots[1]);
+      turn = (dots[0] <= 0) || (dots[1] <= 0);
+    }
+    const bool done = sub_term || turn || (jw + 1 >= p.max_depth);
+    if (!done) {
+      // ---- next doubling: direction (:693), edge selection ----
+      const bool vleft = ds.boolean();
+      const bool cur_is_left = S.cur_is_left != 0;
+      if (vleft != cur_is_left) {  // continue from the other edge: swap the two edge points
+        T* o_th = dslot(q, p, DS_OTH_TH, c);
+        T* o_r = dslot(q, p, DS_OTH_R, c);
+        T* o_g = dslot(q, p, DS_OTH_G, c);
+        T* o_v = dslot(q, p, DS_OTH_V, c);
+        for (int d = lane; d < D; d += 64) {
+          T t;
+          t = o_th[d]; o_th[d] = th[d]; th[d] = t;
+          t = o_r[d]; o_r[d] = r[d]; r[d] = t;
+          t = o_g[d]; o_g[d] = g[d]; g[d] = t;
+          t = o_v[d]; o_v[d] = V[d]; V[d] = t;
+        }
+      }
+      if (lane == 0) {
+        S.w_tree = w_tree; S.sa_tree = sa_tree; S.dh_tree = dh_tree; S.na_tree = na_tree; S.depth = depth;
+        S.cand_lp = cand_lp; S.cand_lk = cand_lk;
+        S.numerical = numerical ? 1 : 0;
+        S.cur_is_left = vleft ? 1 : 0;
+        S.v = vleft ? -1 : 1;
+        S.jw = jw + 1;
+        S.leaf = 1;
+        S.k = ds.k;
+        q.es[c] = vleft ? -eps : eps;
+      }
+      return;
+    }
+    // ---- Transition(zcand, stats) (:725-741) ----
+    {
+      const T* c_th = dslot(q, p, DS_CAND_TH, c);
+      const T* c_r = dslot(q, p, DS_CAND_R, c);
+      const T* c_g = dslot(q, p, DS_CAND_G, c);
+      T* s1 = p.acc_sum() + c * D;
+      T* s2 = p.acc_sumsq() + c * D;
+      T* so = p.samples_out ? p.samples_out + ((int64_t)it * p.N + c) * D : nullptr;
+      for (int d = lane; d < D; d += 64) {
+        const T t = c_th[d];
+        th[d] = t;
+        r[d] = c_r[d];
+        g[d] = c_g[d];
+        if (p.accum) { s1[d] += t; s2[d] += t * t; }
+        if (so) so[d] = t;
+      }
+      if (lane == 0) {
+        const T H = -(cand_lp + cand_lk);
+        p.lp()[c] = cand_lp;
+        p.lk()[c] = cand_lk;
+        p.eps_cur()[c] = eps;
+        p.st_nsteps()[c] = na_tree;
+        p.st_accept()[c] = 1;
+        p.st_accrate()[c] = sa_tree / (T)na_tree;
+        p.st_logdens()[c] = cand_lp;
+        p.st_H()[c] = H;
+        p.st_Herr()[c] = H - H0;
+        p.st_maxHerr()[c] = dh_tree;
+        p.st_depth()[c] = depth;
+        p.st_numerr()[c] = numerical ? 1 : 0;
+        if (p.accum) {
+          p.acc_nsteps()[c] += na_tree;
+          p.acc_ndiv()[c] += numerical ? 1 : 0;
+        }
+      }
+      ++it;
+      if (it >= q.n_trans) {
+        if (lane == 0) {
+          S.phase = DPH_IDLE;
+          S.it = it;
+          q.es[c] = T(0);
+          atomicSub(q.n_active, 1);
+        }
+        return;
+      }
+      start = true;
+      lp_start = cand_lp;  // (lane 0 has just stored it; the other lanes must not re-read it)
+    }
+  }
+  // ---- start of transition `it` (src/sampler.jl:54-57, src/trajectory.jl:677-690): the state is the
+  // previous candidate (θ, g, ℓπ already in place); fresh momentum and v = M⁻¹r from the batch ----
+  {
+    resume_draws((uint32_t)it, 0u);
+    const T eps = chain_eps(p, rng, c);
+    const T* rb = q.RB + ((int64_t)it * p.N + c) * D;
+    const T* vb = q.VB + ((int64_t)it * p.N + c) * D;
+    T* o_th = dslot(q, p, DS_OTH_TH, c);
+    T* o_r = dslot(q, p, DS_OTH_R, c);
+    T* o_g = dslot(q, p, DS_OTH_G, c);
+    T* o_v = dslot(q, p, DS_OTH_V, c);
+    T* t_rho = dslot(q, p, DS_TREE_RHO, c);
+    T* c_th = dslot(q, p, DS_CAND_TH, c);
+    T* c_r = dslot(q, p, DS_CAND_R, c);
+    T* c_g = dslot(q, p, DS_CAND_G, c);
+    T dots[2] = {0, 0};
+    for (int d = lane; d < D; d += 64) {
+      const T rd = rb[d], vd = vb[d], td = th[d], gd = g[d];
+      dots[0] += rd * vd;
+      r[d] = rd;
+      V[d] = vd;
+      o_th[d] = td; o_r[d] = rd; o_g[d] = gd; o_v[d] = vd;
+      t_rho[d] = rd;
+      c_th[d] = td; c_r[d] = rd; c_g[d] = gd;
+    }
+    wave_allsum2<64>(dots[0], dots[1]);
+    const T lp = lp_start;
+    const T lk = sanitize(-dots[0] / 2);
+    const T H0 = -(lp + lk);
+    T lu = 0, w_tree;
+    if (slice) {
+      lu = -H0 - (T)ds.randexp();  // SliceTS(rng, z0) (:144-145)
+      w_tree = 1;
+    } else {
+      w_tree = 0;  // MultinomialTS(rng, z0): ℓw = 0 (:155)
+    }
+    const bool vleft = ds.boolean();
+    if (lane == 0) {
+      p.lk()[c] = lk;
+      S.H0 = H0; S.eps = eps; S.lu = lu; S.w_tree = w_tree; S.sa_tree = 0; S.dh_tree = 0; S.na_tree = 0;
+      S.cand_lp = lp; S.cand_lk = lk;
+      S.depth = 0; S.numerical = 0; S.jw = 0; S.leaf = 1;
+      S.cur_is_left = vleft ? 1 : 0;
+      S.v = vleft ? -1 : 1;
+      S.k = ds.k;
+      S.it = it;
+      S.phase = DPH_RUN;
+      q.es[c] = vleft ? -eps : eps;
+    }
+  }
+}
+
+// reset the chain states for a batch of n_trans transitions
+template <class T>
+__global__ __launch_bounds__(256) void k_d_tree_reset(DChain<T>* S, T* es, int* n_active, int64_t N) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *n_active = (int)N;
+  if (c >= N) return;
+  S[c].phase = DPH_START;
+  S[c].it = 0;
+  es[c] = T(0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// static HMC, EndPointTS (src/trajectory.jl:271-340, :855-880): begin = jitter + keep the start point;
+// end = MH accept (H′ < H + Exp(1)), rejected chains revert, momentum flip, statistics.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_d_hmc_begin(KP<T> p, DP<T> q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= p.N) return;
+  const int D = p.D;
+  Rng rng = make_rng(p, c);
+  const T eps = chain_eps(p, rng, c);
+  const T* th = p.th() + c * D;
+  const T* r = p.r() + c * D;
+  const T* g = p.g() + c * D;
+  T* s_th = dslot(q, p, DS_START_TH, c);
+  T* s_r = dslot(q, p, DS_START_R, c);
+  T* s_g = dslot(q, p, DS_START_G, c);
+  for (int d = lane; d < D; d += 64) {
+    s_th[d] = th[d];
+    s_r[d] = r[d];
+    s_g[d] = g[d];
+  }
+  if (lane == 0) {
+    DChain<T>& S = q.S[c];
+    S.H0 = -(p.lp()[c] + p.lk()[c]);
+    S.cand_lp = p.lp()[c];
+    S.cand_lk = p.lk()[c];
+    S.eps = eps;
+    p.eps_cur()[c] = eps;
+    q.es[c] = eps;
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_hmc_end(KP<T> p, DP<T> q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= p.N) return;
+  const int D = p.D;
+  DChain<T>& S = q.S[c];
+  Rng rng = make_rng(p, c);
+  const T H0 = S.H0;
+  const T lp1 = p.lp()[c], lk1 = p.lk()[c];
+  const T H1 = -(lp1 + lk1);
+  const T e = (T)rng.randexp(RNG_TRANSITION, 0);
+  const bool accept = H1 < H0 + e;                       // mh_accept_ratio (:855-880)
+  const T alpha = jl_min(T(1), exp(H0 - H1));
+  T* th = p.th() + c * D;
+  T* r = p.r() + c * D;
+  T* g = p.g() + c * D;
+  const T* s_th = dslot(q, p, DS_START_TH, c);
+  const T* s_r = dslot(q, p, DS_START_R, c);
+  const T* s_g = dslot(q, p, DS_START_G, c);
+  T* s1 = p.acc_sum() + c * D;
+  T* s2 = p.acc_sumsq() + c * D;
+  for (int d = lane; d < D; d += 64) {
+    T t = th[d], rr = r[d], gg = g[d];
+    if (!accept) { t = s_th[d]; rr = s_r[d]; gg = s_g[d]; }  // accept_phasepoint! (:312-332)
+    th[d] = t;
+    r[d] = -rr;  // z = PhasePoint(z.θ, -z.r, ...) (:283)
+    g[d] = gg;
+    if (p.accum) { s1[d] += t; s2[d] += t * t; }
+  }
+  if (lane == 0) {
+    const T lp = accept ? lp1 : S.cand_lp, lk = accept ? lk1 : S.cand_lk;
+    const T H = -(lp + lk);
+    p.lp()[c] = lp;
+    p.lk()[c] = lk;
+    p.st_nsteps()[c] = (int32_t)p.L;
+    p.st_accept()[c] = accept ? 1 : 0;
+    p.st_accrate()[c] = alpha;
+    p.st_logdens()[c] = lp;
+    p.st_H()[c] = H;
+    p.st_Herr()[c] = H - H0;
+    p.st_maxHerr()[c] = 0;
+    p.st_depth()[c] = 0;
+    p.st_numerr()[c] = (isfinite(lp1) && isfinite(lk1)) ? 0 : 1;
+    if (p.accum) {
+      p.acc_nsteps()[c] += p.L;
+      p.acc_ndiv()[c] += (isfinite(lp1) && isfinite(lk1)) ? 0 : 1;
+    }
+  }
+}
+
+}  // namespace ahmc

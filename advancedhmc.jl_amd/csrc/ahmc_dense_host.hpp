@@ -1,0 +1,313 @@
+// ahmc_dense_host.hpp — host side of the step-synchronous dense engine (included by ahmc_api.hip
+// after Ctx / make_kp / launch_fill_caches).  See ahmc_dense.hpp for the design.
+#pragma once
+
+template <class T>
+bool dense_engine(const Ctx<T>* c) {
+  return c->metric_kind == AHMC_METRIC_DENSE || c->target_kind == AHMC_TARGET_DENSE_GAUSS;
+}
+
+template <class T>
+int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols) {
+  dim3 grid((unsigned)((c->D + GB_M - 1) / GB_M), (unsigned)((ncols + GB_N - 1) / GB_N));
+  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols);
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+template <class T>
+DP<T> make_dp(Ctx<T>* c) {
+  DP<T> q;
+  q.W = c->dn_W;
+  q.S = c->dn_S;
+  q.es = c->dn_es;
+  q.RB = c->dn_RB;
+  q.VB = c->dn_VB;
+  q.n_trans = 1;
+  q.n_active = c->dn_active;
+  return q;
+}
+
+// workspace for trees of up to max_depth doublings
+template <class T>
+int dn_ensure(Ctx<T>* c, int max_depth) {
+  const int nlev = max_depth > 1 ? max_depth - 1 : 1;
+  const size_t slots = (size_t)DS_FIXED + (size_t)DS_PER_LEVEL * nlev;
+  if (slots > c->dn_slots) {
+    if (c->dn_W) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->dn_W)); c->dn_W = nullptr; }
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_W), slots * (size_t)c->D * (size_t)c->N * sizeof(T)));
+    HIPCHK(hipMemsetAsync(c->dn_W, 0, slots * (size_t)c->D * (size_t)c->N * sizeof(T), c->stream));
+    c->dn_slots = slots;
+  }
+  if (!c->dn_S) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_S), (size_t)c->N * sizeof(DChain<T>)));
+    HIPCHK(hipMemsetAsync(c->dn_S, 0, (size_t)c->N * sizeof(DChain<T>), c->stream));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_es), (size_t)c->N * sizeof(T)));
+    HIPCHK(hipMemsetAsync(c->dn_es, 0, (size_t)c->N * sizeof(T), c->stream));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), sizeof(int)));
+  }
+  return AHMC_OK;
+}
+
+template <class T>
+unsigned dn_grid_elems(Ctx<T>* c) { return (unsigned)(((int64_t)c->D * c->N + 255) / 256); }
+template <class T>
+unsigned dn_grid_chains(Ctx<T>* c) { return (unsigned)((c->N + 3) / 4); }  // one wave per chain, 4 per block
+
+// v = ∂H∂r(r) into the CUR_V slot, ℓκ = −½ r·v (src/hamiltonian.jl:50-68,155-184)
+template <class T>
+int dn_velocity(Ctx<T>* c) {
+  T* V = c->dn_W + (size_t)DS_CUR_V * c->D * c->N;
+  if (c->metric_kind == AHMC_METRIC_DENSE) {
+    int rc = dn_gemm(c, c->dn_minv, c->r, V, c->N);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r,
+                       c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V, (int)c->D, c->N);
+  }
+  hipLaunchKernelGGL((k_d_coldot<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, c->r, V, c->lk, T(-0.5), (int)c->D, c->N);
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+// (ℓπ, g = −∇ℓπ) at θ
+template <class T>
+int dn_target(Ctx<T>* c) {
+  if (c->target_kind == AHMC_TARGET_DENSE_GAUSS) {
+    int rc = dn_gemm(c, c->tparams, c->th, c->g, c->N);  // g = Pθ
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_d_coldot<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, c->th, c->g, c->lp, T(-0.5), (int)c->D, c->N);
+    HIPCHK(hipGetLastError());
+    return AHMC_OK;
+  }
+  // built-in family: the group kernel (it also writes a Unit/Diag ℓκ, overwritten by dn_velocity)
+  return launch_fill_caches_builtin(c);
+}
+
+template <class T>
+int dn_fill_caches(Ctx<T>* c) {
+  int rc = dn_ensure(c, 2);
+  if (rc) return rc;
+  rc = dn_target(c);
+  if (rc) return rc;
+  return dn_velocity(c);
+}
+
+// one leapfrog of every chain with its signed step es[c] (0 = idle)
+template <class T>
+int dn_step(Ctx<T>* c) {
+  T* V = c->dn_W + (size_t)DS_CUR_V * c->D * c->N;
+  hipLaunchKernelGGL((k_d_half<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r, c->g, c->dn_es, (int)c->D, c->N);
+  if (c->metric_kind == AHMC_METRIC_DENSE) {
+    int rc = dn_gemm(c, c->dn_minv, c->r, V, c->N);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r,
+                       c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V, (int)c->D, c->N);
+  }
+  hipLaunchKernelGGL((k_d_pos<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->th, V, c->dn_es, (int)c->D, c->N);
+  int rc = dn_target(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_d_half<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r, c->g, c->dn_es, (int)c->D, c->N);
+  return dn_velocity(c);
+}
+
+// fresh momenta of n_trans consecutive transitions (iterations c->iteration + k):
+// R_k = U⁻¹ Z_k (Dense; rand_momentum src/metric.jl:311-320) or Z_k ./ √M⁻¹; V_k = M⁻¹ R_k
+template <class T>
+int dn_momenta(Ctx<T>* c, int n_trans, T* R, T* V) {
+  const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
+  if (need > c->znorm_elems) {
+    if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
+    c->znorm = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->znorm), need * sizeof(T)));
+    c->znorm_elems = need;
+  }
+  KP<T> p = make_kp(c);
+  const int64_t pairs = ((c->D + 1) / 2) * c->N * (int64_t)n_trans;
+  const unsigned grid = (unsigned)std::min<int64_t>((pairs + 255) / 256, (int64_t)c->n_cu * 32);
+  hipLaunchKernelGGL((k_normals<T>), dim3(grid), dim3(256), 0, c->stream, p, c->znorm, n_trans);
+  HIPCHK(hipGetLastError());
+  const int64_t cols = (int64_t)n_trans * c->N;
+  if (c->metric_kind == AHMC_METRIC_DENSE) {
+    int rc = dn_gemm(c, c->dn_uinv, c->znorm, R, cols);
+    if (rc) return rc;
+    if (V) rc = dn_gemm(c, c->dn_minv, R, V, cols);
+    return rc;
+  }
+  const T* sq = c->metric_kind == AHMC_METRIC_DIAG ? c->sqrt_minv : nullptr;
+  hipLaunchKernelGGL((k_d_rdiag<T>), dim3((unsigned)((need + 255) / 256)), dim3(256), 0, c->stream, c->znorm, sq, c->minv_per_chain ? 1 : 0, R,
+                     (int)c->D, c->N, (int64_t)need);
+  if (V) {
+    for (int k = 0; k < n_trans; ++k)
+      hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, R + (size_t)k * c->D * c->N,
+                         c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V + (size_t)k * c->D * c->N, (int)c->D, c->N);
+  }
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+template <class T>
+int dn_check(Ctx<T>* c, const char* what, double refresh_alpha) {
+  if (c->target_kind == AHMC_TARGET_EXTERNAL)
+    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": DenseEuclideanMetric with AHMC_TARGET_EXTERNAL is not implemented");
+  if (c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
+    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the dense engine");
+  if (refresh_alpha != 0)
+    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": partial momentum refreshment is not implemented in the dense engine");
+  return AHMC_OK;
+}
+
+// set the dense metric: M⁻¹ (D,D) column-major; U = chol(M⁻¹).U and U⁻¹ on the host in double
+template <class T>
+int dn_set_metric(Ctx<T>* c, const T* minv_in) {
+  const int64_t D = c->D;
+  std::vector<T> hm((size_t)D * D);
+  HIPCHK(hipMemcpy(hm.data(), minv_in, sizeof(T) * D * D, hipMemcpyDefault));
+  std::vector<double> U((size_t)D * D, 0.0), Ui((size_t)D * D, 0.0);
+  for (int64_t j = 0; j < D; ++j) {  // upper Cholesky factor, UᵀU = M⁻¹ (src/metric.jl:104-109)
+    for (int64_t i = 0; i <= j; ++i) {
+      double s = (double)hm[i + j * D];
+      for (int64_t k = 0; k < i; ++k) s -= U[k + i * D] * U[k + j * D];
+      if (i == j) {
+        if (!(s > 0)) return fail(c, AHMC_ERR_ARGUMENT, "PosDefException: M⁻¹ is not positive definite");
+        U[i + j * D] = std::sqrt(s);
+      } else {
+        U[i + j * D] = s / U[i + i * D];
+      }
+    }
+  }
+  for (int64_t j = 0; j < D; ++j) {  // U⁻¹ (upper triangular) by back substitution on the unit vectors
+    for (int64_t i = j; i >= 0; --i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      for (int64_t k = i + 1; k <= j; ++k) s -= U[i + k * D] * Ui[k + j * D];
+      Ui[i + j * D] = s / U[i + i * D];
+    }
+  }
+  std::vector<T> hu((size_t)D * D);
+  for (size_t i = 0; i < hu.size(); ++i) hu[i] = (T)Ui[i];
+  if (!c->dn_minv) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_minv), sizeof(T) * D * D));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_uinv), sizeof(T) * D * D));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(c->dn_minv, hm.data(), sizeof(T) * D * D, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->dn_uinv, hu.data(), sizeof(T) * D * D, hipMemcpyHostToDevice));
+  c->metric_kind = AHMC_METRIC_DENSE;
+  c->minv_per_chain = false;
+  c->minv_n = D * D;
+  return AHMC_OK;
+}
+
+template <class T>
+int dn_refresh(Ctx<T>* c, double alpha) {
+  int rc = dn_check(c, "refresh_momentum", alpha);
+  if (rc) return rc;
+  rc = dn_ensure(c, 2);
+  if (rc) return rc;
+  rc = dn_momenta(c, 1, c->r, (T*)nullptr);
+  if (rc) return rc;
+  KP<T> p = make_kp(c);
+  hipLaunchKernelGGL((k_d_jitter<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, p);
+  return dn_fill_caches(c);
+}
+
+template <class T>
+int dn_leapfrog(Ctx<T>* c, int64_t n_steps) {
+  int rc = dn_check(c, "leapfrog", 0);
+  if (rc) return rc;
+  rc = dn_ensure(c, 2);
+  if (rc) return rc;
+  const int64_t n = n_steps < 0 ? -n_steps : n_steps;
+  hipLaunchKernelGGL((k_d_set<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_es, c->eps_nom, T(n_steps > 0 ? 1 : -1), c->N);
+  hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
+  for (int64_t i = 0; i < n; ++i) {
+    rc = dn_step(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
+  }
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+template <class T>
+int dn_hmc_transition(Ctx<T>* c, int64_t L, int sampler, double refresh_alpha, bool accum) {
+  int rc = dn_check(c, "hmc_transition", refresh_alpha);
+  if (rc) return rc;
+  if (sampler != AHMC_TS_ENDPOINT)
+    return fail(c, AHMC_ERR_UNSUPPORTED, "hmc_transition: the dense engine implements EndPointTS (static MultinomialTS is not implemented)");
+  rc = dn_ensure(c, 2);
+  if (rc) return rc;
+  rc = dn_momenta(c, 1, c->r, (T*)nullptr);  // refresh (src/sampler.jl:54-57)
+  if (rc) return rc;
+  rc = dn_fill_caches(c);
+  if (rc) return rc;
+  KP<T> p = make_kp(c);
+  p.L = L;
+  p.accum = accum ? 1 : 0;
+  DP<T> q = make_dp(c);
+  hipLaunchKernelGGL((k_d_hmc_begin<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+  for (int64_t i = 0; i < L; ++i) {
+    rc = dn_step(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
+  }
+  hipLaunchKernelGGL((k_d_hmc_end<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+  HIPCHK(hipGetLastError());
+  c->iteration += 1;
+  return AHMC_OK;
+}
+
+// n_trans NUTS transitions of every chain (asynchronous chains, see ahmc_dense.hpp)
+template <class T>
+int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha, bool accum,
+                       int n_trans, T* samples_dev) {
+  int rc = dn_check(c, "nuts_transition", refresh_alpha);
+  if (rc) return rc;
+  if (criterion != AHMC_TC_GENERALISED)
+    return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine implements GeneralisedNoUTurn only");
+  if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");
+  rc = dn_ensure(c, max_depth);
+  if (rc) return rc;
+  const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
+  if (need > c->dn_batch_elems) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->dn_RB) { HIPCHK(hipFree(c->dn_RB)); HIPCHK(hipFree(c->dn_VB)); }
+    c->dn_RB = c->dn_VB = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_RB), need * sizeof(T)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_VB), need * sizeof(T)));
+    c->dn_batch_elems = need;
+  }
+  rc = dn_momenta(c, n_trans, c->dn_RB, c->dn_VB);
+  if (rc) return rc;
+  KP<T> p = make_kp(c);
+  p.max_depth = max_depth;
+  p.delta_max = (T)delta_max;
+  p.criterion = criterion;
+  p.sampler = sampler;
+  p.accum = accum ? 1 : 0;
+  p.samples_out = samples_dev;
+  DP<T> q = make_dp(c);
+  q.n_trans = n_trans;
+  hipLaunchKernelGGL((k_d_tree_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, c->dn_es, c->dn_active, c->N);
+  hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);  // start of transition 0
+  HIPCHK(hipGetLastError());
+  // global steps until every chain has finished the batch; the counter is read every CHUNK steps
+  const int CHUNK = 32;
+  const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
+  for (int64_t done_steps = 0; done_steps < max_steps;) {
+    for (int s = 0; s < CHUNK; ++s) {
+      rc = dn_step(c);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+    }
+    done_steps += CHUNK;
+    int active = 0;
+    HIPCHK(hipMemcpyAsync(&active, c->dn_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->dn_global_steps += CHUNK;
+    if (active <= 0) break;
+  }
+  c->iteration += (uint64_t)n_trans;
+  return AHMC_OK;
+}

@@ -289,6 +289,103 @@ def test_multiwave_chains(hip, oracle, rng, D, target):
     assert np.mean(eg == eo) >= 0.95
 
 
+def _spd(D, rng, cond=4.0):
+    """a random symmetric positive-definite (D, D) matrix with a modest condition number"""
+    Q, _ = np.linalg.qr(rng.normal(size=(D, D)))
+    M = (Q * np.linspace(1.0, cond, D)) @ Q.T
+    return np.asfortranarray((M + M.T) / 2)
+
+
+def _dense_hamiltonian(D, N, rng, metric, target):
+    m = {"dense": lambda: A.DenseEuclideanMetric(_spd(D, rng)), "diag": lambda: make_metric("diag_chain", D, N, rng),
+         "unit": lambda: A.UnitEuclideanMetric((D, N))}[metric]()
+    t = A.DenseGaussian(_spd(D, rng, 3.0)) if target == "dense" else make_target(target, D, rng)
+    return A.Hamiltonian(m, t)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("D", [5, 64, 100, 200])
+def test_dense_phasepoint_leapfrog_refresh(hip, oracle, rng, dtype, D):
+    """DenseEuclideanMetric + dense Gaussian target on the MFMA path (src/hamiltonian.jl:60-68,179-184,
+    src/metric.jl:311-320): caches, step(lf, h, z, n) both directions, rand_momentum"""
+    N = 70  # not a multiple of the 64-column GEMM tile
+    h = _dense_hamiltonian(D, N, rng, "dense", "dense")
+    g, o = pair(hip, oracle, h, N, dtype, eps=0.05 + 0.05 * rng.random(N))
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th, r)
+    assert_points_close(g.phasepoint(), o.phasepoint(), dtype, "phasepoint")
+    for n in (5, -3):
+        for e in (g, o):
+            e.step(n)
+        assert_points_close(g.phasepoint(), o.phasepoint(), dtype, f"step({n})")
+    for e in (g, o):
+        e.refresh()
+    assert_points_close(g.phasepoint(), o.phasepoint(), dtype, "refresh")
+
+
+@pytest.mark.parametrize("metric,target", [("dense", "dense"), ("dense", "funnel"), ("dense", "iso"), ("diag", "dense"), ("unit", "dense")])
+def test_dense_transitions(hip, oracle, rng, metric, target):
+    """static HMC (EndPointTS) and NUTS (MultinomialTS / SliceTS + GeneralisedNoUTurn) through the
+    step-synchronous dense engine == the oracle's per-chain recursion"""
+    D, N = 24, 300
+    dtype = np.float64
+    h = _dense_hamiltonian(D, N, rng, metric, target)
+    lf = A.Leapfrog(np.full(N, 0.2 if target != "funnel" else 0.3))
+    g, o = pair(hip, oracle, h, N, dtype, seed=9, lf=lf)
+    th = 0.5 * rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+    kernels = [
+        A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(7))),
+        A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=7))),
+        A.HMCKernel(A.Trajectory(A.SliceTS, lf, A.GeneralisedNoUTurn(max_depth=6))),
+    ]
+    for k in kernels:
+        for it in range(3):
+            for e in (g, o):
+                e.transition(k)
+            sg, so = g.stats(), o.stats()
+            same = compare_transition_stats(sg, so, dtype, 0.99 if it == 0 else 0.5)
+            zg, zo = g.phasepoint(), o.phasepoint()
+            np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(zg.r[:, same], zo.r[:, same], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(zg.lp.gradient[:, same], zo.lp.gradient[:, same], rtol=1e-8, atol=1e-8)
+        if not isinstance(k.tau.termination_criterion, A.FixedNSteps):
+            assert sg["tree_depth"].max() >= 3
+        for e in (g, o):
+            e.set_position(o.phasepoint().theta)
+
+
+def test_dense_bulk_sample_and_stepsize_adaptation(hip, rng):
+    """ahmc_sample on the dense engine: batched asynchronous transitions == one at a time; dual
+    averaging drives the acceptance rate to δ; the draws have the target's covariance"""
+    D, N = 16, 2048
+    cov = _spd(D, rng, 5.0)
+    h = A.Hamiltonian(A.DenseEuclideanMetric(cov), A.DenseGaussian(np.asfortranarray(np.linalg.inv(cov))))
+    lf = A.Leapfrog(np.full(N, 0.1))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=8)))
+    th0 = rng.normal(size=(D, N))
+    a = A.Engine(h, N, rng=21, lib=hip); a.set_integrator(lf); a.set_position(th0)
+    b = A.Engine(h, N, rng=21, lib=hip); b.set_integrator(lf); b.set_position(th0)
+    a.run(k, 6, 0)
+    for _ in range(6):
+        b.transition(k)
+    np.testing.assert_array_equal(a.phasepoint().theta, b.phasepoint().theta)
+    np.testing.assert_array_equal(a.stats()["n_steps"], b.stats()["n_steps"])
+    # step-size adaptation + statistics (M⁻¹ = Σ makes the target isotropic for the sampler)
+    a.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+    a.run(k, 150, 150)
+    a.run(k, 40, 0)
+    acc = a.accum()
+    assert abs(np.mean(a.stats()["acceptance_rate"]) - 0.8) < 0.08
+    n = acc["n_transitions"] * N
+    mean = acc["sum_theta"].sum(axis=1) / n
+    var = acc["sumsq_theta"].sum(axis=1) / n - mean ** 2
+    assert np.abs(mean).max() < 0.05
+    np.testing.assert_allclose(var, np.diag(cov), rtol=0.08)
+
+
 def test_max_depth_and_single_leaf(hip, oracle, rng):
     """max_depth = 1 (one leaf) and a tiny step size that always hits max_depth"""
     D, N = 5, 64
