@@ -125,15 +125,16 @@ struct Ctx : CtxBase {
   T *dn_minv = nullptr, *dn_uinv = nullptr, *dn_W = nullptr, *dn_es = nullptr, *dn_RB = nullptr, *dn_VB = nullptr;
   DChain<T>* dn_S = nullptr;
   int* dn_active = nullptr;
+  int* dn_list = nullptr;
   size_t dn_slots = 0, dn_batch_elems = 0;
-  int64_t dn_global_steps = 0;
+  int64_t dn_global_steps = 0, dn_chain_steps = 0;
 
   ~Ctx() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active};
+                    dn_S, dn_active, dn_list};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -232,6 +233,7 @@ int check_builtin(Ctx<T>* c, const char* what) {
 template <class T>
 int launch_fill_caches_builtin(Ctx<T>* c) {
   KP<T> p = make_kp(c);
+  p.no_lk = c->metric_kind == AHMC_METRIC_DENSE ? 1 : 0;  // ℓκ = −½ rᵀM⁻¹r comes from the dense engine
   with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::fill_caches(c->G, c->E, group_grid(c), c->stream, p); });
   HIPCHK(hipGetLastError());
   return AHMC_OK;

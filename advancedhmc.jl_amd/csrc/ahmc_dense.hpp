@@ -40,14 +40,29 @@ template <> struct Mfma<float> {
   static __device__ __forceinline__ int row(int lane, int v) { return 4 * (lane >> 4) + v; }
 };
 
-constexpr int GB_M = 64, GB_N = 64, GB_K = 16, GB_PAD = 4;
+#ifndef AHMC_GB_PAD
+#define AHMC_GB_PAD 16
+#endif
+#ifndef AHMC_GB_P
+#define AHMC_GB_P 2
+#endif
+constexpr int GB_M = 64, GB_N = 64, GB_K = 16, GB_PAD = AHMC_GB_PAD;  // row stride 80 doubles: rows k, k+1 land on disjoint LDS banks
+constexpr int GB_P = AHMC_GB_P;
+// Measured (D = 512, f64, µs per GEMM at N = 512 / 2048 / 4096 / 8192 columns): P=1 43/45/62/103, P=2 38/40/58/99,
+// P=4 38/41/60/110; the padding makes no difference.  A lone wave issues one f64 16x16x4 MFMA per ≈61 ns and the
+// whole chip sustains 48.8 TFLOP/s on independent MFMAs (scripts/probe/mfma_rate.hip; spec 78.6): at N = 8192
+// this kernel runs at 43.5 TFLOP/s = 89 % of that, and a single workgroup's 32 k-steps × 16 MFMAs ≈ 38 µs is
+// the floor for small N.  // software pipeline depth: tiles t+1 .. t+P are in flight (registers) while tile t is multiplied
 
-// TRANS_A: use Aᵀ (A[k + i*D] instead of A[i + k*D]) — for the general (non-symmetric) U⁻¹ both
-// orientations are needed nowhere else, so only the plain form is instantiated today.
+// Pipeline: LDS holds tile t (buffer t&1); registers hold tiles t+1 … t+P-1 as they arrive and the
+// loads of tile t+P are issued before tile t is multiplied, so a lone workgroup on a CU (the tail of a
+// NUTS batch, when few chains are still running) still covers the ≈1-2 µs load latency with
+// P·16 MFMAs ≈ 1.7 µs of matrix work.  One barrier per tile.
 template <class T>
-__global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N) {
-  __shared__ T As[GB_K][GB_M + GB_PAD];
-  __shared__ T Bs[GB_K][GB_N + GB_PAD];
+__global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N,
+                                               const int* __restrict__ idx) {  // idx: optional list of the N columns (chains) to process
+  __shared__ T As[2][GB_K][GB_M + GB_PAD];
+  __shared__ T Bs[2][GB_K][GB_N + GB_PAD];
   using M = Mfma<T>;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int m0 = blockIdx.x * GB_M;
@@ -58,53 +73,58 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = typename M::acc_t{0, 0, 0, 0};
-  T ra[4], rb[4];
+  T ra[GB_P][4], rb[GB_P][4];
   const int ai = (tid & 31) * 2, ak = tid >> 5;  // A tile: rows ai, ai+1 of k-rows ak and ak+8
   const int bn = tid >> 2, bk = (tid & 3) * 4;   // X tile: column bn, k-rows bk..bk+3
-  auto load_tiles = [&](int k0) {
+  const int64_t bcol = n0 + bn < N ? (idx ? (int64_t)idx[n0 + bn] : n0 + bn) : -1;
+  const bool arow0 = m0 + ai < D, arow1 = m0 + ai + 1 < D;
+  const T* Ap = A + (m0 + ai);
+  const T* Xp = X + (bcol >= 0 ? bcol : 0) * (int64_t)D;
+  auto load_tile = [&](int k0, T (&a)[4], T (&b)[4]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int k = k0 + ak + 8 * q;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int i = m0 + ai + e;
-        ra[2 * q + e] = (k < D && i < D) ? A[i + (int64_t)k * D] : T(0);
-      }
+      a[2 * q + 0] = (k < D && arow0) ? Ap[(int64_t)k * D] : T(0);
+      a[2 * q + 1] = (k < D && arow1) ? Ap[(int64_t)k * D + 1] : T(0);
     }
-    const int64_t col = n0 + bn;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = k0 + bk + e;
-      rb[e] = (col < N && k < D) ? X[k + col * D] : T(0);
+      b[e] = (bcol >= 0 && k < D) ? Xp[k] : T(0);
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tile = [&](int buf, const T (&a)[4], const T (&b)[4]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) As[ak + 8 * q][ai + e] = ra[2 * q + e];
+      for (int e = 0; e < 2; ++e) As[buf][ak + 8 * q][ai + e] = a[2 * q + e];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Bs[bk + e][bn] = rb[e];
+    for (int e = 0; e < 4; ++e) Bs[buf][bk + e][bn] = b[e];
   };
-  load_tiles(0);
-  store_tiles();
-  __syncthreads();
-  for (int k0 = 0; k0 < D; k0 += GB_K) {
-    const bool more = k0 + GB_K < D;
-    if (more) load_tiles(k0 + GB_K);
+  const int nk = (D + GB_K - 1) / GB_K;
+  const int nk_round = (nk + GB_P - 1) / GB_P * GB_P;  // tiles past D are all zero: harmless to multiply
 #pragma unroll
-    for (int ks = 0; ks < GB_K / 4; ++ks) {
-      const int kq = ks * 4 + (lane >> 4), l16 = lane & 15;
-      const T a0 = As[kq][wm + l16], a1 = As[kq][wm + 16 + l16];
-      const T b0 = Bs[kq][wn + l16], b1 = Bs[kq][wn + 16 + l16];
-      acc[0][0] = M::mma(a0, b0, acc[0][0]);
-      acc[0][1] = M::mma(a0, b1, acc[0][1]);
-      acc[1][0] = M::mma(a1, b0, acc[1][0]);
-      acc[1][1] = M::mma(a1, b1, acc[1][1]);
-    }
-    __syncthreads();
-    if (more) {
-      store_tiles();
+  for (int s = 0; s < GB_P; ++s) load_tile(s * GB_K, ra[s], rb[s]);
+  store_tile(0, ra[0], rb[0]);
+  __syncthreads();
+  for (int kt = 0; kt < nk_round; kt += GB_P) {
+#pragma unroll
+    for (int s = 0; s < GB_P; ++s) {
+      const int t = kt + s;  // tile t sits in LDS buffer s & 1 (GB_P is even); registers s are free again
+      load_tile((t + GB_P) * GB_K, ra[s], rb[s]);
+      const int buf = (GB_P % 2 == 0) ? (s & 1) : (t & 1);
+#pragma unroll
+      for (int ks = 0; ks < GB_K / 4; ++ks) {
+        const int kq = ks * 4 + (lane >> 4), l16 = lane & 15;
+        const T a0 = As[buf][kq][wm + l16], a1 = As[buf][kq][wm + 16 + l16];
+        const T b0 = Bs[buf][kq][wn + l16], b1 = Bs[buf][kq][wn + 16 + l16];
+        acc[0][0] = M::mma(a0, b0, acc[0][0]);
+        acc[0][1] = M::mma(a0, b1, acc[0][1]);
+        acc[1][0] = M::mma(a1, b0, acc[1][0]);
+        acc[1][1] = M::mma(a1, b1, acc[1][1]);
+      }
+      // tile t+1 → the other buffer (last read while multiplying tile t-1, i.e. before the previous barrier)
+      store_tile(buf ^ 1, ra[(s + 1) % GB_P], rb[(s + 1) % GB_P]);
       __syncthreads();
     }
   }
@@ -112,48 +132,86 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
-      const int64_t col = n0 + wn + tj * 16 + (lane & 15);
+      const int64_t j = n0 + wn + tj * 16 + (lane & 15);
+      const int64_t col = j < N ? (idx ? (int64_t)idx[j] : j) : -1;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = m0 + wm + ti * 16 + M::row(lane, v);
-        if (row < D && col < N) Y[row + col * D] = acc[ti][tj][v];
+        if (row < D && col >= 0) Y[row + col * D] = acc[ti][tj][v];
       }
     }
 }
 
 // out[c] = sanitize(scale · Σ_d a[d,c] b[d,c]); one wave per chain
 template <class T>
-__global__ __launch_bounds__(256) void k_d_coldot(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, T scale, int D, int64_t N) {
+__global__ __launch_bounds__(256) void k_d_coldot(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, T scale, int D, int64_t N,
+                                                  const int* __restrict__ idx) {
   const int lane = threadIdx.x & 63;
-  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= N) return;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  const int64_t c = idx ? idx[j] : j;
   T s[2] = {0, 0};
   for (int d = lane; d < D; d += 64) s[0] += a[c * D + d] * b[c * D + d];
   wave_allsum2<64>(s[0], s[1]);
   if (lane == 0) out[c] = sanitize(scale * s[0]);
 }
 
-// r[:,c] −= es[c]/2 · g[:,c]  (es = signed step of the chain this global step; 0 = chain idle)
+// First half of a leapfrog for every listed chain (src/integrator.jl:231-237):
+//   r ← r − ϵ/2 g ;  v ← M⁻¹r   (dense: v ← v − ϵ/2 w with w = M⁻¹g carried along, so no GEMM) ;  θ ← θ + ϵ v
 template <class T>
-__global__ __launch_bounds__(256) void k_d_half(T* __restrict__ r, const T* __restrict__ g, const T* __restrict__ es, int D, int64_t N) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_d_pre(T* __restrict__ th, T* __restrict__ r, const T* __restrict__ g, T* __restrict__ v, const T* __restrict__ w,
+                                               const T* __restrict__ minv, int per_chain, const T* __restrict__ es, int D, int64_t N,
+                                               const int* __restrict__ list) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)D * N) return;
+  if (list) idx = (int64_t)list[idx / D] * D + idx % D;
   const T e = es[idx / D];
-  if (e != T(0)) r[idx] = r[idx] - e / 2 * g[idx];
+  if (e == T(0)) return;
+  const T rh = r[idx] - e / 2 * g[idx];
+  T vh;
+  if (w) vh = v[idx] - e / 2 * w[idx];
+  else vh = minv ? minv[per_chain ? idx : idx % D] * rh : rh;
+  r[idx] = rh;
+  v[idx] = vh;
+  th[idx] = th[idx] + e * vh;
 }
-// θ[:,c] += es[c] · v[:,c]
+// Second half, one wave per chain (src/integrator.jl:238-243): r ← r − ϵ/2 g′ ; v likewise ; ℓκ = −½ r·v ;
+// dense target: ℓπ = −½ θ·g′ (g′ = Pθ from the GEMM)
 template <class T>
-__global__ __launch_bounds__(256) void k_d_pos(T* __restrict__ th, const T* __restrict__ v, const T* __restrict__ es, int D, int64_t N) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)D * N) return;
-  const T e = es[idx / D];
-  if (e != T(0)) th[idx] = th[idx] + e * v[idx];
+__global__ __launch_bounds__(256) void k_d_post(const T* __restrict__ th, T* __restrict__ r, const T* __restrict__ g, T* __restrict__ v,
+                                                const T* __restrict__ w, const T* __restrict__ minv, int per_chain, const T* __restrict__ es,
+                                                T* __restrict__ lp, T* __restrict__ lk, int dense_target, int D, int64_t N,
+                                                const int* __restrict__ list) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  const int64_t c = list ? list[j] : j;
+  const T e = es[c];
+  T s[2] = {0, 0};
+  for (int d = lane; d < D; d += 64) {
+    const int64_t i = c * D + d;
+    const T gd = g[i];
+    T rn = r[i], vn;
+    if (e != T(0)) rn = rn - e / 2 * gd;
+    if (w) vn = e != T(0) ? v[i] - e / 2 * w[i] : v[i];
+    else vn = minv ? minv[per_chain ? i : d] * rn : rn;
+    if (e != T(0) || !w) { r[i] = rn; v[i] = vn; }
+    s[0] += rn * vn;
+    s[1] += th[i] * gd;
+  }
+  wave_allsum2<64>(s[0], s[1]);
+  if (lane == 0) {
+    lk[c] = sanitize(-s[0] / 2);
+    if (dense_target) lp[c] = sanitize(-s[1] / 2);
+  }
 }
 // v = M⁻¹ ⊙ r for Unit / Diag metrics used together with the dense target (minv may be null)
 template <class T>
-__global__ __launch_bounds__(256) void k_d_vdiag(const T* __restrict__ r, const T* __restrict__ minv, int per_chain, T* __restrict__ v, int D, int64_t N) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_d_vdiag(const T* __restrict__ r, const T* __restrict__ minv, int per_chain, T* __restrict__ v, int D, int64_t N,
+                                                 const int* __restrict__ list) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)D * N) return;
+  if (list) idx = (int64_t)list[idx / D] * D + idx % D;
   v[idx] = minv ? minv[per_chain ? idx : idx % D] * r[idx] : r[idx];
 }
 // r = z ./ sqrtM⁻¹ (Diag) or r = z (Unit), n vectors of the batch at once
@@ -190,14 +248,15 @@ __global__ __launch_bounds__(256) void k_d_freeze(const T* __restrict__ lp, cons
 // Per-chain tree state of the dense engine
 // ------------------------------------------------------------------------------------------------
 constexpr int DN_MAXLEV = 16;  // pending levels = max_depth − 1
-enum { DPH_IDLE = 0, DPH_START = 1, DPH_RUN = 2 };
+enum { DPH_IDLE = 0, DPH_START = 1, DPH_RUN = 2, DPH_WARM = 3 };  // WARM: one motionless step that computes W = M⁻¹g at the start point
 // vector slots: T[slot][N][D]
 enum {
-  DS_CUR_V = 0,
+  DS_CUR_V = 0, DS_CUR_W,  // v = M⁻¹r and w = M⁻¹g of the moving edge (w: dense metric only)
+  DS_OTH_W,
   DS_OTH_TH, DS_OTH_R, DS_OTH_G, DS_OTH_V,
   DS_TREE_RHO,
   DS_CAND_TH, DS_CAND_R, DS_CAND_G,
-  DS_SUB_RHO, DS_SUB_VF, DS_SUB_CTH, DS_SUB_CR, DS_SUB_CG,
+  DS_SUB_RHO,
   DS_START_TH, DS_START_R, DS_START_G,  // static HMC: the start point (for rejected proposals)
   DS_FIXED,
   DS_PER_LEVEL = 5  // ρ, v_first, candidate θ, r, g
@@ -223,7 +282,20 @@ struct DP {  // dense-engine arguments (beside KP)
   const T* VB;     // (n_trans, N, D) M⁻¹ · RB
   int n_trans;
   int* n_active;   // device counter: chains that have not finished the batch
+  const int* list; // chains still running (compacted every few steps), or null = all
+  int64_t n_list;
+  int dense_metric;
 };
+
+// stream compaction of the running chains: out = { c in in[0..n) : phase(c) != idle }
+template <class T>
+__global__ __launch_bounds__(256) void k_d_compact(const DChain<T>* __restrict__ S, const int* __restrict__ in, int64_t n, int* __restrict__ out,
+                                                   int* __restrict__ count) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int c = in ? in[j] : (int)j;
+  if (S[c].phase != DPH_IDLE) out[atomicAdd(count, 1)] = c;
+}
 
 template <class T>
 __device__ __forceinline__ T* dslot(const DP<T>& q, const KP<T>& p, int slot, int64_t c) {
@@ -241,8 +313,9 @@ __device__ __forceinline__ void vcopy(T* __restrict__ dst, const T* __restrict__
 template <class T>
 __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
   const int lane = threadIdx.x & 63;
-  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= p.N) return;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= q.n_list) return;
+  const int64_t c = q.list ? q.list[j] : j;
   DChain<T>& S = q.S[c];
   if (S.phase == DPH_IDLE) return;
   const int D = p.D;
@@ -261,6 +334,18 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
   };
   // scalars are uniform across the wave: every lane computes them; lane 0 writes them back
   int phase = S.phase, it = S.it;
+  if (phase == DPH_WARM) {
+    // the motionless step has produced W = M⁻¹g at the start point: remember it for the other edge
+    // too and let the first leapfrog go
+    const T* Wc = dslot(q, p, DS_CUR_W, c);
+    T* o_w = dslot(q, p, DS_OTH_W, c);
+    for (int d = lane; d < D; d += 64) o_w[d] = Wc[d];
+    if (lane == 0) {
+      S.phase = DPH_RUN;
+      q.es[c] = S.v < 0 ? -S.eps : S.eps;
+    }
+    return;
+  }
   bool start = phase == DPH_START;
   T lp_start = start ? p.lp()[c] : T(0);  // ℓπ(θ) of the point the next transition starts from
   if (!start) {
@@ -284,19 +369,14 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
       sub_term = !(-H0 < p.delta_max + ne);
     }
     bool numerical = S.numerical != 0 || sub_term;
+    // The subtree being assembled lives only inside this call, so its vectors are VIEWS: a fresh leaf's
+    // ρ, v_first and candidate are the moving edge itself; after a merge ρ is in the SUB_RHO slot and
+    // v_first / the candidate may point into a pending level.  Data is copied only when it must
+    // outlive the call (park, tree-level candidate).
     T* s_rho = dslot(q, p, DS_SUB_RHO, c);
-    T* s_vf = dslot(q, p, DS_SUB_VF, c);
-    T* s_cth = dslot(q, p, DS_SUB_CTH, c);
-    T* s_cr = dslot(q, p, DS_SUB_CR, c);
-    T* s_cg = dslot(q, p, DS_SUB_CG, c);
-    for (int d = lane; d < D; d += 64) {
-      const T rd = r[d];
-      s_rho[d] = rd;
-      s_vf[d] = V[d];
-      s_cth[d] = th[d];
-      s_cr[d] = rd;
-      s_cg[d] = g[d];
-    }
+    const T* rho_v = r;
+    const T* vf_v = V;
+    const T *cth_v = th, *cr_v = r, *cg_v = g;
     T sub_lp = lp, sub_lk = lk;
     // ---- merges: one per trailing zero bit of `leaf` (:649-673) ----
     const int nm = __builtin_ctz((uint32_t)leaf);
@@ -315,14 +395,9 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
         keep_first = w_new < w_p + (T)ds.randexp();
       }
       if (keep_first) {
-        const T* p_cth = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 2, c);
-        const T* p_cr = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 3, c);
-        const T* p_cg = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 4, c);
-        for (int d = lane; d < D; d += 64) {
-          s_cth[d] = p_cth[d];
-          s_cr[d] = p_cr[d];
-          s_cg[d] = p_cg[d];
-        }
+        cth_v = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 2, c);
+        cr_v = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 3, c);
+        cg_v = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 4, c);
         sub_lp = S.plp[lvl];
         sub_lk = S.plk[lvl];
       }
@@ -334,13 +409,13 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
       // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
       T dots[2] = {0, 0};
       for (int d = lane; d < D; d += 64) {
-        const T rho = p_rho[d] + s_rho[d];
-        const T vf = p_vf[d];
-        dots[0] += rho * vf;
+        const T rho = p_rho[d] + rho_v[d];
+        dots[0] += rho * p_vf[d];
         dots[1] += rho * V[d];
         s_rho[d] = rho;
-        s_vf[d] = vf;
       }
+      rho_v = s_rho;
+      vf_v = p_vf;
       wave_allsum2<64>(dots[0], dots[1]);
       sub_term = (dots[0] <= 0) || (dots[1] <= 0);
       merged = lvl + 1;
@@ -365,11 +440,11 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
       T* p_cr = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 3, c);
       T* p_cg = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 4, c);
       for (int d = lane; d < D; d += 64) {
-        p_rho[d] = s_rho[d];
-        p_vf[d] = s_vf[d];
-        p_cth[d] = s_cth[d];
-        p_cr[d] = s_cr[d];
-        p_cg[d] = s_cg[d];
+        p_rho[d] = rho_v[d];
+        p_vf[d] = vf_v[d];
+        p_cth[d] = cth_v[d];
+        p_cr[d] = cr_v[d];
+        p_cg[d] = cg_v[d];
       }
       if (lane == 0) {
         S.pw[nm] = w_c;
@@ -400,9 +475,9 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
         T* c_r = dslot(q, p, DS_CAND_R, c);
         T* c_g = dslot(q, p, DS_CAND_G, c);
         for (int d = lane; d < D; d += 64) {
-          c_th[d] = s_cth[d];
-          c_r[d] = s_cr[d];
-          c_g[d] = s_cg[d];
+          c_th[d] = cth_v[d];
+          c_r[d] = cr_v[d];
+          c_g[d] = cg_v[d];
         }
         cand_lp = sub_lp;
         cand_lk = sub_lk;
@@ -419,7 +494,7 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
       const T* o_v = dslot(q, p, DS_OTH_V, c);
       T dots[2] = {0, 0};
       for (int d = lane; d < D; d += 64) {
-        const T rho = t_rho[d] + s_rho[d];
+        const T rho = t_rho[d] + rho_v[d];
         dots[0] += rho * V[d];
         dots[1] += rho * o_v[d];
         t_rho[d] = rho;
@@ -437,12 +512,15 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
         T* o_r = dslot(q, p, DS_OTH_R, c);
         T* o_g = dslot(q, p, DS_OTH_G, c);
         T* o_v = dslot(q, p, DS_OTH_V, c);
+        T* o_w = dslot(q, p, DS_OTH_W, c);
+        T* Wc = dslot(q, p, DS_CUR_W, c);
         for (int d = lane; d < D; d += 64) {
           T t;
           t = o_th[d]; o_th[d] = th[d]; th[d] = t;
           t = o_r[d]; o_r[d] = r[d]; r[d] = t;
           t = o_g[d]; o_g[d] = g[d]; g[d] = t;
           t = o_v[d]; o_v[d] = V[d]; V[d] = t;
+          if (q.dense_metric) { t = o_w[d]; o_w[d] = Wc[d]; Wc[d] = t; }
         }
       }
       if (lane == 0) {
@@ -553,8 +631,8 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
       S.v = vleft ? -1 : 1;
       S.k = ds.k;
       S.it = it;
-      S.phase = DPH_RUN;
-      q.es[c] = vleft ? -eps : eps;
+      S.phase = q.dense_metric ? DPH_WARM : DPH_RUN;
+      q.es[c] = q.dense_metric ? T(0) : (vleft ? -eps : eps);
     }
   }
 }

@@ -8,9 +8,10 @@ bool dense_engine(const Ctx<T>* c) {
 }
 
 template <class T>
-int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols) {
+int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* list = nullptr) {
+  if (ncols <= 0) return AHMC_OK;
   dim3 grid((unsigned)((c->D + GB_M - 1) / GB_M), (unsigned)((ncols + GB_N - 1) / GB_N));
-  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols);
+  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -25,6 +26,9 @@ DP<T> make_dp(Ctx<T>* c) {
   q.VB = c->dn_VB;
   q.n_trans = 1;
   q.n_active = c->dn_active;
+  q.list = nullptr;
+  q.n_list = c->N;
+  q.dense_metric = c->metric_kind == AHMC_METRIC_DENSE ? 1 : 0;
   return q;
 }
 
@@ -44,39 +48,44 @@ int dn_ensure(Ctx<T>* c, int max_depth) {
     HIPCHK(hipMemsetAsync(c->dn_S, 0, (size_t)c->N * sizeof(DChain<T>), c->stream));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_es), (size_t)c->N * sizeof(T)));
     HIPCHK(hipMemsetAsync(c->dn_es, 0, (size_t)c->N * sizeof(T), c->stream));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), 2 * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_list), 2 * (size_t)c->N * sizeof(int)));
   }
   return AHMC_OK;
 }
 
 template <class T>
-unsigned dn_grid_elems(Ctx<T>* c) { return (unsigned)(((int64_t)c->D * c->N + 255) / 256); }
+unsigned dn_grid_elems(Ctx<T>* c, int64_t n = -1) { return (unsigned)(((int64_t)c->D * (n < 0 ? c->N : n) + 255) / 256); }
 template <class T>
-unsigned dn_grid_chains(Ctx<T>* c) { return (unsigned)((c->N + 3) / 4); }  // one wave per chain, 4 per block
+unsigned dn_grid_chains(Ctx<T>* c, int64_t n = -1) { return (unsigned)(((n < 0 ? c->N : n) + 3) / 4); }  // one wave per chain, 4 per block
 
 // v = ∂H∂r(r) into the CUR_V slot, ℓκ = −½ r·v (src/hamiltonian.jl:50-68,155-184)
 template <class T>
-int dn_velocity(Ctx<T>* c) {
+int dn_velocity(Ctx<T>* c, const int* list = nullptr, int64_t n = -1) {
+  if (n < 0) n = c->N;
+  if (n == 0) return AHMC_OK;
   T* V = c->dn_W + (size_t)DS_CUR_V * c->D * c->N;
   if (c->metric_kind == AHMC_METRIC_DENSE) {
-    int rc = dn_gemm(c, c->dn_minv, c->r, V, c->N);
+    int rc = dn_gemm(c, c->dn_minv, c->r, V, n, list);
     if (rc) return rc;
   } else {
-    hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r,
-                       c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V, (int)c->D, c->N);
+    hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c, n)), dim3(256), 0, c->stream, c->r,
+                       c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V, (int)c->D, n, list);
   }
-  hipLaunchKernelGGL((k_d_coldot<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, c->r, V, c->lk, T(-0.5), (int)c->D, c->N);
+  hipLaunchKernelGGL((k_d_coldot<T>), dim3(dn_grid_chains(c, n)), dim3(256), 0, c->stream, c->r, V, c->lk, T(-0.5), (int)c->D, n, list);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
 
 // (ℓπ, g = −∇ℓπ) at θ
 template <class T>
-int dn_target(Ctx<T>* c) {
+int dn_target(Ctx<T>* c, const int* list = nullptr, int64_t n = -1) {
+  if (n < 0) n = c->N;
+  if (n == 0) return AHMC_OK;
   if (c->target_kind == AHMC_TARGET_DENSE_GAUSS) {
-    int rc = dn_gemm(c, c->tparams, c->th, c->g, c->N);  // g = Pθ
+    int rc = dn_gemm(c, c->tparams, c->th, c->g, n, list);  // g = Pθ
     if (rc) return rc;
-    hipLaunchKernelGGL((k_d_coldot<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, c->th, c->g, c->lp, T(-0.5), (int)c->D, c->N);
+    hipLaunchKernelGGL((k_d_coldot<T>), dim3(dn_grid_chains(c, n)), dim3(256), 0, c->stream, c->th, c->g, c->lp, T(-0.5), (int)c->D, n, list);
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   }
@@ -93,23 +102,39 @@ int dn_fill_caches(Ctx<T>* c) {
   return dn_velocity(c);
 }
 
-// one leapfrog of every chain with its signed step es[c] (0 = idle)
+// W = M⁻¹g of the current points (dense metric): what the recurrence of dn_step starts from
 template <class T>
-int dn_step(Ctx<T>* c) {
+int dn_prepare_w(Ctx<T>* c) {
+  if (c->metric_kind != AHMC_METRIC_DENSE) return AHMC_OK;
+  return dn_gemm(c, c->dn_minv, c->g, c->dn_W + (size_t)DS_CUR_W * c->D * c->N, c->N);
+}
+
+// One leapfrog of every listed chain with its signed step es[c] (0 = motionless: caches only).
+// Dense metric: v = M⁻¹r is carried by the recurrence v ← v − ϵ/2·w, w = M⁻¹g (linear in r), so a
+// step costs TWO D×D products — g′ = Pθ′ and w′ = M⁻¹g′ — not three (M⁻¹r twice + Pθ).
+template <class T>
+int dn_step(Ctx<T>* c, const int* list = nullptr, int64_t n = -1) {
+  if (n < 0) n = c->N;
+  if (n == 0) return AHMC_OK;
+  const bool dm = c->metric_kind == AHMC_METRIC_DENSE;
   T* V = c->dn_W + (size_t)DS_CUR_V * c->D * c->N;
-  hipLaunchKernelGGL((k_d_half<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r, c->g, c->dn_es, (int)c->D, c->N);
-  if (c->metric_kind == AHMC_METRIC_DENSE) {
-    int rc = dn_gemm(c, c->dn_minv, c->r, V, c->N);
-    if (rc) return rc;
-  } else {
-    hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r,
-                       c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V, (int)c->D, c->N);
-  }
-  hipLaunchKernelGGL((k_d_pos<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->th, V, c->dn_es, (int)c->D, c->N);
-  int rc = dn_target(c);
+  T* W = dm ? c->dn_W + (size_t)DS_CUR_W * c->D * c->N : nullptr;
+  const T* minv = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
+  const int pc = c->minv_per_chain ? 1 : 0;
+  hipLaunchKernelGGL((k_d_pre<T>), dim3(dn_grid_elems(c, n)), dim3(256), 0, c->stream, c->th, c->r, c->g, V, W, minv, pc, c->dn_es, (int)c->D, n, list);
+  int rc;
+  const bool dt = c->target_kind == AHMC_TARGET_DENSE_GAUSS;
+  if (dt) rc = dn_gemm(c, c->tparams, c->th, c->g, n, list);  // g′ = Pθ′
+  else rc = launch_fill_caches_builtin(c);                    // built-in family: (ℓπ, g′) by the group kernel
   if (rc) return rc;
-  hipLaunchKernelGGL((k_d_half<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r, c->g, c->dn_es, (int)c->D, c->N);
-  return dn_velocity(c);
+  if (dm) {
+    rc = dn_gemm(c, c->dn_minv, c->g, W, n, list);  // w′ = M⁻¹g′
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL((k_d_post<T>), dim3(dn_grid_chains(c, n)), dim3(256), 0, c->stream, c->th, c->r, c->g, V, W, minv, pc, c->dn_es, c->lp, c->lk,
+                     dt ? 1 : 0, (int)c->D, n, list);
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
 }
 
 // fresh momenta of n_trans consecutive transitions (iterations c->iteration + k):
@@ -141,7 +166,8 @@ int dn_momenta(Ctx<T>* c, int n_trans, T* R, T* V) {
   if (V) {
     for (int k = 0; k < n_trans; ++k)
       hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, R + (size_t)k * c->D * c->N,
-                         c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V + (size_t)k * c->D * c->N, (int)c->D, c->N);
+                         c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr, c->minv_per_chain ? 1 : 0, V + (size_t)k * c->D * c->N, (int)c->D, c->N,
+                         (const int*)nullptr);
   }
   HIPCHK(hipGetLastError());
   return AHMC_OK;
@@ -219,6 +245,10 @@ int dn_leapfrog(Ctx<T>* c, int64_t n_steps) {
   rc = dn_ensure(c, 2);
   if (rc) return rc;
   const int64_t n = n_steps < 0 ? -n_steps : n_steps;
+  rc = dn_velocity(c);  // v = M⁻¹r of the point as it is now (the slot may hold another edge's)
+  if (rc) return rc;
+  rc = dn_prepare_w(c);
+  if (rc) return rc;
   hipLaunchKernelGGL((k_d_set<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_es, c->eps_nom, T(n_steps > 0 ? 1 : -1), c->N);
   hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
   for (int64_t i = 0; i < n; ++i) {
@@ -246,6 +276,8 @@ int dn_hmc_transition(Ctx<T>* c, int64_t L, int sampler, double refresh_alpha, b
   p.L = L;
   p.accum = accum ? 1 : 0;
   DP<T> q = make_dp(c);
+  rc = dn_prepare_w(c);
+  if (rc) return rc;
   hipLaunchKernelGGL((k_d_hmc_begin<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
   for (int64_t i = 0; i < L; ++i) {
     rc = dn_step(c);
@@ -292,22 +324,38 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   hipLaunchKernelGGL((k_d_tree_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, c->dn_es, c->dn_active, c->N);
   hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);  // start of transition 0
   HIPCHK(hipGetLastError());
-  // global steps until every chain has finished the batch; the counter is read every CHUNK steps
-  const int CHUNK = 32;
+  // global steps until every chain has finished the batch.  Every CHUNK steps the list of chains
+  // still running is compacted and its length read back, so the tail of the batch (few chains with
+  // long trees left) costs GEMMs over those chains only.
+  const int CHUNK = 16;
   const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
-  for (int64_t done_steps = 0; done_steps < max_steps;) {
+  const int* list = nullptr;
+  int64_t n_list = c->N;
+  int pp = 0;
+  for (int64_t done_steps = 0; done_steps < max_steps && n_list > 0;) {
+    q.list = list;
+    q.n_list = n_list;
     for (int s = 0; s < CHUNK; ++s) {
-      rc = dn_step(c);
+      rc = dn_step(c, list, n_list);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+      hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c, n_list)), dim3(256), 0, c->stream, p, q);
     }
     done_steps += CHUNK;
-    int active = 0;
-    HIPCHK(hipMemcpyAsync(&active, c->dn_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     c->dn_global_steps += CHUNK;
-    if (active <= 0) break;
+    int* out = c->dn_list + (size_t)pp * c->N;
+    int* cnt = c->dn_active + 1;
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL((k_d_compact<T>), dim3((unsigned)((n_list + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, list, n_list, out, cnt);
+    int active = 0;
+    HIPCHK(hipMemcpyAsync(&active, cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    list = out;
+    n_list = active;
+    pp ^= 1;
+    c->dn_chain_steps += (int64_t)CHUNK * q.n_list;
   }
+  static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[ahmc] dense NUTS batch of %d: %lld global steps so far, %lld chain-slots stepped\n", n_trans, (long long)c->dn_global_steps, (long long)c->dn_chain_steps);
   c->iteration += (uint64_t)n_trans;
   return AHMC_OK;
 }

@@ -52,6 +52,7 @@ struct KP {
   // rng
   uint32_t k0, k1, chain_offset, chain_stride, iteration;
   int accum;  // accumulate Σn_steps, Σθ, Σθ² for this (kept) transition
+  int no_lk;  // k_fill_caches: leave ℓκ alone (dense metric: the dense engine computes it)
   T refresh_alpha;
   // NUTS
   int max_depth;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(G > 256 ? G : 256) void k_fill_caches(KP<T> p) {
   store_vec<T, E>(z.g, p.g(), c * p.D, d0, p.D);
   if (lane == 0) {
     p.lp()[c] = z.lp;
-    p.lk()[c] = z.lk;
+    if (!p.no_lk) p.lk()[c] = z.lk;
   }
 }
 
