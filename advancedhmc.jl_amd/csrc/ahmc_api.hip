@@ -458,6 +458,12 @@ int64_t nuts_batch(Ctx<T>* c) {
   // batch * D * N elements, kept under 4 GiB
   static const int batch_env = getenv("AHMC_NUTS_BATCH") ? atoi(getenv("AHMC_NUTS_BATCH")) : 0;
   if (batch_env > 0) return batch_env;
+  if (dense_engine(c)) {
+    // dense engine: chains run asynchronously through the batch and only its end has idle chains, so longer
+    // is better; three (batch, D, N) arrays (normals, momenta, M⁻¹·momenta) kept under 8 GiB
+    const int64_t capd = (int64_t)(8ull << 30) / (int64_t)(3 * sizeof(T) * c->D * c->N);
+    return std::max<int64_t>(1, std::min<int64_t>(64, capd));
+  }
   const int64_t cap = (int64_t)(4ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
   return std::max<int64_t>(1, std::min<int64_t>(32, cap));
 }

@@ -10,7 +10,17 @@ bool dense_engine(const Ctx<T>* c) {
 template <class T>
 int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* list = nullptr) {
   if (ncols <= 0) return AHMC_OK;
-  dim3 grid((unsigned)((c->D + GB_M - 1) / GB_M), (unsigned)((ncols + GB_N - 1) / GB_N));
+  // few columns: the 64×16-tile kernel puts 4× as many workgroups on the chip (same arithmetic per column,
+  // so results do not depend on which kernel ran)
+  const int64_t row_blocks = (c->D + GB_M - 1) / GB_M;
+  static const int64_t small_below = getenv("AHMC_GEMM_SMALL_BELOW") ? atoll(getenv("AHMC_GEMM_SMALL_BELOW")) : 1;  // measured D=512: N=512 22 vs 38 µs, N=2048 38 vs 40, N=4096 67 vs 59
+  if (row_blocks * ((ncols + GB_N - 1) / GB_N) < small_below * c->n_cu) {
+    dim3 grid((unsigned)row_blocks, (unsigned)((ncols + 15) / 16));
+    hipLaunchKernelGGL((k_dgemm_small<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list);
+    HIPCHK(hipGetLastError());
+    return AHMC_OK;
+  }
+  dim3 grid((unsigned)row_blocks, (unsigned)((ncols + GB_N - 1) / GB_N));
   hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
