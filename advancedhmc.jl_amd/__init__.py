@@ -11,5 +11,7 @@ from .api import *  # noqa: F401,F403
 from .api import (Engine, PhiloxRNG, sample, find_good_stepsize, stan_windows, EBFMI, renew, energy, neg_energy)
 from .build import build_hip_library  # noqa: E402
 from . import shard  # noqa: E402,F401
+from . import diagnostics  # noqa: E402,F401
+from .diagnostics import ess, bundle_samples  # noqa: E402,F401
 
 __version__ = "0.1.0"

@@ -116,8 +116,10 @@ def main():
     ap.add_argument("--adapt", type=int, default=200, help="untimed Stan adaptation transitions")
     ap.add_argument("--seed", type=int, default=0x5EED0002)
     ap.add_argument("--cpu-chains", type=int, default=0, help="0 = 128 per host core, capped at --chains")
-    ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--cpu-steps", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ess", type=int, default=0, help="after the timed region: K more transitions with the draws kept in HBM, "
+                    "ESS/sec (min over dimensions, Geyer estimator, 256-chain subset) reported under config.ess")
     args = ap.parse_args()
 
     import torch
@@ -167,6 +169,26 @@ def main():
 
     acc = eng.accum(moments=True)
     n_leap = acc["total_n_steps"]
+    n_launches = max(1, eng.info("nuts_launches") - launches0)
+    nuts_ns = eng.info("nuts_kernel_ns") - kns0
+    ess_info = None
+    if args.ess > 0 and rank == 0:
+        # ESS/sec (BASELINE.json's secondary metric): draws (K, N, D) written by k_nuts straight into HBM
+        from ahmc_amd.diagnostics import ess as ess_fn
+
+        draws = torch.empty((args.ess, N, D), dtype=torch.float64, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.run(kernel, args.ess, 0, samples_out=draws.data_ptr())
+        eng.sync()
+        dt_ess = time.perf_counter() - t1
+        sub = draws[:, :256, :].cpu().numpy()                      # (K, 256 chains, D)
+        e = ess_fn(sub, axis=0)                                    # (256, D) per chain and dimension
+        per_chain = e.mean(axis=0)                                 # mean over the subset, per dimension
+        ess_info = {"draws_per_chain": args.ess, "seconds": dt_ess, "min_over_dims_ess_per_chain": float(per_chain.min()),
+                    "ess_per_sec": float(per_chain.min() * N * world / dt_ess),
+                    "estimator": "Geyer initial monotone sequence on FFT autocorrelation, per chain, 256-chain subset"}
+        del draws
     tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
     tn = torch.tensor([float(n_leap), float(acc["n_divergent"])], dtype=torch.float64, device=f"cuda:{local_rank}")
     # per-dimension pooled moments of this shard; the final gather over RCCL —
@@ -184,8 +206,7 @@ def main():
 
     if rank == 0:
         B_lf = algorithmic_bytes_per_leapfrog(D, True, 8)
-        n_launches = max(1, eng.info("nuts_launches") - launches0)
-        per_launch_s = (eng.info("nuts_kernel_ns") - kns0) / 1e9 / n_launches  # HIP events around k_nuts, engine stream
+        per_launch_s = nuts_ns / 1e9 / n_launches  # HIP events around k_nuts, engine stream
         achieved = (n_leap / n_launches) * B_lf / per_launch_s / 1e9  # this rank's dominant kernel
         traffic = measured_traffic(D, N)
         if traffic is not None:  # measured per launch of `transitions_per_launch`; rescale to this run's launches
@@ -211,6 +232,7 @@ def main():
                 "mean_leapfrogs_per_transition": total_leap / (args.steps * N * world),
                 "divergent": float(tn[1].item()),
                 "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()),
+                "ess": ess_info,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_nuts<double,%d,%d,mode 0,iso>" % (eng.info("group_lanes"), eng.info("elems_per_lane")),

@@ -171,3 +171,33 @@ def test_ref_compat_batch_early_exit(oracle):
         res[compat] = e.phasepoint().theta
     assert np.allclose(res[1][:, 0], 0.1, atol=1e-3)      # stopped after ONE step
     assert np.allclose(res[0][:, 0], np.sin(0.5), atol=1e-2)  # five steps of the unit oscillator
+
+
+def test_ess_and_bundle_samples(oracle):
+    """output side: ESS on an AR(1) process with known autocorrelation time,
+    EBFMI, and the Chains-shaped bundle of `sample`'s outputs"""
+    import ahmc_amd as A
+    from ahmc_amd import diagnostics as dg
+
+    rng = np.random.default_rng(0)
+    n, m, phi = 20000, 8, 0.7
+    x = np.zeros((n, m))
+    e = rng.normal(size=(n, m))
+    for t in range(1, n):
+        x[t] = phi * x[t - 1] + e[t]
+    ess = dg.ess(x)
+    np.testing.assert_allclose(ess / n, (1 - phi) / (1 + phi), rtol=0.15)   # τ = (1+φ)/(1−φ)
+    np.testing.assert_allclose(dg.ess(rng.normal(size=(4000, 3))) / 4000, 1.0, rtol=0.15)
+    E = rng.normal(size=(500, 4))
+    np.testing.assert_allclose(dg.EBFMI(E), A.EBFMI(E), rtol=1e-12)
+    # bundle of a short sampler-vec run on the oracle
+    D, N = 3, 5
+    h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
+    k = A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(0.2), A.FixedNSteps(4)))
+    ths, stats = A.sample(3, h, k, rng.normal(size=(D, N)), 12, lib=oracle)
+    b = dg.bundle_samples(ths, stats, param_names=["a", "b", "c"], discard_initial=2)
+    assert b["value"].shape == (10, 3 + len(b["internals"]), N)
+    assert b["names"][:3] == ["a", "b", "c"] and "hamiltonian_energy" in b["internals"]
+    np.testing.assert_array_equal(b["value"][:, :3, :], np.stack(ths)[2:])
+    j = b["names"].index("n_steps")
+    assert np.all(b["value"][:, j, :] == 4)
