@@ -393,9 +393,7 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
   DrawStream ds;
   auto resume_draws = [&](uint32_t it, uint32_t k) {
     rng.iter = p.iteration + it;
-    ds.init(rng);
-    ds.k = k;
-    if (k & 1u) ds.blk = rng.raw(RNG_TRANSITION, k >> 1);
+    ds.resume(rng, k);
   };
   // scalars are uniform across the wave: every lane computes them; lane 0 writes them back
   int phase = S.phase, it = S.it;

@@ -108,27 +108,29 @@ __device__ __forceinline__ void leapfrog_core(Point<T, E>& z, const T (&minv)[E]
   temper(lf, z.r, 1, false, 1);
 }
 
-// sequential scalar draws of one transition: draw k = half (k & 1) of Philox block k >> 1
+// Sequential scalar draws of one NUTS transition (direction bits, multinomial / slice uniforms, Exp(1)):
+// draw k = 32-bit word k & 3 of Philox block k >> 2; uniform = (w + ½)·2⁻³² ∈ (0,1), boolean = top bit.
+// One Philox block (≈75 VALU) serves four draws; 32 bits of resolution are ample for tree sampling
+// (the momentum normals, jitter and the static-HMC draws keep 53-bit uniforms).
 struct DrawStream {
   Rng rng;
   uint32_t k;
   Philox4 blk;
   __device__ __forceinline__ void init(const Rng& r) { rng = r; k = 0; }
-  __device__ __forceinline__ void fetch() {
-    if ((k & 1u) == 0u) blk = rng.raw(RNG_TRANSITION, k >> 1);
+  __device__ __forceinline__ void resume(const Rng& r, uint32_t k0) {  // continue a stream at draw k0
+    rng = r;
+    k = k0;
+    if (k & 3u) blk = rng.raw(RNG_TRANSITION, k >> 2);
   }
-  __device__ __forceinline__ double uniform() {
-    fetch();
-    double u = (k & 1u) ? u53(blk.v[2], blk.v[3]) : u53(blk.v[0], blk.v[1]);
+  __device__ __forceinline__ uint32_t word() {
+    if ((k & 3u) == 0u) blk = rng.raw(RNG_TRANSITION, k >> 2);
+    const uint32_t lo = (k & 1u) ? blk.v[1] : blk.v[0], hi = (k & 1u) ? blk.v[3] : blk.v[2];
+    const uint32_t w = (k & 2u) ? hi : lo;
     ++k;
-    return u;
+    return w;
   }
-  __device__ __forceinline__ bool boolean() {
-    fetch();
-    bool b = (((k & 1u) ? blk.v[2] : blk.v[0]) >> 31) != 0;
-    ++k;
-    return b;
-  }
+  __device__ __forceinline__ double uniform() { return ((double)word() + 0.5) * 2.3283064365386962890625e-10; }
+  __device__ __forceinline__ bool boolean() { return (word() >> 31) != 0; }
   __device__ __forceinline__ double randexp() { return -log(uniform()); }
 };
 

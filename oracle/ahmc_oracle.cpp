@@ -134,14 +134,15 @@ struct Rng {
   }
   bool boolean(uint32_t purpose, uint32_t slot) const { return (raw(purpose, slot).v[0] >> 31) != 0; }
   double randexp(uint32_t purpose, uint32_t slot) const { return -std::log(uniform(purpose, slot)); }
-  // sequential scalar draws of one NUTS transition: draw k = half (k & 1) of Philox block k >> 1
+  // sequential scalar draws of one NUTS transition: draw k = 32-bit word k & 3 of Philox block k >> 2;
+  // uniform = (w + ½)·2⁻³² ∈ (0,1), boolean = top bit of the word
   double seq_uniform(uint32_t k) const {
-    Philox4 p = raw(RNG_TRANSITION, k >> 1);
-    return (k & 1u) ? u53(p.v[2], p.v[3]) : u53(p.v[0], p.v[1]);
+    Philox4 p = raw(RNG_TRANSITION, k >> 2);
+    return ((double)p.v[k & 3u] + 0.5) * 2.3283064365386962890625e-10;
   }
   bool seq_boolean(uint32_t k) const {
-    Philox4 p = raw(RNG_TRANSITION, k >> 1);
-    return (((k & 1u) ? p.v[2] : p.v[0]) >> 31) != 0;
+    Philox4 p = raw(RNG_TRANSITION, k >> 2);
+    return (p.v[k & 3u] >> 31) != 0;
   }
   double seq_randexp(uint32_t k) const { return -std::log(seq_uniform(k)); }
   // standard normal for element d: Box–Muller on pair d/2
