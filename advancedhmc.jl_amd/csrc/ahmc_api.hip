@@ -421,7 +421,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.n_trans = n_trans;
   p.znorm = c->znorm;
   p.samples_out = samples_dev;
-  if (sampler == AHMC_TS_MULTINOMIAL && criterion == AHMC_TC_GENERALISED) {
+  if (sampler == AHMC_TS_MULTINOMIAL && criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED) {
     if (!no_linw) {
       // fast pass: multinomial weights in the linear domain; chains that came near overflow are
       // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
@@ -442,7 +442,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
       p.redo_only = 0;
       rc = launch_nuts<T, 1>(c, p, max_depth);
     }
-  } else {  // SliceTS, Classic / Strict criteria: the general instantiation
+  } else {  // SliceTS, Classic / Strict criteria, TemperedLeapfrog: the general instantiation
     p.redo_only = 0;
     rc = launch_nuts<T, 2>(c, p, max_depth);
   }

@@ -309,13 +309,16 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
   T part = 0;
   {  // the target family is a compile-time parameter: a 4-way run-time switch costs 36 VGPRs in k_nuts
     if constexpr (TK == 0) {  // AHMC_TARGET_ISO_GAUSS (test/common.jl:40-44, m = 0, s = 1)
+      // padded elements (d >= D) hold θ = 0 in every kernel, so they need no mask: Σθ² and g = θ are
+      // already right, and the constant −D/2·log 2π goes in once (lane 0's partial)
+      T ss = 0;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        bool ok = d0 + e < D;
-        part += ok ? -(log2pi + th[e] * th[e]) / 2 : T(0);
-        grad[e] = ok ? th[e] : T(0);
+        ss += th[e] * th[e];
+        grad[e] = th[e];
       }
-
+      part = -ss / 2;
+      if (lane == 0) part -= (T)D * log2pi / 2;
     }
     if constexpr (TK == 1) {  // AHMC_TARGET_DIAG_GAUSS: params = m[D], s[D]
 #pragma unroll
@@ -433,10 +436,12 @@ __device__ __forceinline__ T kinetic_partial(const T (&r)[E], const T (&minv)[E]
 
 // One leapfrog step of step i of n (tempering indices) with signed step size eps:
 //   r -= ϵ/2 g ; θ += ϵ M⁻¹ r ; (ℓπ, g) = ∂H∂θ(θ) ; r -= ϵ/2 g ; ℓκ = -½ rᵀM⁻¹r ; sanitise
-template <class T, int G, int E, int TK>
+// TEMPER = false compiles the tempering out (the default NUTS kernels: the if-converted r·√α / r/√α
+// select costs 6 VALU per leaf even when unused; TemperedLeapfrog runs the general instantiation)
+template <class T, int G, int E, int TK, bool TEMPER = true>
 __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp,
                                               const LeapfrogP<T>& lf, int lane, int d0, int64_t i, int64_t n) {
-  temper(lf, z.r, i, true, n);
+  if constexpr (TEMPER) temper(lf, z.r, i, true, n);
   const T eh = eps / 2;
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];

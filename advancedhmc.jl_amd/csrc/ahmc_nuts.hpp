@@ -93,10 +93,10 @@ struct Slots {
 };
 
 // the vector half of a leapfrog step (no energies): used to re-integrate to the candidate
-template <class T, int G, int E, int TK>
+template <class T, int G, int E, int TK, bool TEMPER = true>
 __device__ __forceinline__ void leapfrog_core(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp,
                                               const LeapfrogP<T>& lf, int lane, int d0) {
-  temper(lf, z.r, 1, true, 1);
+  if constexpr (TEMPER) temper(lf, z.r, 1, true, 1);
   const T eh = eps / 2;
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (E <= 2 && MODE != 2 ? 3 : (MO
         int merged = 0;
         if (alive) {
           // leaf: one leapfrog step in direction v (:638-647)
-          leapfrog_step<T, G, E, TK>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+          leapfrog_step<T, G, E, TK, GENERAL>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
           pos_cur += v;
           const T ne = cur.lp + cur.lk;  // neg_energy(z′)
           const T dH = -ne - H0;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (E <= 2 && MODE != 2 ? 3 : (MO
       for (int s = 0;; ++s) {
         const bool go = s < steps;
         if (__builtin_amdgcn_ballot_w64(go) == 0) break;
-        if (go) leapfrog_core<T, G, E, TK>(zc, minv, es, p.tp, p.lf, lane, d0);
+        if (go) leapfrog_core<T, G, E, TK, GENERAL>(zc, minv, es, p.tp, p.lf, lane, d0);
       }
       if (on && redo) {
         // stop here: the log-domain kernel resumes this chain at transition kt (its θ0 is in p.th)
