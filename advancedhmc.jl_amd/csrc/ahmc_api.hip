@@ -168,9 +168,10 @@ inline bool pick_geometry(int64_t D, int& G, int& E) {
   else if (D <= 256) { G = 64; E = 4; }
   else if (D <= 512) { G = 64; E = 8; }
   // multi-wave chains: one chain per workgroup of G/64 waves, reductions cross waves through LDS
-  // measured (hier Gaussian, f64, leapfrog/s): D=512 (64,8) 3.10e8 / (128,4) 3.07e8 / (256,2) 2.2e8;
-  // D=1024 (128,8) 1.33e8 / (256,4) 1.36e8; D=2048 (256,8) 5.8e7 / (512,4) 5.2e7
-  else if (D <= 1024) { G = 256; E = 4; }
+  // measured (hier Gaussian, f64, leapfrog/s; E = 8 kernels capped at 256 VGPRs = 2 waves/SIMD, spilling
+  // to scratch — at 1 wave/SIMD they ran at about half these rates): D=512 (64,8) 5.5e8 / (128,4) 3.1e8;
+  // D=1024 (128,8) 2.4e8 / (256,4) 1.5e8; D=2048 (256,8) 1.08e8 / (512,4) 5.2e7
+  else if (D <= 1024) { G = 128; E = 8; }
   else if (D <= 2048) { G = 256; E = 8; }
   else if (D <= 4096) { G = 512; E = 8; }
   else return false;

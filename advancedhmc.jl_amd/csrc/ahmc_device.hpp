@@ -451,7 +451,7 @@ __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E]
   red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
-  temper(lf, z.r, i, false, n);
+  if constexpr (TEMPER) temper(lf, z.r, i, false, n);
   red[1] = kinetic_partial(z.r, minv);
   group_allsum<G>(red);
   z.lp = sanitize(red[0]);

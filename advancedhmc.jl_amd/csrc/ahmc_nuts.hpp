@@ -105,7 +105,7 @@ __device__ __forceinline__ void leapfrog_core(Point<T, E>& z, const T (&minv)[E]
   (void)target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
-  temper(lf, z.r, 1, false, 1);
+  if constexpr (TEMPER) temper(lf, z.r, 1, false, 1);
 }
 
 // Sequential scalar draws of one NUTS transition (direction bits, multinomial / slice uniforms, Exp(1)):
@@ -139,7 +139,7 @@ struct DrawStream {
 // MODE 2: any sampler / criterion chosen at run time, log-domain weights (the run-time variants
 //         cost registers: with them in the fast kernel (32,4) loses a wave per SIMD)
 template <class T, int G, int E, int MODE, int TK>
-__global__ __launch_bounds__((G > 256 ? G : 256), (E <= 2 && MODE != 2 ? 3 : (MODE == 2 || E >= 8 ? 1 : 2))) void k_nuts(KP<T> p) {
+__global__ __launch_bounds__((G > 256 ? G : 256), (E <= 2 && MODE != 2 ? 3 : (E >= 8 && (G > 64 || MODE != 2) ? 2 : (MODE == 2 ? 1 : 2)))) void k_nuts(KP<T> p) {
   constexpr int CPW = G >= 64 ? 1 : 64 / G;  // chains per wave (G > 64: one chain per workgroup of G/64 waves)
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
   constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)

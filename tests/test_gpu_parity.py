@@ -253,7 +253,7 @@ def test_nuts_geometries_and_targets(hip, oracle, rng, D, target):
         assert n_div > 0, "the funnel at eps=0.5 must produce divergent transitions (Δ_max test, :500-507)"
 
 
-@pytest.mark.parametrize("D,target", [(600, "hier"), (2048, "iso"), (2048, "funnel"), (3000, "diag")])
+@pytest.mark.parametrize("D,target", [(400, "iso"), (600, "hier"), (1000, "iso"), (2048, "iso"), (2048, "funnel"), (3000, "diag")])
 def test_multiwave_chains(hip, oracle, rng, D, target):
     """D > 512: a chain spans 2-8 wavefronts of one workgroup (cross-wave reductions through LDS).
     Every transition kind on those geometries — BASELINE.json configs[4] is D = 2048."""
