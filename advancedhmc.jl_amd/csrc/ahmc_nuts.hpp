@@ -138,8 +138,12 @@ struct DrawStream {
 // MODE 1: multinomial + generalised, log-domain weights (redo pass for chains flagged by MODE 0)
 // MODE 2: any sampler / criterion chosen at run time, log-domain weights (the run-time variants
 //         cost registers: with them in the fast kernel (32,4) loses a wave per SIMD)
+// Minimum waves per SIMD (register cap): MEASURED, not derived — the compiler left to itself takes 168 / 231 /
+// 330 registers for E = 2 / 4 / 8 (3 / 2 / 1 waves); capping at 128 / 168 / 256 with a few spills to scratch
+// is faster every time: cfg2 (64,2) 1.68e9 -> 1.79e9 (5 waves: 1.22e9), hier D=256 (64,4) 7.1e8 -> 1.0e9,
+// D=512 (64,8) 3.1e8 -> 5.5e8 (3 waves: 2.3e8), D=2048 (256,8) 5.8e7 -> 1.08e8.
 template <class T, int G, int E, int MODE, int TK>
-__global__ __launch_bounds__((G > 256 ? G : 256), (E <= 2 && MODE != 2 ? 3 : (E >= 8 && (G > 64 || MODE != 2) ? 2 : (MODE == 2 ? 1 : 2)))) void k_nuts(KP<T> p) {
+__global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) : (E <= 2 ? 4 : (E <= 4 ? 3 : 2)))) void k_nuts(KP<T> p) {
   constexpr int CPW = G >= 64 ? 1 : 64 / G;  // chains per wave (G > 64: one chain per workgroup of G/64 waves)
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
   constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)
