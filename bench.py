@@ -129,7 +129,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AHMC_BENCH_FORCE_DIST"):  # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist_mod
 
         dist = dist_mod
