@@ -104,6 +104,8 @@ SIGNATURES = {
     "ahmc_find_good_stepsize": (_i32, [_vp, _f64, _i32]),
     "ahmc_adaptor_init": (_i32, [_vp, _i32, _f64, _i32, _i32, _i32]),
     "ahmc_adapt": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "ahmc_adapt_point": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "ahmc_set_var_estimator": (_i32, [_vp, _i32]),
     "ahmc_stan_windows": (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i64), C.POINTER(_i64),
                                  C.POINTER(_i64), _i32, C.POINTER(_i32)]),
     "ahmc_sample": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i32, _vp]),

@@ -352,6 +352,14 @@ class MassMatrixAdaptor:
     metric: AbstractMetric
     code = capi.ADAPT_MASSMATRIX
     delta = 0.8
+    estimator = 0  # AHMC_VAR_WELFORD
+
+
+class NutpieVar(MassMatrixAdaptor):
+    """NutpieVar(size) (src/adaptation/massmatrix.jl:160-250): the nutpie-style diagonal estimator
+    M⁻¹ = sqrt(var θ / var ∇ℓπ); a drop-in for the WelfordVar behind MassMatrixAdaptor(DiagEuclideanMetric),
+    e.g. StanHMCAdaptor(NutpieVar(metric), StepSizeAdaptor(δ, lf)) (test/adaptation.jl:141-143)"""
+    estimator = 1  # AHMC_VAR_NUTPIE
 
 
 @dataclass
@@ -596,14 +604,21 @@ class Engine:
     def adaptor_init(self, adaptor):
         ib, tb, ws = (getattr(adaptor, "init_buffer", 75), getattr(adaptor, "term_buffer", 50),
                       getattr(adaptor, "window_size", 25))
+        pc = adaptor if isinstance(adaptor, MassMatrixAdaptor) else getattr(adaptor, "pc", None)
+        self._call("ahmc_set_var_estimator", int(getattr(pc, "estimator", 0)))
         self._call("ahmc_adaptor_init", adaptor.code, float(adaptor.delta), ib, tb, ws)
 
-    def adapt(self, i, n_adapts, theta=None, alpha=None):
-        """adapt!(h, κ, adaptor, i, n_adapts, θ, α) (src/sampler.jl:72-90); θ/α default to the
-        context's position and the last transition's acceptance_rate"""
+    def adapt(self, i, n_adapts, theta=None, alpha=None, grad=None):
+        """adapt!(h, κ, adaptor, i, n_adapts, z_or_θ, α) (src/sampler.jl:72-90); θ/α default to the
+        context's position and the last transition's acceptance_rate; `grad` = z.ℓπ.gradient makes the
+        argument a phase point (needed by NutpieVar, src/adaptation/massmatrix.jl:238-243)"""
         th = None if theta is None else self._mat(theta, "θ")
         al = None if alpha is None else np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=self.dtype), (self.N,)))
-        self._call("ahmc_adapt", int(i), int(n_adapts), capi.as_ptr(th), capi.as_ptr(al))
+        if grad is None:
+            self._call("ahmc_adapt", int(i), int(n_adapts), capi.as_ptr(th), capi.as_ptr(al))
+        else:
+            g = self._mat(grad, "∇")
+            self._call("ahmc_adapt_point", int(i), int(n_adapts), capi.as_ptr(th), capi.as_ptr(g), capi.as_ptr(al))
 
     # -- bulk driver --
     def run(self, kernel: HMCKernel, n_samples, n_adapts=0, drop_warmup=False, samples_out=None):

@@ -111,6 +111,8 @@ struct Ctx : CtxBase {
   T *da_eps = nullptr, *da_mu = nullptr, *da_xbar = nullptr, *da_Hbar = nullptr;
   int64_t wv_n = 0, wv_nmin = 10;
   T *wv_mu = nullptr, *wv_M = nullptr, *wv_var = nullptr;
+  int var_estimator = AHMC_VAR_WELFORD;            // WelfordVar or NutpieVar (massmatrix.jl:160-250)
+  T *wg_mu = nullptr, *wg_M = nullptr, *ext_g = nullptr;  // NutpieVar: gradient estimator state, staging for a caller's gradient
   T *ext_th = nullptr, *ext_alpha = nullptr;  // staging for ahmc_adapt(θ, α) arguments
   int stan_init = 75, stan_term = 50, stan_window = 25;
   int64_t stan_i = 0;
@@ -134,7 +136,7 @@ struct Ctx : CtxBase {
     if (stream) (void)hipStreamSynchronize(stream);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active, dn_list};
+                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -564,6 +566,14 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
     }
     HIPCHK(hipMemsetAsync(c->wv_mu, 0, sizeof(T) * DN, c->stream));
     HIPCHK(hipMemsetAsync(c->wv_M, 0, sizeof(T) * DN, c->stream));
+    if (c->var_estimator == AHMC_VAR_NUTPIE) {
+      if (!c->wg_mu) {
+        if ((rc = dev_alloc(c, &c->wg_mu, (size_t)DN))) return rc;
+        if ((rc = dev_alloc(c, &c->wg_M, (size_t)DN))) return rc;
+      }
+      HIPCHK(hipMemsetAsync(c->wg_mu, 0, sizeof(T) * DN, c->stream));
+      HIPCHK(hipMemsetAsync(c->wg_M, 0, sizeof(T) * DN, c->stream));
+    }
     c->wv_n = 0;
   }
   return AHMC_OK;
@@ -571,7 +581,7 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
 
 // adapt!(h, κ, adaptor, i, n_adapts, z, α) + update(h/κ, adaptor) (src/sampler.jl:72-90, :3-22)
 template <class T>
-int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr) {
+int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr, const T* g_ext = nullptr) {
   if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
   const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
   const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
@@ -628,6 +638,18 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     }
     a.wv_mu = c->wv_mu; a.wv_M = c->wv_M; a.wv_var = c->wv_var;
     a.minv = c->minv; a.sqrt_minv = c->sqrt_minv;
+    if (c->var_estimator == AHMC_VAR_NUTPIE) {
+      if (th_ext && !g_ext)  // massmatrix.jl:234-236
+        return fail(c, AHMC_ERR_ARGUMENT, "`NutpieVar` adaptation requires position and gradient information!");
+      a.nutpie = 1;
+      a.gr = c->g;
+      if (g_ext) {
+        if (!c->ext_g) { int rc2 = dev_alloc(c, &c->ext_g, (size_t)a.DN); if (rc2) return rc2; }
+        HIPCHK(hipMemcpyAsync(c->ext_g, g_ext, sizeof(T) * a.DN, hipMemcpyDefault, c->stream));
+        a.gr = c->ext_g;
+      }
+      a.wg_mu = c->wg_mu; a.wg_M = c->wg_M;
+    }
     hipLaunchKernelGGL((k_adapt_wv<T>), dim3((unsigned)((a.DN + 255) / 256)), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     if (wv_reset) c->wv_n = 0;
@@ -998,6 +1020,18 @@ int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t ini
   FOR_CTX(ctx, {
     if (kind < AHMC_ADAPT_NONE || kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: unknown adaptor kind");
     return adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
+  });
+}
+
+int32_t ahmc_adapt_point(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* grad, const void* alpha) {
+  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha), static_cast<const T*>(grad)); });
+}
+
+int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t est) {
+  FOR_CTX(ctx, {
+    if (est != AHMC_VAR_WELFORD && est != AHMC_VAR_NUTPIE) return fail(c, AHMC_ERR_ARGUMENT, "set_var_estimator: unknown estimator");
+    c->var_estimator = est;
+    return AHMC_OK;
   });
 }
 

@@ -507,6 +507,10 @@ struct AdaptP {
   const T* th;
   T *wv_mu, *wv_M, *wv_var;
   T *minv, *sqrt_minv;  // update(h, adaptor): M⁻¹ ← var, sqrtM⁻¹ recomputed (metric.jl:61-63)
+  // NutpieVar (massmatrix.jl:160-250): a second Welford estimator on z.ℓπ.gradient
+  int nutpie;
+  const T* gr;
+  T *wg_mu, *wg_M;
 };
 
 template <class T>
@@ -543,15 +547,26 @@ __global__ __launch_bounds__(256) void k_adapt_wv(AdaptP<T> a) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.DN) return;
   T mu = a.wv_mu[k], M = a.wv_M[k];
+  T mug = 0, Mg = 0;
+  if (a.nutpie) { mug = a.wg_mu[k]; Mg = a.wg_M[k]; }
   if (a.do_push) {
     const T n = a.wv_n;
     T delta = a.th[k] - mu;
     mu = mu + delta / n;
     M = M + delta * delta * ((n - 1) / n);
+    if (a.nutpie) {  // push!(nv, z) (:238-243)
+      T dg = a.gr[k] - mug;
+      mug = mug + dg / n;
+      Mg = Mg + dg * dg * ((n - 1) / n);
+    }
   }
   if (a.do_update) {  // get_estimation (:152-157), only when n >= n_min (host decides)
     const T n = a.wv_n;
     T var = n / ((n + 5) * (n - 1)) * M + T(1e-3) * (5 / (n + 5));
+    if (a.nutpie) {  // sqrt.(est(θ) ./ est(∇)) (:246-250)
+      T eg = n / ((n + 5) * (n - 1)) * Mg + T(1e-3) * (5 / (n + 5));
+      var = sqrt(var / eg);
+    }
     a.wv_var[k] = var;
     a.minv[k] = var;
     a.sqrt_minv[k] = sqrt(var);
@@ -559,9 +574,12 @@ __global__ __launch_bounds__(256) void k_adapt_wv(AdaptP<T> a) {
   if (a.wv_reset) {
     mu = 0;
     M = 0;
+    mug = 0;
+    Mg = 0;
   }
   a.wv_mu[k] = mu;
   a.wv_M[k] = M;
+  if (a.nutpie) { a.wg_mu[k] = mug; a.wg_M[k] = Mg; }
 }
 
 // standard normals of the momentum draws of `n_trans` consecutive transitions: element d of chain c

@@ -217,6 +217,18 @@ int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t ini
  * acceptance_rate" (what the sample loop passes, src/sampler.jl:187).                        */
 int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta,
                    const void* alpha);
+/* The variance estimator behind MassMatrixAdaptor / NaiveHMCAdaptor / StanHMCAdaptor with a Diag
+ * metric: WelfordVar (src/adaptation/massmatrix.jl:64-157) or NutpieVar (:160-250: Welford
+ * estimators of the positions AND of the gradients, M⁻¹ = sqrt(var θ / var ∇)).  Call before
+ * ahmc_adaptor_init.                                                                          */
+enum { AHMC_VAR_WELFORD = 0, AHMC_VAR_NUTPIE = 1 };
+int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t estimator);
+/* adapt! on an explicit phase point (src/adaptation/Adaptation.jl:24-26 PositionOrPhasePoint): as
+ * ahmc_adapt plus grad (D,N) = z.ℓπ.gradient, which NutpieVar needs; with NutpieVar a theta
+ * without grad is the reference's error "requires position and gradient information"
+ * (massmatrix.jl:234-236).  NULLs mean the context's own state.                              */
+int32_t ahmc_adapt_point(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta,
+                         const void* grad, const void* alpha);
 /* Stan window schedule for n_adapts (stan_adaptor.jl:13-50): writes up to cap split points,
  * returns their count in *n_splits and the window start/end.  Pure host logic.               */
 int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size,

@@ -780,6 +780,8 @@ struct Ctx : CtxBase {
   std::vector<T> da_eps, da_mu, da_xbar, da_Hbar;
   int64_t wv_n = 0, wv_nmin = 10;
   std::vector<T> wv_mu, wv_M, wv_var;
+  int var_estimator = AHMC_VAR_WELFORD;  // WelfordVar or NutpieVar (massmatrix.jl:160-250)
+  std::vector<T> wg_mu, wg_M;             // NutpieVar: the gradient estimator's Welford state
   int stan_init = 75, stan_term = 50, stan_window = 25;
   int64_t stan_i = 0;
   StanWindows windows;
@@ -1171,17 +1173,25 @@ void wv_reset(Ctx<T>* c) {  // reset!(wv) (src/adaptation/massmatrix.jl:133-138)
   c->wv_n = 0;
   std::fill(c->wv_mu.begin(), c->wv_mu.end(), T(0));
   std::fill(c->wv_M.begin(), c->wv_M.end(), T(0));
+  std::fill(c->wg_mu.begin(), c->wg_mu.end(), T(0));  // NutpieVar reset! (:232-236)
+  std::fill(c->wg_M.begin(), c->wg_M.end(), T(0));
 }
 
 template <class T>
-void wv_push(Ctx<T>* c, const T* th_ext = nullptr) {  // push! (:141-149)
+void wv_push(Ctx<T>* c, const T* th_ext = nullptr, const T* g_ext = nullptr) {  // push! (:141-149; NutpieVar :238-243)
   c->wv_n += 1;
   T n = T(c->wv_n);
+  const bool nutpie = c->var_estimator == AHMC_VAR_NUTPIE;
 #pragma omp parallel for schedule(static)
   for (int64_t k = 0; k < c->D * c->N; ++k) {
     T delta = (th_ext ? th_ext[k] : c->th[k]) - c->wv_mu[k];
     c->wv_mu[k] = c->wv_mu[k] + delta / n;
     c->wv_M[k] = c->wv_M[k] + delta * delta * ((n - 1) / n);
+    if (nutpie) {  // the same recursion on z.ℓπ.gradient
+      T dg = (g_ext ? g_ext[k] : c->g[k]) - c->wg_mu[k];
+      c->wg_mu[k] = c->wg_mu[k] + dg / n;
+      c->wg_M[k] = c->wg_M[k] + dg * dg * ((n - 1) / n);
+    }
   }
 }
 
@@ -1190,14 +1200,23 @@ void wv_update(Ctx<T>* c) {  // update! (:60-62) + get_estimation (:152-157)
   if (c->wv_n < c->wv_nmin) return;
   T n = T(c->wv_n), e = T(1e-3);
 #pragma omp parallel for schedule(static)
-  for (int64_t k = 0; k < c->D * c->N; ++k) c->wv_var[k] = n / ((n + 5) * (n - 1)) * c->wv_M[k] + e * (5 / (n + 5));
+  for (int64_t k = 0; k < c->D * c->N; ++k) {
+    T est = n / ((n + 5) * (n - 1)) * c->wv_M[k] + e * (5 / (n + 5));
+    if (c->var_estimator == AHMC_VAR_NUTPIE) {  // sqrt.(est(positions) ./ est(gradients)) (:246-250)
+      T eg = n / ((n + 5) * (n - 1)) * c->wg_M[k] + e * (5 / (n + 5));
+      est = std::sqrt(est / eg);
+    }
+    c->wv_var[k] = est;
+  }
 }
 
 template <class T>
-int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr) {  // src/sampler.jl:72-90
+int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr, const T* g_ext = nullptr) {  // src/sampler.jl:72-90
   if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
   const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
   const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
+  if (has_mm && c->var_estimator == AHMC_VAR_NUTPIE && th_ext && !g_ext)  // massmatrix.jl:234-236
+    return fail(c, AHMC_ERR_ARGUMENT, "`NutpieVar` adaptation requires position and gradient information!");
   if (i == 1 && c->adapt_kind == AHMC_ADAPT_STAN) {  // initialize! (stan_adaptor.jl:105-115)
     c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);
   }
@@ -1207,7 +1226,7 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
     bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
     if (in_window && has_mm) {
-      wv_push(c, th_ext);
+      wv_push(c, th_ext, g_ext);
       if (window_end) wv_update(c);
     }
     if (window_end) {
@@ -1216,7 +1235,7 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     }
   } else {
     if (has_ss) da_adapt(c, alpha_ext);  // NaiveHMCAdaptor: ssa then pc (Adaptation.jl:52-60)
-    if (has_mm) { wv_push(c, th_ext); wv_update(c); }
+    if (has_mm) { wv_push(c, th_ext, g_ext); wv_update(c); }
   }
   if (i == n_adapts && has_ss) {  // finalize! (stepsize.jl:55-62): ϵ = exp(x̄)
     for (int64_t k = 0; k < c->N; ++k) c->da_eps[k] = std::exp(c->da_xbar[k]);
@@ -1250,6 +1269,7 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
     c->wv_mu.assign(c->D * c->N, T(0));
     c->wv_M.assign(c->D * c->N, T(0));
     c->wv_var.resize(c->D * c->N);
+    if (c->var_estimator == AHMC_VAR_NUTPIE) { c->wg_mu.assign(c->D * c->N, T(0)); c->wg_M.assign(c->D * c->N, T(0)); }
     for (int64_t i = 0; i < c->N; ++i)
       for (int64_t d = 0; d < c->D; ++d)
         c->wv_var[d + i * c->D] = c->minv[c->metric_per_chain ? d + i * c->D : d];
@@ -1566,6 +1586,18 @@ int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t ini
 
 int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* alpha) {
   FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha)); });
+}
+
+int32_t ahmc_adapt_point(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* grad, const void* alpha) {
+  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha), static_cast<const T*>(grad)); });
+}
+
+int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t est) {
+  FOR_CTX(ctx, {
+    if (est != AHMC_VAR_WELFORD && est != AHMC_VAR_NUTPIE) return fail(c, AHMC_ERR_ARGUMENT, "set_var_estimator: unknown estimator");
+    c->var_estimator = est;
+    return AHMC_OK;
+  });
 }
 
 int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size, int64_t n_adapts,

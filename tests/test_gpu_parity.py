@@ -488,6 +488,38 @@ def test_adaptation(hip, oracle, rng, kind):
     np.testing.assert_allclose(g2.get_stepsize(), o2.get_stepsize(), rtol=1e-7)
 
 
+def test_nutpie_var(hip, oracle, rng):
+    """NutpieVar (src/adaptation/massmatrix.jl:160-250) on identical (θ, ∇, α) inputs: HIP == oracle; and as the
+    estimator of a StanHMCAdaptor on a diagonal Gaussian it recovers σ² (test/adaptation.jl:183-192)"""
+    D, N = 6, 64
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    g, o = pair(hip, oracle, h, N, np.float64, eps=0.2)
+    for e in (g, o):
+        e.set_position(np.zeros((D, N)))
+        e.adaptor_init(A.StanHMCAdaptor(A.NutpieVar(metric), A.StepSizeAdaptor(0.8, A.Leapfrog(0.2))))
+    for i in range(1, 161):
+        th, gr, al = rng.normal(size=(D, N)), rng.normal(size=(D, N)), rng.random(N)
+        for e in (g, o):
+            e.adapt(i, 160, theta=th, alpha=al, grad=gr)
+        if i in (20, 100, 150, 160):
+            np.testing.assert_allclose(g.get_metric(), o.get_metric(), rtol=1e-11, err_msg=f"M⁻¹ at {i}")
+            np.testing.assert_allclose(g.get_stepsize(), o.get_stepsize(), rtol=1e-10, err_msg=f"ϵ at {i}")
+    # end to end: NUTS + Stan windows with the nutpie estimator on N(0, diag σ²)
+    D, N = 5, 512
+    sig = 0.5 + 2 * rng.random(D)
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.DiagGaussian(np.zeros(D), sig))
+    lf = A.Leapfrog(np.full(N, 0.1))
+    e = A.Engine(h, N, rng=77, lib=hip)
+    e.set_integrator(lf)
+    e.set_position(rng.normal(size=(D, N)))
+    e.adaptor_init(A.StanHMCAdaptor(A.NutpieVar(metric), A.StepSizeAdaptor(0.8, lf)))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+    e.run(k, 300, 300)
+    np.testing.assert_allclose(np.median(e.get_metric(), axis=1), sig ** 2, rtol=0.1)
+
+
 def test_bulk_sample_equals_stepwise(hip, rng):
     """ahmc_sample (one enqueue for the whole loop of src/sampler.jl:182-228) == per-iteration calls"""
     D, N, n, n_adapts = 10, 200, 60, 40

@@ -293,3 +293,42 @@ def test_adaptors_statistical(oracle):
         acc = np.mean([st["acceptance_rate"].mean() for st in stats[700:]])
         if not isinstance(ad, A.MassMatrixAdaptor):
             assert 0.6 < acc < 0.95
+
+
+def test_nutpie_var(oracle):
+    """NutpieVar (src/adaptation/massmatrix.jl:160-250): constructor behaviour of test/adaptation.jl:101-128
+    (estimate stays at ones below n_min), the estimator formula sqrt(est(θ)/est(∇)) against a direct numpy
+    evaluation, the error for a bare position, and test/adaptation.jl:183-192: on a diagonal Gaussian the
+    un-regularised estimate is exact (var θ = σ², var ∇ = 1/σ²)"""
+    import ahmc_amd as A
+
+    D, N = 4, 3
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    e = A.Engine(h, N, rng=1, lib=oracle)
+    e.set_integrator(A.Leapfrog(0.1))
+    e.set_position(np.zeros((D, N)))
+    e.adaptor_init(A.NutpieVar(metric))
+    z = np.zeros((D, N))
+    e.adapt(1, 100, theta=z, alpha=np.ones(N), grad=z)
+    e.adapt(2, 100, theta=z, alpha=np.ones(N), grad=z)
+    np.testing.assert_array_equal(e.get_metric(), np.ones((D, N)))       # getM⁻¹(pc2_nutpie) == ones
+    with pytest.raises(A.ArgumentError, match="position and gradient"):
+        e.adapt(3, 100, theta=z, alpha=np.ones(N))                       # push!(::NutpieVar, x) errors
+    e.close()
+
+    rng = np.random.default_rng(5)
+    sig2 = 1 + np.abs(rng.normal(size=D))
+    e = A.Engine(h, N, rng=1, lib=oracle)
+    e.set_integrator(A.Leapfrog(0.1))
+    e.set_position(np.zeros((D, N)))
+    e.adaptor_init(A.NutpieVar(metric))
+    n = 40
+    ths = rng.normal(size=(n, D, N)) * np.sqrt(sig2)[None, :, None]
+    grs = ths / sig2[None, :, None]                                      # −∇ log N(0, Σ) = θ/σ²
+    for i in range(n):
+        e.adapt(i + 1, 1000, theta=ths[i], alpha=np.ones(N), grad=grs[i])
+    est = lambda x: n / ((n + 5) * (n - 1)) * ((x - x.mean(0)) ** 2).sum(0) + 1e-3 * 5 / (n + 5)
+    np.testing.assert_allclose(e.get_metric(), np.sqrt(est(ths) / est(grs)), rtol=1e-12)
+    np.testing.assert_allclose(e.get_metric(), np.broadcast_to(sig2[:, None], (D, N)), rtol=2e-3)  # exact up to the regulariser
+    e.close()
