@@ -65,8 +65,17 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
   __shared__ T Bs[2][GB_K][GB_N + GB_PAD];
   using M = Mfma<T>;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int m0 = blockIdx.x * GB_M;
-  const int64_t n0 = (int64_t)blockIdx.y * GB_N;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+  // the row blocks of ONE column block are given the same id mod 8 — they read the same X tile from
+  // the same L2 instead of eight L2s each fetching it from the Infinity Cache.  (Launched as a 1-D grid
+  // of row_blocks × 8·⌈col_blocks/8⌉ workgroups.)
+  const int nrb = (D + GB_M - 1) / GB_M;
+  const unsigned lin = blockIdx.x;
+  const unsigned xcd = lin & 7u, slot = lin >> 3;
+  const int64_t cb = (int64_t)(slot / nrb) * 8 + xcd;
+  const int m0 = (int)(slot % nrb) * GB_M;
+  const int64_t n0 = cb * GB_N;
+  if (n0 >= N) return;
   const int wm = (w & 1) * 32, wn = (w >> 1) * 32;
   typename M::acc_t acc[2][2];
 #pragma unroll

@@ -20,7 +20,8 @@ int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* l
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   }
-  dim3 grid((unsigned)row_blocks, (unsigned)((ncols + GB_N - 1) / GB_N));
+  const int64_t cb8 = ((ncols + GB_N - 1) / GB_N + 7) / 8 * 8;  // column blocks padded to the 8 XCDs (see k_dgemm)
+  dim3 grid((unsigned)(row_blocks * cb8));
   hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
