@@ -24,9 +24,10 @@ const LIB = get(ENV, "AHMC_HIP_LIB", "libahmc_hip.so")
 
 # --- enums of include/ahmc_hip.h -----------------------------------------------------------------
 const F32, F64 = Cint(0), Cint(1)
-const METRIC_UNIT, METRIC_DIAG = Cint(0), Cint(1)
+const METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = Cint(0), Cint(1), Cint(2)
 const TARGET_ISO_GAUSS, TARGET_DIAG_GAUSS, TARGET_FUNNEL, TARGET_HIER_GAUSS = Cint.(0:3)
-const TARGET_EXTERNAL = Cint(5)
+const TARGET_DENSE_GAUSS, TARGET_EXTERNAL = Cint(4), Cint(5)
+const VAR_WELFORD, VAR_NUTPIE = Cint(0), Cint(1)
 const TS_ENDPOINT, TS_MULTINOMIAL, TS_SLICE = Cint.(0:2)
 const TC_CLASSIC, TC_GENERALISED, TC_STRICT = Cint.(0:2)
 const ADAPT_NONE, ADAPT_STEPSIZE, ADAPT_MASSMATRIX, ADAPT_NAIVE, ADAPT_STAN = Cint.(0:4)
@@ -91,6 +92,16 @@ set_metric!(z::MI355XChains, ::UnitEuclideanMetric) =
 function set_metric!(z::MI355XChains{T}, m::DiagEuclideanMetric) where {T}
     M = convert(Array{T}, m.M⁻¹)   # (D,) or (D, N): column-major, passed as is
     check(z.ctx, ccall((:ahmc_set_metric, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{T}, Int64), z.ctx, METRIC_DIAG, M, length(M)))
+end
+
+function set_metric!(z::MI355XChains{T}, m::DenseEuclideanMetric) where {T}
+    M = convert(Matrix{T}, m.M⁻¹)   # (D, D) column-major, shared by all chains; runs on the MFMA engine
+    check(z.ctx, ccall((:ahmc_set_metric, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{T}, Int64), z.ctx, METRIC_DENSE, M, length(M)))
+end
+# ℓπ = -½ θᵀPθ with the precision P applied as a GEMM (SURVEY §8d cfg4)
+function set_dense_gaussian_target!(z::MI355XChains{T}, P::AbstractMatrix) where {T}
+    Pm = convert(Matrix{T}, P)
+    check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{T}, Int64), z.ctx, TARGET_DENSE_GAUSS, Pm, length(Pm)))
 end
 
 function set_integrator!(z::MI355XChains{T}, lf) where {T}
@@ -186,6 +197,9 @@ adaptor_code(::NaiveHMCAdaptor) = ADAPT_NAIVE
 adaptor_code(::StanHMCAdaptor) = ADAPT_STAN
 
 function adaptor_init!(z::MI355XChains, a::AbstractAdaptor, δ::Real)
+    pc = a isa MassMatrixAdaptor ? a : (hasproperty(a, :pc) ? a.pc : nothing)
+    est = pc isa AdvancedHMC.Adaptation.NutpieVar ? VAR_NUTPIE : VAR_WELFORD   # src/adaptation/massmatrix.jl:160-250
+    check(z.ctx, ccall((:ahmc_set_var_estimator, LIB), Cint, (Ptr{Cvoid}, Cint), z.ctx, est))
     ib, tb, ws = a isa StanHMCAdaptor ? (a.init_buffer, a.term_buffer, a.window_size) : (75, 50, 25)
     check(z.ctx, ccall((:ahmc_adaptor_init, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint, Cint),
                        z.ctx, adaptor_code(a), Float64(δ), ib, tb, ws))
