@@ -418,7 +418,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
     }
     const int64_t pairs = ((c->D + 1) / 2) * c->N * (int64_t)n_trans;
     const unsigned grid = (unsigned)std::min<int64_t>((pairs + 255) / 256, (int64_t)c->n_cu * 32);
-    hipLaunchKernelGGL((k_normals<T>), dim3(grid), dim3(256), 0, c->stream, p, c->znorm, n_trans);
+    hipLaunchKernelGGL((k_normals<T>), dim3(grid), dim3(256), 0, c->stream, p, c->znorm, n_trans, (uint32_t)RNG_MOMENTUM);
     HIPCHK(hipGetLastError());
   }
   p.n_trans = n_trans;
@@ -1002,6 +1002,7 @@ int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
 int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
   FOR_CTX(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "find_good_stepsize before set_position");
+    if (dense_engine(c)) return dn_find_eps(c, initial_step_size, max_n_iters);
     int rc = check_builtin(c, "find_good_stepsize");
     if (rc) return rc;
     KP<T> p = make_kp(c);

@@ -804,4 +804,128 @@ __global__ __launch_bounds__(256) void k_d_hmc_end(KP<T> p, DP<T> q) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// find_good_stepsize (src/trajectory.jl:768-837) as a per-chain state machine.  DChain fields reused:
+// H0 = H(z0), eps / lu = the bracket (ϵ, ϵ′), w_tree = the ϵ being evaluated, phase = 0 first evaluation,
+// 1 doubling/halving until the acceptance ratio crosses ½ (Q3: A is evaluated at ϵ, not ϵ′), 2 bisection to
+// (¼, ¾), 3 done; v = too_high; it = iteration counter.  z0 is kept in the OTH slots.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_d_fe_save(KP<T> p, DP<T> q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= p.N) return;
+  const int D = p.D;
+  vcopy(dslot(q, p, DS_START_TH, c), p.th() + c * D, D, lane);
+  vcopy(dslot(q, p, DS_START_R, c), p.r() + c * D, D, lane);
+  vcopy(dslot(q, p, DS_START_G, c), p.g() + c * D, D, lane);
+  if (lane == 0) {
+    q.S[c].cand_lp = p.lp()[c];
+    q.S[c].cand_lk = p.lk()[c];
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_fe_begin(KP<T> p, DP<T> q, int* n_active) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c == 0 && lane == 0) *n_active = (int)p.N;
+  if (c >= p.N) return;
+  const int D = p.D;
+  vcopy(dslot(q, p, DS_OTH_TH, c), p.th() + c * D, D, lane);
+  vcopy(dslot(q, p, DS_OTH_R, c), p.r() + c * D, D, lane);
+  vcopy(dslot(q, p, DS_OTH_G, c), p.g() + c * D, D, lane);
+  vcopy(dslot(q, p, DS_OTH_V, c), dslot(q, p, DS_CUR_V, c), D, lane);
+  if (q.dense_metric) vcopy(dslot(q, p, DS_OTH_W, c), dslot(q, p, DS_CUR_W, c), D, lane);
+  if (lane == 0) {
+    DChain<T>& S = q.S[c];
+    S.H0 = -(p.lp()[c] + p.lk()[c]);
+    S.sub_lp = p.lp()[c];  // ℓπ, ℓκ of z0 (restored with it)
+    S.sub_lk = p.lk()[c];
+    S.eps = p.init_eps;
+    S.lu = p.init_eps;
+    S.w_tree = p.init_eps;
+    S.phase = 0;
+    S.it = 0;
+    S.v = 0;
+    q.es[c] = p.init_eps;
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_fe_iter(KP<T> p, DP<T> q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= p.N) return;
+  DChain<T>& S = q.S[c];
+  int phase = S.phase;
+  if (phase == 3) return;
+  const int D = p.D;
+  const T log_a_min = 2 * log(T(0.5)), log_a_cross = log(T(0.5)), log_a_max = log(T(0.75));
+  const T dH = S.H0 - (-(p.lp()[c] + p.lk()[c]));  // H − A(ϵ_eval)
+  T eps = S.eps, epsp = S.lu;
+  int it = S.it;
+  bool too_high = S.v != 0;
+  auto to_bisection = [&]() {
+    const T lo = jl_min(eps, epsp), hi = jl_max(eps, epsp);
+    eps = lo;
+    epsp = hi;
+    it = 0;
+    phase = p.max_iters > 0 ? 2 : 3;
+  };
+  if (phase == 0) {
+    too_high = dH > log_a_cross;
+    if (p.max_iters > 0) phase = 1;
+    else to_bisection();
+  } else if (phase == 1) {
+    epsp = too_high ? 2 * eps : eps / 2;
+    if (too_high != (dH > log_a_cross)) {
+      to_bisection();
+    } else {
+      eps = epsp;
+      if (++it >= p.max_iters) to_bisection();
+    }
+  } else {  // bisection: the evaluation was at mid = S.w_tree
+    const T mid = S.w_tree;
+    bool done = false;
+    if (dH > log_a_max) eps = mid;
+    else if (dH < log_a_min) epsp = mid;
+    else { eps = mid; done = true; }
+    if (done || ++it >= p.max_iters) phase = 3;
+  }
+  const T eval = phase == 2 ? eps / 2 + epsp / 2 : eps;
+  // rewind to z0 for the next evaluation
+  vcopy(p.th() + c * D, dslot(q, p, DS_OTH_TH, c), D, lane);
+  vcopy(p.r() + c * D, dslot(q, p, DS_OTH_R, c), D, lane);
+  vcopy(p.g() + c * D, dslot(q, p, DS_OTH_G, c), D, lane);
+  vcopy(dslot(q, p, DS_CUR_V, c), dslot(q, p, DS_OTH_V, c), D, lane);
+  if (q.dense_metric) vcopy(dslot(q, p, DS_CUR_W, c), dslot(q, p, DS_OTH_W, c), D, lane);
+  if (lane == 0) {
+    p.lp()[c] = S.sub_lp;
+    p.lk()[c] = S.sub_lk;
+    S.eps = eps;
+    S.lu = epsp;
+    S.w_tree = eval;
+    S.it = it;
+    S.v = too_high ? 1 : 0;
+    S.phase = phase;
+    q.es[c] = phase == 3 ? T(0) : eval;
+    if (phase == 3) atomicSub(q.n_active, 1);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_fe_end(KP<T> p, DP<T> q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= p.N) return;
+  const int D = p.D;
+  vcopy(p.th() + c * D, dslot(q, p, DS_START_TH, c), D, lane);
+  vcopy(p.r() + c * D, dslot(q, p, DS_START_R, c), D, lane);
+  vcopy(p.g() + c * D, dslot(q, p, DS_START_G, c), D, lane);
+  if (lane == 0) {
+    p.lp()[c] = q.S[c].cand_lp;
+    p.lk()[c] = q.S[c].cand_lk;
+    p.eps_cur()[c] = q.S[c].eps;
+    q.es[c] = T(0);
+  }
+}
+
 }  // namespace ahmc

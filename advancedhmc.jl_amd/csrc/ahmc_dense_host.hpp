@@ -151,7 +151,7 @@ int dn_step(Ctx<T>* c, const int* list = nullptr, int64_t n = -1) {
 // fresh momenta of n_trans consecutive transitions (iterations c->iteration + k):
 // R_k = U⁻¹ Z_k (Dense; rand_momentum src/metric.jl:311-320) or Z_k ./ √M⁻¹; V_k = M⁻¹ R_k
 template <class T>
-int dn_momenta(Ctx<T>* c, int n_trans, T* R, T* V) {
+int dn_momenta(Ctx<T>* c, int n_trans, T* R, T* V, uint32_t purpose = RNG_MOMENTUM) {
   const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
   if (need > c->znorm_elems) {
     if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
@@ -162,7 +162,7 @@ int dn_momenta(Ctx<T>* c, int n_trans, T* R, T* V) {
   KP<T> p = make_kp(c);
   const int64_t pairs = ((c->D + 1) / 2) * c->N * (int64_t)n_trans;
   const unsigned grid = (unsigned)std::min<int64_t>((pairs + 255) / 256, (int64_t)c->n_cu * 32);
-  hipLaunchKernelGGL((k_normals<T>), dim3(grid), dim3(256), 0, c->stream, p, c->znorm, n_trans);
+  hipLaunchKernelGGL((k_normals<T>), dim3(grid), dim3(256), 0, c->stream, p, c->znorm, n_trans, purpose);
   HIPCHK(hipGetLastError());
   const int64_t cols = (int64_t)n_trans * c->N;
   if (c->metric_kind == AHMC_METRIC_DENSE) {
@@ -368,5 +368,46 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] dense NUTS batch of %d: %lld global steps so far, %lld chain-slots stepped\n", n_trans, (long long)c->dn_global_steps, (long long)c->dn_chain_steps);
   c->iteration += (uint64_t)n_trans;
+  return AHMC_OK;
+}
+
+// find_good_stepsize per chain (src/trajectory.jl:768-837, quirk Q3 kept) on the dense engine: every
+// evaluation A(ϵ) = H after ONE leapfrog from the start point is one global step; k_d_fe_iter advances
+// each chain's doubling / bisection and rewinds it to the start point.
+template <class T>
+int dn_find_eps(Ctx<T>* c, double init_eps, int max_iters) {
+  int rc = dn_check(c, "find_good_stepsize", 0);
+  if (rc) return rc;
+  rc = dn_ensure(c, 2);
+  if (rc) return rc;
+  KP<T> p = make_kp(c);
+  p.init_eps = (T)init_eps;
+  p.max_iters = max_iters;
+  DP<T> q = make_dp(c);
+  hipLaunchKernelGGL((k_d_fe_save<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);  // the caller's point survives the search
+  rc = dn_momenta(c, 1, c->r, (T*)nullptr, (uint32_t)RNG_FINDEPS);
+  if (rc) return rc;
+  rc = dn_fill_caches(c);
+  if (rc) return rc;
+  rc = dn_prepare_w(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_d_fe_begin<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q, c->dn_active);
+  HIPCHK(hipGetLastError());
+  const int total = 2 * max_iters + 2;
+  for (int it = 0; it < total; ++it) {
+    rc = dn_step(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_d_fe_iter<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+    if ((it & 7) == 7) {
+      int active = 0;
+      HIPCHK(hipMemcpyAsync(&active, c->dn_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (active <= 0) break;
+    }
+  }
+  hipLaunchKernelGGL((k_d_fe_end<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->eps_nom, c->eps_cur, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
+  c->eps_scalar = false;
   return AHMC_OK;
 }

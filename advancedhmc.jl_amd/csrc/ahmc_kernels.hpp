@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_adapt_wv(AdaptP<T> a) {
 // standard normals of the momentum draws of `n_trans` consecutive transitions: element d of chain c
 // at transition kt = Box–Muller half (d & 1) of Philox block (chain, iteration+kt, MOMENTUM, d >> 1)
 template <class T>
-__global__ __launch_bounds__(256) void k_normals(KP<T> p, T* __restrict__ out, int n_trans) {
+__global__ __launch_bounds__(256) void k_normals(KP<T> p, T* __restrict__ out, int n_trans, uint32_t purpose) {
   const int64_t pairs_per_chain = (p.D + 1) / 2;
   const int64_t total = pairs_per_chain * p.N * n_trans;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_normals(KP<T> p, T* __restrict__ out, i
     Rng rng = make_rng(p, c);
     rng.iter = p.iteration + (uint32_t)kt;
     double a, b;
-    rng.normal_pair(RNG_MOMENTUM, (uint32_t)pair, a, b);
+    rng.normal_pair(purpose, (uint32_t)pair, a, b);
     T* dst = out + (kt * p.N + c) * p.D + 2 * pair;
     dst[0] = (T)a;
     if (2 * pair + 1 < p.D) dst[1] = (T)b;

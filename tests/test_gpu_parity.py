@@ -355,6 +355,14 @@ def test_dense_transitions(hip, oracle, rng, metric, target):
             assert sg["tree_depth"].max() >= 3
         for e in (g, o):
             e.set_position(o.phasepoint().theta)
+    # find_good_stepsize (src/trajectory.jl:768-837) as a state machine over global steps; the point survives it
+    z_before = g.phasepoint()
+    eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
+    assert np.mean(eg == eo) >= 0.99 and len(np.unique(eo)) > 1
+    z_after = g.phasepoint()
+    np.testing.assert_array_equal(z_before.theta, z_after.theta)
+    np.testing.assert_array_equal(z_before.r, z_after.r)
+    np.testing.assert_array_equal(z_before.lp.value, z_after.lp.value)
 
 
 def test_dense_bulk_sample_and_stepsize_adaptation(hip, rng):
