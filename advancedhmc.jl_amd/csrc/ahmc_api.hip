@@ -130,13 +130,16 @@ struct Ctx : CtxBase {
   int* dn_list = nullptr;
   size_t dn_slots = 0, dn_batch_elems = 0;
   int64_t dn_global_steps = 0, dn_chain_steps = 0;
+  // WelfordCov of the shared dense metric: μ (D) [+ batch mean + column-sum partials], M, batch scatter, estimate
+  T *wc_mu = nullptr, *wc_M = nullptr, *wc_S = nullptr, *wc_cov = nullptr;
+  int64_t wc_n = 0;
 
   ~Ctx() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g};
+                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -275,8 +278,6 @@ int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
   if (kind == AHMC_METRIC_DENSE) {
     if (!minv) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: M⁻¹ pointer is NULL");
     if (n != c->D * c->D) return fail(c, AHMC_ERR_ARGUMENT, "AxesMismatch: dense M⁻¹ must have D*D elements");
-    if (c->adapt_kind == AHMC_ADAPT_MASSMATRIX || c->adapt_kind == AHMC_ADAPT_NAIVE || c->adapt_kind == AHMC_ADAPT_STAN)
-      return fail(c, AHMC_ERR_UNSUPPORTED, "mass-matrix adaptation of a DenseEuclideanMetric is not implemented");
     return dn_set_metric(c, minv);
   }
   if (kind != AHMC_METRIC_DIAG) return fail(c, AHMC_ERR_ARGUMENT, "set_metric: unknown metric kind");
@@ -517,8 +518,6 @@ int reset_accum(Ctx<T>* c) {
 
 template <class T>
 int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
-  if (c->metric_kind == AHMC_METRIC_DENSE && (kind == AHMC_ADAPT_MASSMATRIX || kind == AHMC_ADAPT_NAIVE || kind == AHMC_ADAPT_STAN))
-    return fail(c, AHMC_ERR_UNSUPPORTED, "mass-matrix adaptation of a DenseEuclideanMetric is not implemented (StepSizeAdaptor is)");
   c->adapt_kind = kind;
   c->da_delta = delta;
   c->stan_init = ib; c->stan_term = tb; c->stan_window = ws;
@@ -543,6 +542,9 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
     a.eps_nom = c->eps_nom;
     hipLaunchKernelGGL((k_adapt_da<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
+  }
+  if (c->metric_kind == AHMC_METRIC_DENSE && kind != AHMC_ADAPT_STEPSIZE) {  // WelfordCov (src/AdvancedHMC.jl:116-118)
+    if ((rc = dn_cov_init(c))) return rc;
   }
   // WelfordVar{T}(size(metric); var = copy(M⁻¹)) per chain (src/AdvancedHMC.jl:113-115)
   if (c->metric_kind == AHMC_METRIC_DIAG && kind != AHMC_ADAPT_STEPSIZE) {
@@ -585,21 +587,22 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
   if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
   const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
   const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
+  const bool has_cov = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DENSE;  // WelfordCov
   bool do_push = false, do_update = false, wv_reset = false, da_reset = false;
   if (c->adapt_kind == AHMC_ADAPT_STAN) {
     if (i == 1) c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);  // initialize!
     c->stan_i += 1;  // adapt!(tp::StanHMCAdaptor, ...) (stan_adaptor.jl:137-159)
     const bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
     const bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
-    if (in_window && has_mm) {
+    if (in_window && (has_mm || has_cov)) {
       do_push = true;
       do_update = window_end;
     }
     if (window_end) {
       da_reset = true;
-      wv_reset = has_mm;
+      wv_reset = has_mm || has_cov;
     }
-  } else if (has_mm) {
+  } else if (has_mm || has_cov) {
     do_push = true;
     do_update = true;
   }
@@ -623,6 +626,19 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     hipLaunchKernelGGL((k_adapt_da<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     c->eps_scalar = false;
+  }
+  if (has_cov && (do_push || wv_reset)) {
+    const T* th = c->th;
+    if (th_ext) {  // caller-supplied θ
+      if (!c->ext_th) { int rc2 = dev_alloc(c, &c->ext_th, (size_t)a.DN); if (rc2) return rc2; }
+      HIPCHK(hipMemcpyAsync(c->ext_th, th_ext, sizeof(T) * a.DN, hipMemcpyDefault, c->stream));
+      th = c->ext_th;
+    }
+    int rc2 = AHMC_OK;
+    if (do_push) rc2 = dn_cov_push(c, th);
+    if (!rc2 && do_update) rc2 = dn_cov_update(c);
+    if (!rc2 && wv_reset) rc2 = dn_cov_init(c);
+    if (rc2) return rc2;
   }
   if (has_mm && (do_push || wv_reset)) {
     if (do_push) c->wv_n += 1;

@@ -928,4 +928,110 @@ __global__ __launch_bounds__(256) void k_d_fe_end(KP<T> p, DP<T> q) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// WelfordCov behind the shared DenseEuclideanMetric (src/adaptation/massmatrix.jl:283-340).  The oracle pushes the
+// N chains' positions one after another; here one adapt! folds the whole batch in at once (Chan et al.):
+//   m_b = mean_c x_c,  S_b = Σ_c (x_c − m_b)(x_c − m_b)ᵀ  (a rank-N update on the MFMA units),
+//   δ = m_b − μ,  M += S_b + δδᵀ·n·N/(n+N),  μ += δ·N/(n+N),  n += N.
+// ------------------------------------------------------------------------------------------------
+constexpr int COV_SLICES = 64;
+template <class T>
+__global__ __launch_bounds__(256) void k_d_colsum_partial(const T* __restrict__ X, T* __restrict__ partial, int D, int64_t N) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sl = blockIdx.y;
+  if (d >= D) return;
+  const int64_t per = (N + COV_SLICES - 1) / COV_SLICES;
+  const int64_t n0 = sl * per, n1 = n0 + per < N ? n0 + per : N;
+  T s = 0;
+  for (int64_t n = n0; n < n1; ++n) s += X[d + n * D];
+  partial[(int64_t)sl * D + d] = s;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_colsum_final(const T* __restrict__ partial, T* __restrict__ mean, int D, int64_t N) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  T s = 0;
+  for (int sl = 0; sl < COV_SLICES; ++sl) s += partial[(int64_t)sl * D + d];  // fixed order
+  mean[d] = s / (T)N;
+}
+// S (D,D) = Σ_n (x_n − m)(x_n − m)ᵀ: 64×64 tile per workgroup, K = the N chains, 2×2 MFMA tiles per wave
+template <class T>
+__global__ __launch_bounds__(256) void k_dsyrk(const T* __restrict__ X, const T* __restrict__ mean, T* __restrict__ S, int D, int64_t N) {
+  __shared__ T As[GB_K][GB_M + GB_PAD];
+  __shared__ T Bs[GB_K][GB_N + GB_PAD];
+  using M = Mfma<T>;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
+  const int wm = (w & 1) * 32, wn = (w >> 1) * 32;
+  typename M::acc_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = typename M::acc_t{0, 0, 0, 0};
+  const int ai = (tid & 31) * 2, ak = tid >> 5;  // rows ai, ai+1 of chains ak and ak+8 (both operand tiles)
+  T ma[2], mb[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    ma[e] = m0 + ai + e < D ? mean[m0 + ai + e] : T(0);
+    mb[e] = n0 + ai + e < D ? mean[n0 + ai + e] : T(0);
+  }
+  for (int64_t k0 = 0; k0 < N; k0 += GB_K) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t n = k0 + ak + 8 * q;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ia = m0 + ai + e, ib = n0 + ai + e;
+        As[ak + 8 * q][ai + e] = (n < N && ia < D) ? X[ia + n * D] - ma[e] : T(0);
+        Bs[ak + 8 * q][ai + e] = (n < N && ib < D) ? X[ib + n * D] - mb[e] : T(0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GB_K / 4; ++ks) {
+      const int kq = ks * 4 + (lane >> 4), l16 = lane & 15;
+      const T a0 = As[kq][wm + l16], a1 = As[kq][wm + 16 + l16];
+      const T b0 = Bs[kq][wn + l16], b1 = Bs[kq][wn + 16 + l16];
+      acc[0][0] = M::mma(a0, b0, acc[0][0]);
+      acc[0][1] = M::mma(a0, b1, acc[0][1]);
+      acc[1][0] = M::mma(a1, b0, acc[1][0]);
+      acc[1][1] = M::mma(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int col = n0 + wn + tj * 16 + (lane & 15);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = m0 + wm + ti * 16 + M::row(lane, v);
+        if (row < D && col < D) S[row + (int64_t)col * D] = acc[ti][tj][v];
+      }
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_cov_combine(T* __restrict__ Mc, const T* __restrict__ mu, const T* __restrict__ mb, const T* __restrict__ Sb,
+                                                       T n, T nb, int D) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)D * D) return;
+  const int i = (int)(idx % D), j = (int)(idx / D);
+  const T di = mb[i] - mu[i], dj = mb[j] - mu[j];
+  Mc[idx] = Mc[idx] + Sb[idx] + di * dj * (n * nb / (n + nb));
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_d_cov_mean(T* __restrict__ mu, const T* __restrict__ mb, T n, T nb, int D) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < D) mu[d] = mu[d] + (mb[d] - mu[d]) * (nb / (n + nb));
+}
+// get_estimation(wc) (:333-340): n/((n+5)(n−1))·M + 10⁻³·5/(n+5)·I
+template <class T>
+__global__ __launch_bounds__(256) void k_d_cov_estimate(const T* __restrict__ Mc, T* __restrict__ cov, T n, int D) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)D * D) return;
+  const int i = (int)(idx % D), j = (int)(idx / D);
+  cov[idx] = n / ((n + 5) * (n - 1)) * Mc[idx] + (i == j ? T(1e-3) * (5 / (n + 5)) : T(0));
+}
+
 }  // namespace ahmc

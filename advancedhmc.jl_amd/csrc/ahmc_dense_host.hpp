@@ -411,3 +411,46 @@ int dn_find_eps(Ctx<T>* c, double init_eps, int max_iters) {
   c->eps_scalar = false;
   return AHMC_OK;
 }
+
+// ---- WelfordCov adaptation of the shared dense metric (see ahmc_dense.hpp) ----
+template <class T>
+int dn_cov_init(Ctx<T>* c) {
+  const size_t D = (size_t)c->D;
+  if (!c->wc_M) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->wc_M), sizeof(T) * D * D));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->wc_S), sizeof(T) * D * D));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->wc_cov), sizeof(T) * D * D));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->wc_mu), sizeof(T) * D * (2 + COV_SLICES)));
+  }
+  HIPCHK(hipMemsetAsync(c->wc_M, 0, sizeof(T) * D * D, c->stream));
+  HIPCHK(hipMemsetAsync(c->wc_mu, 0, sizeof(T) * D, c->stream));
+  c->wc_n = 0;
+  return AHMC_OK;
+}
+template <class T>
+int dn_cov_push(Ctx<T>* c, const T* th) {
+  const int D = (int)c->D;
+  T* mu = c->wc_mu;
+  T* mb = c->wc_mu + D;
+  T* partial = c->wc_mu + 2 * D;
+  hipLaunchKernelGGL((k_d_colsum_partial<T>), dim3((unsigned)((D + 255) / 256), COV_SLICES), dim3(256), 0, c->stream, th, partial, D, c->N);
+  hipLaunchKernelGGL((k_d_colsum_final<T>), dim3((unsigned)((D + 255) / 256)), dim3(256), 0, c->stream, partial, mb, D, c->N);
+  const unsigned tb = (unsigned)((D + GB_M - 1) / GB_M);
+  hipLaunchKernelGGL((k_dsyrk<T>), dim3(tb, tb), dim3(256), 0, c->stream, th, mb, c->wc_S, D, c->N);
+  const T n = (T)c->wc_n, nb = (T)c->N;
+  hipLaunchKernelGGL((k_d_cov_combine<T>), dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, c->stream, c->wc_M, mu, mb, c->wc_S, n, nb, D);
+  hipLaunchKernelGGL((k_d_cov_mean<T>), dim3((unsigned)((D + 255) / 256)), dim3(256), 0, c->stream, mu, mb, n, nb, D);
+  HIPCHK(hipGetLastError());
+  c->wc_n += c->N;
+  return AHMC_OK;
+}
+// update!(wc) + update(h, adaptor): M⁻¹ ← estimate, new Cholesky factor / U⁻¹ (host, at window ends)
+template <class T>
+int dn_cov_update(Ctx<T>* c) {
+  if (c->wc_n < c->wv_nmin) return AHMC_OK;
+  const int D = (int)c->D;
+  hipLaunchKernelGGL((k_d_cov_estimate<T>), dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, c->stream, c->wc_M, c->wc_cov, (T)c->wc_n, D);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return dn_set_metric(c, c->wc_cov);
+}

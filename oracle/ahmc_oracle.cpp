@@ -782,6 +782,10 @@ struct Ctx : CtxBase {
   std::vector<T> wv_mu, wv_M, wv_var;
   int var_estimator = AHMC_VAR_WELFORD;  // WelfordVar or NutpieVar (massmatrix.jl:160-250)
   std::vector<T> wg_mu, wg_M;             // NutpieVar: the gradient estimator's Welford state
+  // WelfordCov (massmatrix.jl:283-340) behind a DenseEuclideanMetric.  The metric is shared by all chains (this
+  // engine's extension), so is the estimator: every adapt! pushes the N chains' positions one after another.
+  int64_t wc_n = 0;
+  std::vector<T> wc_mu, wc_M, wc_cov;
   int stan_init = 75, stan_term = 50, stan_window = 25;
   int64_t stan_i = 0;
   StanWindows windows;
@@ -1211,10 +1215,42 @@ void wv_update(Ctx<T>* c) {  // update! (:60-62) + get_estimation (:152-157)
 }
 
 template <class T>
+void wc_reset(Ctx<T>* c) {  // reset!(wc) (massmatrix.jl:316-321)
+  c->wc_n = 0;
+  std::fill(c->wc_mu.begin(), c->wc_mu.end(), T(0));
+  std::fill(c->wc_M.begin(), c->wc_M.end(), T(0));
+}
+template <class T>
+void wc_push(Ctx<T>* c, const T* th_ext) {  // push!(wc, s) (:323-331) for s = each chain's position in turn
+  const int64_t D = c->D;
+  std::vector<T> delta(D);
+  for (int64_t ch = 0; ch < c->N; ++ch) {
+    const T* s = (th_ext ? th_ext : c->th.data()) + ch * D;
+    c->wc_n += 1;
+    const T n = (T)c->wc_n;
+    for (int64_t d = 0; d < D; ++d) {
+      delta[d] = s[d] - c->wc_mu[d];
+      c->wc_mu[d] = c->wc_mu[d] + delta[d] / n;
+    }
+    for (int64_t j = 0; j < D; ++j)
+      for (int64_t i2 = 0; i2 < D; ++i2) c->wc_M[i2 + j * D] += (s[i2] - c->wc_mu[i2]) * delta[j];  // M + (s − μ) δᵀ
+  }
+}
+template <class T>
+void wc_update(Ctx<T>* c) {  // update! + get_estimation (:333-340): n/((n+5)(n−1))·M + 10⁻³·5/(n+5)·I
+  if (c->wc_n < c->wv_nmin) return;
+  const T n = (T)c->wc_n, e = T(1e-3);
+  const int64_t D = c->D;
+  for (int64_t j = 0; j < D; ++j)
+    for (int64_t i2 = 0; i2 < D; ++i2) c->wc_cov[i2 + j * D] = n / ((n + 5) * (n - 1)) * c->wc_M[i2 + j * D] + (i2 == j ? e * (5 / (n + 5)) : T(0));
+}
+
+template <class T>
 int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr, const T* g_ext = nullptr) {  // src/sampler.jl:72-90
   if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
   const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
   const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
+  const bool has_cov = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DENSE;
   if (has_mm && c->var_estimator == AHMC_VAR_NUTPIE && th_ext && !g_ext)  // massmatrix.jl:234-236
     return fail(c, AHMC_ERR_ARGUMENT, "`NutpieVar` adaptation requires position and gradient information!");
   if (i == 1 && c->adapt_kind == AHMC_ADAPT_STAN) {  // initialize! (stan_adaptor.jl:105-115)
@@ -1229,13 +1265,19 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
       wv_push(c, th_ext, g_ext);
       if (window_end) wv_update(c);
     }
+    if (in_window && has_cov) {
+      wc_push(c, th_ext);
+      if (window_end) wc_update(c);
+    }
     if (window_end) {
       da_reset(c);
       if (has_mm) wv_reset(c);
+      if (has_cov) wc_reset(c);
     }
   } else {
     if (has_ss) da_adapt(c, alpha_ext);  // NaiveHMCAdaptor: ssa then pc (Adaptation.jl:52-60)
     if (has_mm) { wv_push(c, th_ext, g_ext); wv_update(c); }
+    if (has_cov) { wc_push(c, th_ext); wc_update(c); }
   }
   if (i == n_adapts && has_ss) {  // finalize! (stepsize.jl:55-62): ϵ = exp(x̄)
     for (int64_t k = 0; k < c->N; ++k) c->da_eps[k] = std::exp(c->da_xbar[k]);
@@ -1243,6 +1285,11 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
   // update(h, adaptor), update(κ, adaptor) (src/sampler.jl:3-22)
   if (has_mm) {
     int rc = set_metric(c, AHMC_METRIC_DIAG, c->wv_var.data(), (int64_t)c->wv_var.size());
+    if (rc) return rc;
+  }
+  if (has_cov) {  // update(h, adaptor): DenseEuclideanMetric(getM⁻¹) recomputes the Cholesky factor (metric.jl:104-109)
+    std::vector<T> cov = c->wc_cov;
+    int rc = set_metric(c, AHMC_METRIC_DENSE, cov.data(), (int64_t)cov.size());
     if (rc) return rc;
   }
   if (has_ss) {
@@ -1264,6 +1311,12 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
   c->da_mu.resize(c->N); c->da_xbar.assign(c->N, T(0)); c->da_Hbar.assign(c->N, T(0));
   for (int64_t i = 0; i < c->N; ++i) c->da_mu[i] = std::log(10 * c->da_eps[i]);
   // WelfordVar{T}(size(metric); var = copy(M⁻¹)) per chain (src/AdvancedHMC.jl:113-115)
+  if (c->metric_kind == AHMC_METRIC_DENSE) {  // WelfordCov{T}(size; cov = copy(M⁻¹)) (src/AdvancedHMC.jl:116-118)
+    c->wc_n = 0;
+    c->wc_mu.assign(c->D, T(0));
+    c->wc_M.assign(c->D * c->D, T(0));
+    c->wc_cov = c->minv;
+  }
   if (c->metric_kind == AHMC_METRIC_DIAG) {
     c->wv_n = 0;
     c->wv_mu.assign(c->D * c->N, T(0));

@@ -18,7 +18,10 @@ e = A.Engine(h, N, dtype=dtype, rng=A.PhiloxRNG(0x5EED0004), lib=lib)
 lf = A.Leapfrog(np.full(N, 0.05)); e.set_integrator(lf)
 e.set_position(np.asfortranarray(np.random.default_rng(4).random((D, N))))
 e.find_good_stepsize()
-e.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+if os.environ.get("ADAPTOR") == "stan":  # WelfordCov adaptation of the shared dense metric (M⁻¹ → Σ: short trees)
+    e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(A.DenseEuclideanMetric(minv)), A.StepSizeAdaptor(0.8, lf)))
+else:
+    e.adaptor_init(A.StepSizeAdaptor(0.8, lf))
 k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10)))
 t = time.perf_counter(); e.run(k, n_adapt, n_adapt); e.sync(); print("adaptation %d steps: %.2f s" % (n_adapt, time.perf_counter() - t))
 e.run(k, 4, 0); e.sync()

@@ -394,6 +394,50 @@ def test_dense_bulk_sample_and_stepsize_adaptation(hip, rng):
     np.testing.assert_allclose(var, np.diag(cov), rtol=0.08)
 
 
+def test_dense_covariance_adaptation(hip, oracle, rng):
+    """WelfordCov behind the shared DenseEuclideanMetric (src/adaptation/massmatrix.jl:283-340): batch (Chan) update on
+    the MFMA units == the oracle pushing the chains one after another, on identical (θ, α); then NUTS + StanHMCAdaptor
+    end to end: the adapted M⁻¹ approaches the target covariance and the trees get shorter"""
+    D, N = 12, 96
+    L = np.linalg.cholesky(_spd(D, rng, 6.0))
+    h = A.Hamiltonian(A.DenseEuclideanMetric(np.eye(D)), A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.2))
+    g, o = pair(hip, oracle, h, N, np.float64, lf=lf)
+    for e in (g, o):
+        e.set_position(np.zeros((D, N)))
+        e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(A.DenseEuclideanMetric(np.eye(D))), A.StepSizeAdaptor(0.8, lf)))
+    for i in range(1, 161):
+        th, al = L @ rng.normal(size=(D, N)) + 0.3, rng.random(N)
+        for e in (g, o):
+            e.adapt(i, 160, theta=th, alpha=al)
+        if i in (100, 150, 160):  # window ends of the 160-step schedule fall before these
+            np.testing.assert_allclose(g.get_metric(), o.get_metric(), rtol=1e-9, atol=1e-12, err_msg=f"M⁻¹ at {i}")
+            np.testing.assert_allclose(g.get_stepsize(), o.get_stepsize(), rtol=1e-10)
+    assert np.abs(g.get_metric() - L @ L.T).max() < 0.5 * np.abs(L @ L.T).max()  # a covariance estimate, not I any more
+    # end to end on N(0, Σ)
+    D, N = 16, 1024
+    Sigma = _spd(D, rng, 30.0)
+    h = A.Hamiltonian(A.DenseEuclideanMetric(np.eye(D)), A.DenseGaussian(np.asfortranarray(np.linalg.inv(Sigma))))
+    lf = A.Leapfrog(np.full(N, 0.1))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+    e = A.Engine(h, N, rng=5, lib=hip)
+    e.set_integrator(lf)
+    e.set_position(rng.normal(size=(D, N)))
+    e.find_good_stepsize()
+    e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(A.DenseEuclideanMetric(np.eye(D))), A.StepSizeAdaptor(0.8, lf)))
+    e.run(k, 250, 250)
+    e.run(k, 40, 0)
+    acc = e.accum()
+    np.testing.assert_allclose(e.get_metric(), Sigma, rtol=0.2, atol=0.2)
+    # with M⁻¹ ≈ Σ the sampler sees an isotropic target: short trees at acceptance ≈ δ, right moments
+    assert acc["total_n_steps"] / (40 * N) < 12
+    assert abs(np.mean(e.stats()["acceptance_rate"]) - 0.8) < 0.1
+    n = acc["n_transitions"] * N
+    mean = acc["sum_theta"].sum(axis=1) / n
+    var = acc["sumsq_theta"].sum(axis=1) / n - mean ** 2
+    np.testing.assert_allclose(var, np.diag(Sigma), rtol=0.1)
+
+
 def test_max_depth_and_single_leaf(hip, oracle, rng):
     """max_depth = 1 (one leaf) and a tiny step size that always hits max_depth"""
     D, N = 5, 64
