@@ -384,14 +384,11 @@ __device__ __forceinline__ void vcopy(T* __restrict__ dst, const T* __restrict__
 // (leaf, merges, end of subtree, end of doubling, end of transition, start of the next transition)
 // and publish the signed step of its next leapfrog.  MultinomialTS / SliceTS with
 // GeneralisedNoUTurn; log-domain weights as the reference (src/trajectory.jl:144-206,626-742).
+// Returns the signed step of the chain's next leapfrog (0 = motionless step or idle).  lp_in / lk_in: ℓπ, ℓκ of the
+// point the leapfrog that has just completed arrived at (registers, uniform across the wave).
 template <class T>
-__global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
-  const int lane = threadIdx.x & 63;
-  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= q.n_list) return;
-  const int64_t c = q.list ? q.list[j] : j;
+__device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int64_t c, int lane, T lp_in, T lk_in) {
   DChain<T>& S = q.S[c];
-  if (S.phase == DPH_IDLE) return;
   const int D = p.D;
   const bool slice = p.sampler == 2;
   T* th = p.th() + c * D;
@@ -412,21 +409,19 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
     const T* Wc = dslot(q, p, DS_CUR_W, c);
     T* o_w = dslot(q, p, DS_OTH_W, c);
     for (int d = lane; d < D; d += 64) o_w[d] = Wc[d];
-    if (lane == 0) {
-      S.phase = DPH_RUN;
-      q.es[c] = S.v < 0 ? -S.eps : S.eps;
-    }
-    return;
+    const T e_first = S.v < 0 ? -S.eps : S.eps;
+    if (lane == 0) S.phase = DPH_RUN;
+    return e_first;
   }
   bool start = phase == DPH_START;
-  T lp_start = start ? p.lp()[c] : T(0);  // ℓπ(θ) of the point the next transition starts from
+  T lp_start = lp_in;  // ℓπ(θ) of the point the next transition starts from
   if (!start) {
     resume_draws((uint32_t)it, S.k);
     const T H0 = S.H0, eps = S.eps;
     const int v = S.v, jw = S.jw;
     int leaf = S.leaf;
     const uint32_t nleaf = 1u << jw;
-    const T lp = p.lp()[c], lk = p.lk()[c];
+    const T lp = lp_in, lk = lk_in;
     // ---- leaf (:638-647) ----
     const T ne = lp + lk;
     const T dH = -ne - H0;
@@ -531,7 +526,7 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
       }
       subtree_over = false;  // next leapfrog: same edge, same direction (es unchanged)
     }
-    if (!subtree_over) return;
+    if (!subtree_over) return v > 0 ? eps : -eps;
 
     // ---- top level of the doubling loop (:708-722) ----
     T w_tree = S.w_tree, sa_tree = S.sa_tree, dh_tree = S.dh_tree;
@@ -604,9 +599,8 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
         S.jw = jw + 1;
         S.leaf = 1;
         S.k = ds.k;
-        q.es[c] = vleft ? -eps : eps;
       }
-      return;
+      return vleft ? -eps : eps;
     }
     // ---- Transition(zcand, stats) (:725-741) ----
     {
@@ -648,10 +642,9 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
         if (lane == 0) {
           S.phase = DPH_IDLE;
           S.it = it;
-          q.es[c] = T(0);
           atomicSub(q.n_active, 1);
         }
-        return;
+        return T(0);
       }
       start = true;
       lp_start = cand_lp;  // (lane 0 has just stored it; the other lanes must not re-read it)
@@ -704,7 +697,58 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q) {
       S.k = ds.k;
       S.it = it;
       S.phase = q.dense_metric ? DPH_WARM : DPH_RUN;
-      q.es[c] = q.dense_metric ? T(0) : (vleft ? -eps : eps);
+    }
+    return q.dense_metric ? T(0) : (vleft ? -eps : eps);
+  }
+}
+
+// One global step of the NUTS batch for every listed chain, fused (one wave per chain):
+//   second half of the leapfrog that the GEMMs have just served (k_d_post) → d_tree_advance → first half of the
+//   next leapfrog (k_d_pre).  `do_post` = 0 for the very first call of a batch (no leapfrog in flight yet).
+template <class T>
+__global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= q.n_list) return;
+  const int64_t c = q.list ? q.list[j] : j;
+  if (q.S[c].phase == DPH_IDLE) return;
+  const int D = p.D;
+  T* th = p.th() + c * D;
+  T* r = p.r() + c * D;
+  T* g = p.g() + c * D;
+  T* V = dslot(q, p, DS_CUR_V, c);
+  T* W = q.dense_metric ? dslot(q, p, DS_CUR_W, c) : nullptr;
+  T lp = p.lp()[c], lk = p.lk()[c];
+  if (do_post) {
+    const T e = q.es[c];
+    T s[2] = {0, 0};
+    for (int d = lane; d < D; d += 64) {
+      const T gd = g[d];
+      T rn = r[d], vn;
+      if (e != T(0)) rn = rn - e / 2 * gd;
+      if (W) vn = e != T(0) ? V[d] - e / 2 * W[d] : V[d];
+      else vn = minv ? minv[per_chain ? c * D + d : d] * rn : rn;
+      if (e != T(0) || !W) { r[d] = rn; V[d] = vn; }
+      s[0] += rn * vn;
+      s[1] += th[d] * gd;
+    }
+    wave_allsum2<64>(s[0], s[1]);
+    lk = sanitize(-s[0] / 2);
+    if (dense_target) lp = sanitize(-s[1] / 2);
+    if (lane == 0) {
+      p.lk()[c] = lk;
+      if (dense_target) p.lp()[c] = lp;
+    }
+  }
+  const T e = d_tree_advance(p, q, c, lane, lp, lk);
+  if (lane == 0) q.es[c] = e;
+  if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237)
+    for (int d = lane; d < D; d += 64) {
+      const T rh = r[d] - e / 2 * g[d];
+      const T vh = W ? V[d] - e / 2 * W[d] : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
+      r[d] = rh;
+      V[d] = vh;
+      th[d] = th[d] + e * vh;
     }
   }
 }

@@ -333,7 +333,12 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   DP<T> q = make_dp(c);
   q.n_trans = n_trans;
   hipLaunchKernelGGL((k_d_tree_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, c->dn_es, c->dn_active, c->N);
-  hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);  // start of transition 0
+  const bool dm = c->metric_kind == AHMC_METRIC_DENSE, dt = c->target_kind == AHMC_TARGET_DENSE_GAUSS;
+  const T* minv_d = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
+  const int pc = c->minv_per_chain ? 1 : 0;
+  T* Wcur = dm ? c->dn_W + (size_t)DS_CUR_W * c->D * c->N : nullptr;
+  // start of transition 0 (and, for Unit/Diag metrics, the first half of its first leapfrog)
+  hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 0);
   HIPCHK(hipGetLastError());
   // global steps until every chain has finished the batch.  Every CHUNK steps the list of chains
   // still running is compacted and its length read back, so the tail of the batch (few chains with
@@ -347,9 +352,15 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     q.list = list;
     q.n_list = n_list;
     for (int s = 0; s < CHUNK; ++s) {
-      rc = dn_step(c, list, n_list);
+      // one global step = g′ = Pθ′ (or the built-in family's kernel), w′ = M⁻¹g′, then the fused
+      // second-half / tree / first-half kernel: three launches
+      rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, n_list, list) : launch_fill_caches_builtin(c);
       if (rc) return rc;
-      hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c, n_list)), dim3(256), 0, c->stream, p, q);
+      if (dm) {
+        rc = dn_gemm(c, c->dn_minv, c->g, Wcur, n_list, list);
+        if (rc) return rc;
+      }
+      hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c, n_list)), dim3(256), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 1);
     }
     done_steps += CHUNK;
     c->dn_global_steps += CHUNK;

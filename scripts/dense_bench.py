@@ -34,3 +34,7 @@ print("cfg4 dense D=%d N=%d %s: %.3e leapfrog/s, %.2f ms/transition, %.1f leapfr
     D, N, dtype.__name__, lfps, dt / n_timed * 1e3, acc["total_n_steps"] / n, acc["n_divergent"] / n, np.median(e.get_stepsize()),
     np.mean(e.stats()["acceptance_rate"])))
 print("MFMA: %.2f TFLOP/s at F_lf = 4·D² flop per chain-leapfrog (two D×D products per step; useful leapfrogs only)" % (lfps * 4 * D * D / 1e12))
+if os.environ.get("EPS_STATS"):
+    eps = e.get_stepsize(); ns = e.stats()["n_steps"]
+    print("eps percentiles 0/0.1/1/50/99/100:", np.percentile(eps, [0, 0.1, 1, 50, 99, 100]))
+    print("n_steps percentiles 50/99/99.9/100:", np.percentile(ns, [50, 99, 99.9, 100]), "chains with n_steps >= 511:", int((ns >= 511).sum()))
