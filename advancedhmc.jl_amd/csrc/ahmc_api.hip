@@ -132,6 +132,8 @@ struct Ctx : CtxBase {
   int64_t dn_global_steps = 0, dn_chain_steps = 0;
   // WelfordCov of the shared dense metric: μ (D) [+ batch mean + column-sum partials], M, batch scatter, estimate
   T *wc_mu = nullptr, *wc_M = nullptr, *wc_S = nullptr, *wc_cov = nullptr;
+  T* stage = nullptr;  // device stage for ahmc_sample(samples_out = host buffer)
+  size_t stage_elems = 0;
   int64_t wc_n = 0;
 
   ~Ctx() override {
@@ -139,7 +141,7 @@ struct Ctx : CtxBase {
     if (stream) (void)hipStreamSynchronize(stream);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov};
+                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -1092,7 +1094,7 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
         reset_done = true;
       }
       const bool adapting = c->adapt_kind != AHMC_ADAPT_NONE && i <= n_adapts;
-      if (cfg->nuts && !adapting && keep && (!so || so_on_device)) {
+      if (cfg->nuts && !adapting && keep) {
         // chains are independent and nothing is adapted any more: run a batch of transitions per
         // launch (no per-transition barrier; see the note on tree-size tails in ahmc_nuts.hpp)
         // (split the remaining transitions evenly: 50 = 13+13+12+12, not 16+16+16+2 — a short
@@ -1100,9 +1102,25 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
         const int64_t left = n_samples - i + 1, nb_left = (left + batch - 1) / batch;
         const int64_t k = (left + nb_left - 1) / nb_left;
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
+        T* dst = so ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
+        T* dev_dst = dst;
+        if (so && !so_on_device) {  // host buffer: the kernel writes the batch's draws into a device stage
+          const size_t need = (size_t)k * c->D * c->N;
+          if (need > c->stage_elems) {
+            if (c->stage) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->stage)); }
+            c->stage = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->stage), need * sizeof(T)));
+            c->stage_elems = need;
+          }
+          dev_dst = c->stage;
+        }
         int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, true,
-                                 (int)k, so ? so + (size_t)(j - 1) * c->D * c->N : nullptr);
+                                 (int)k, dev_dst);
         if (rc) return rc;
+        if (so && !so_on_device) {
+          HIPCHK(hipMemcpyAsync(dst, c->stage, nb * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));  // the stage is reused by the next batch; pageable host memory anyway
+        }
         c->acc_ntrans += k;
         i += k;
         continue;
