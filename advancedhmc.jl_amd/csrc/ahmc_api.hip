@@ -96,7 +96,9 @@ struct Ctx : CtxBase {
   // NUTS scratch
   T* scratch = nullptr;
   size_t scratch_bytes = 0;
-  unsigned int* queue = nullptr;
+  int* order = nullptr;       // chain order for k_nuts (ascending step size), valid while order_valid
+  bool order_valid = false, order_from_work = false;
+  unsigned* order_hist = nullptr;
   T* znorm = nullptr;  // standard normals of the momentum draws of one k_nuts launch
   size_t znorm_elems = 0;
   int32_t* redo = nullptr;  // per-chain "redo in the log domain" flags of the NUTS fast pass
@@ -139,7 +141,7 @@ struct Ctx : CtxBase {
   ~Ctx() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, queue, hmc_H, da_m, da_eps, da_mu, da_xbar,
+    void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
                     dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage};
     for (void* b : bufs)
@@ -217,7 +219,7 @@ KP<T> make_kp(Ctx<T>* c) {
   p.chain_stride = (uint32_t)c->chain_stride;
   p.iteration = (uint32_t)c->iteration;
   p.scratch = c->scratch;
-  p.queue = c->queue;
+  p.order = nullptr;
   p.hmc_H = c->hmc_H;
   return p;
 }
@@ -367,6 +369,19 @@ int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
   return AHMC_OK;
 }
 
+// chain dispatch order of k_nuts (see k_order_* in ahmc_kernels.hpp): asynchronous on the stream
+template <class T>
+int build_order(Ctx<T>* c, int by_work) {
+  if (!c->order_hist) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->order_hist), 65536 * sizeof(unsigned)));
+  HIPCHK(hipMemsetAsync(c->order_hist, 0, 65536 * sizeof(unsigned), c->stream));
+  const unsigned grid = (unsigned)((c->N + 255) / 256);
+  hipLaunchKernelGGL((k_order_hist<T>), dim3(grid), dim3(256), 0, c->stream, c->eps_nom, c->acc_nsteps, by_work, c->order_hist, c->N);
+  hipLaunchKernelGGL((k_order_scan<unsigned>), dim3(1), dim3(1024), 0, c->stream, c->order_hist);
+  hipLaunchKernelGGL((k_order_scatter<T>), dim3(grid), dim3(256), 0, c->stream, c->eps_nom, c->acc_nsteps, by_work, c->order_hist, c->order, c->N);
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
 // fold the finished launch timings into nuts_kernel_ns (synchronises the stream)
 template <class T>
 int flush_nuts_events(Ctx<T>* c) {
@@ -427,6 +442,18 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.n_trans = n_trans;
   p.znorm = c->znorm;
   p.samples_out = samples_dev;
+  static const bool no_order = getenv("AHMC_NUTS_NO_ORDER") != nullptr;
+  if (n_trans > 1 && !c->eps_scalar && !no_order) {
+    // sampling phase: dispatch the chains in ascending step size (longest expected trees first); the
+    // permutation is rebuilt only when the step sizes have changed (host argsort of N floats)
+    if (!c->order_valid) {
+      int rc2 = build_order(c, 0);
+      if (rc2) return rc2;
+      c->order_valid = true;
+      c->order_from_work = false;
+    }
+    p.order = c->order;
+  }
   if (sampler == AHMC_TS_MULTINOMIAL && criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED) {
     if (!no_linw) {
       // fast pass: multinomial weights in the linear domain; chains that came near overflow are
@@ -628,6 +655,7 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     hipLaunchKernelGGL((k_adapt_da<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     c->eps_scalar = false;
+    c->order_valid = false;
   }
   if (has_cov && (do_push || wv_reset)) {
     const T* th = c->th;
@@ -726,7 +754,7 @@ static int32_t create_impl(int32_t device, int32_t dtype, int64_t D, int64_t N, 
     c->st_nsteps = c->ibase; c->st_accept = c->ibase + n; c->st_depth = c->ibase + 2 * n; c->st_numerr = c->ibase + 3 * n;
     c->acc_nsteps = c->lbase; c->acc_ndiv = c->lbase + n;
   }
-  A(&c->queue, 64);
+  A(&c->order, n);
   A(&c->redo, n);
   if (!ok) return bail("ahmc_create: hipMalloc failed (out of device memory?)", AHMC_ERR_RUNTIME);
   (void)hipMemsetAsync(c->th, 0, sizeof(T) * DN, c->stream);
@@ -838,6 +866,7 @@ int32_t ahmc_set_stepsize(ahmc_ctx* ctx, const void* eps, int64_t n) {
     HIPCHK(hipMemcpyAsync(c->eps_cur, c->eps_nom, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->eps_scalar = (n == 1);
+    c->order_valid = false;
     return AHMC_OK;
   });
 }
@@ -1031,6 +1060,7 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->eps_nom, c->eps_cur, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
     c->eps_scalar = false;
+    c->order_valid = false;
     return AHMC_OK;
   });
 }
@@ -1086,6 +1116,19 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
       (void)hipGetLastError();
     }
     const int64_t batch = nuts_batch(c);
+    // Dispatch order by measured work: a better predictor of a chain's tree sizes than its step size is what it
+    // actually did — Σ n_steps per chain of the previous sampling call (still in the accumulators here) or of
+    // this call's first batch (below).  Counting sort on the stream, no host synchronisation.
+    auto order_by_work = [&](bool refresh) -> int {
+      if (!cfg->nuts || dense_engine(c) || !c->order_valid || (c->order_from_work && !refresh) || c->acc_ntrans < 8) return AHMC_OK;
+      int rc2 = build_order(c, 1);
+      if (!rc2) c->order_from_work = true;
+      return rc2;
+    };
+    {
+      int rc2 = order_by_work(true);  // the previous call's counts are the freshest estimate there is
+      if (rc2) return rc2;
+    }
     for (int64_t i = 1; i <= n_samples;) {  // src/sampler.jl:182-228
       const bool keep = !drop_warmup || i > n_adapts;
       if (keep && !reset_done) {
@@ -1123,6 +1166,8 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
         }
         c->acc_ntrans += k;
         i += k;
+        rc = order_by_work(false);  // (first batch of a fresh chain set: from now on schedule by measured work)
+        if (rc) return rc;
         continue;
       }
       int rc = cfg->nuts ? nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, keep)

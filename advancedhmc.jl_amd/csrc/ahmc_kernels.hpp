@@ -59,7 +59,7 @@ struct KP {
   T delta_max;
   int criterion, sampler;
   T* scratch;           // vector slots that do not fit in LDS
-  unsigned int* queue;  // work queue head
+  const int* order;     // k_nuts: chain handled by group slot i (longest expected trees first), or null = identity
   unsigned int n_chunks;
   int n_lds_levels;     // number of vector slots held in LDS (hottest first)
   int32_t* redo;        // per-chain flag: linear-domain weights came near overflow → redo in log domain
@@ -601,6 +601,52 @@ __global__ __launch_bounds__(256) void k_normals(KP<T> p, T* __restrict__ out, i
     dst[0] = (T)a;
     if (2 * pair + 1 < p.D) dst[1] = (T)b;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dispatch order of k_nuts (LPT: chains with the most expected work first).  A counting sort on 16-bit keys,
+// entirely on the stream: key = bin index, smaller bin = earlier.  by_work = 0: ascending step size (the
+// 8 exponent + 8 top mantissa bits of float(ϵ)); by_work = 1: descending Σ n_steps of the previous sampling call.
+// Chains inside one bin land in arbitrary order (atomics) — the order only schedules, results do not depend on it.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ unsigned order_key(const T* eps, const long long* work, int by_work, int64_t i) {
+  if (by_work) {
+    long long w = work[i];
+    return 65535u - (unsigned)(w < 0 ? 0 : (w > 65535 ? 65535 : w));
+  }
+  return (__float_as_uint((float)eps[i]) >> 15) & 0xFFFFu;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_order_hist(const T* eps, const long long* work, int by_work, unsigned* hist, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) atomicAdd(&hist[order_key(eps, work, by_work, i)], 1u);
+}
+template <class U>
+__global__ __launch_bounds__(1024) void k_order_scan(U* hist) {  // exclusive prefix sum of 65536 bins, one block
+  __shared__ unsigned part[1024];
+  const int t = threadIdx.x;
+  unsigned s = 0;
+  for (int k = 0; k < 64; ++k) s += hist[t * 64 + k];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    unsigned v = t >= off ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned base = t ? part[t - 1] : 0u;
+  for (int k = 0; k < 64; ++k) {
+    unsigned h = hist[t * 64 + k];
+    hist[t * 64 + k] = base;
+    base += h;
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_order_scatter(const T* eps, const long long* work, int by_work, unsigned* offs, int* order, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) order[atomicAdd(&offs[order_key(eps, work, by_work, i)], 1u)] = (int)i;
 }
 
 template <class T>

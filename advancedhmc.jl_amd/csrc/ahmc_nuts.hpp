@@ -192,7 +192,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   // per-transition barrier and the tail is paid once per launch.
   const unsigned int chunk = G > 64 ? blockIdx.x : blockIdx.x * nwaves + wib;
   if (chunk >= p.n_chunks) return;
-  const int64_t c = (int64_t)chunk * CPW + gi;
+  // Dispatch order: workgroups start in blockIdx order, so slot i takes chain order[i] — sorted by step size,
+  // smallest ϵ (longest trees) first — and the stragglers of a launch are the cheap chains (LPT scheduling);
+  // lockstep neighbours (G < 64) then also have similar trees.
+  const int64_t slot = (int64_t)chunk * CPW + gi;
+  const int64_t c = slot < p.N ? (p.order ? (int64_t)p.order[slot] : slot) : p.N;
   int64_t cc = c < p.N ? c : 0;  // out-of-range groups shadow chain 0 and never write
   // redo pass: only the chains flagged by the linear-domain pass, from the transition they bailed at
   const int kt0 = p.redo_only ? p.redo[cc] - 1 : 0;
