@@ -99,6 +99,8 @@ struct Ctx : CtxBase {
   int* order = nullptr;       // chain order for k_nuts (ascending step size), valid while order_valid
   bool order_valid = false, order_from_work = false;
   unsigned* order_hist = nullptr;
+  AdaptK<T>* adaptk_dev = nullptr;  // k_nuts MODE 3 arguments
+  bool adapting = false;            // an adaptor is initialised and has not seen its last iteration yet
   T* znorm = nullptr;  // standard normals of the momentum draws of one k_nuts launch
   size_t znorm_elems = 0;
   int32_t* redo = nullptr;  // per-chain "redo in the log domain" flags of the NUTS fast pass
@@ -141,7 +143,7 @@ struct Ctx : CtxBase {
   ~Ctx() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, hmc_H, da_m, da_eps, da_mu, da_xbar,
+    void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
                     dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage};
     for (void* b : bufs)
@@ -399,7 +401,7 @@ int flush_nuts_events(Ctx<T>* c) {
 
 template <class T>
 int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha,
-                    bool accum, int n_trans = 1, T* samples_dev = nullptr) {
+                    bool accum, int n_trans = 1, T* samples_dev = nullptr, const AdaptK<T>* adapt_host = nullptr) {
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
   if (dense_engine(c)) {
     if (sampler != AHMC_TS_MULTINOMIAL && sampler != AHMC_TS_SLICE)
@@ -443,7 +445,8 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.znorm = c->znorm;
   p.samples_out = samples_dev;
   static const bool no_order = getenv("AHMC_NUTS_NO_ORDER") != nullptr;
-  if (n_trans > 1 && !c->eps_scalar && !no_order) {
+  static const bool order_adapt = getenv("AHMC_NUTS_ORDER_ADAPT") ? atoi(getenv("AHMC_NUTS_ORDER_ADAPT")) != 0 : false;  // measured: no gain (a per-transition launch lasts as long as its longest tree)
+  if ((n_trans > 1 || order_adapt) && !c->eps_scalar && !no_order) {
     // sampling phase: dispatch the chains in ascending step size (longest expected trees first); the
     // permutation is rebuilt only when the step sizes have changed (host argsort of N floats)
     if (!c->order_valid) {
@@ -454,7 +457,30 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
     }
     p.order = c->order;
   }
-  if (sampler == AHMC_TS_MULTINOMIAL && criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED) {
+  if (adapt_host) {
+    // warm-up batch: MODE 3 = the log-domain kernel + adapt! after every transition, inside the kernel
+    if (!c->adaptk_dev) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->adaptk_dev), sizeof(AdaptK<T>)));
+    hipLaunchKernelGGL((k_put<AdaptK<T>>), dim3(1), dim3(64), 0, c->stream, *adapt_host, c->adaptk_dev);
+    HIPCHK(hipGetLastError());
+    p.adaptk = c->adaptk_dev;
+    // dispatch by the step sizes at the start of the batch (they move inside it, but slowly)
+    p.order = nullptr;
+    if (!c->eps_scalar && !no_order) {
+      int rc2 = build_order(c, 0);
+      if (rc2) return rc2;
+      p.order = c->order;
+    }
+    if (!no_linw) {  // linear-domain pass, then the log-domain redo pass for the chains it flagged (as MODE 0 → 1)
+      p.redo_only = 0;
+      rc = launch_nuts<T, 3>(c, p, max_depth);
+      if (rc) return rc;
+      p.redo_only = 1;
+      rc = launch_nuts<T, 4>(c, p, max_depth);
+    } else {
+      p.redo_only = 0;
+      rc = launch_nuts<T, 4>(c, p, max_depth);
+    }
+  } else if (sampler == AHMC_TS_MULTINOMIAL && criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED) {
     if (!no_linw) {
       // fast pass: multinomial weights in the linear domain; chains that came near overflow are
       // flagged and redone, from the same counter-based RNG stream, by the log-domain kernel
@@ -548,6 +574,7 @@ int reset_accum(Ctx<T>* c) {
 template <class T>
 int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
   c->adapt_kind = kind;
+  c->adapting = kind != AHMC_ADAPT_NONE;
   c->da_delta = delta;
   c->stan_init = ib; c->stan_term = tb; c->stan_window = ws;
   c->stan_i = 0;
@@ -614,6 +641,7 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
 template <class T>
 int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, const T* alpha_ext = nullptr, const T* g_ext = nullptr) {
   if (c->adapt_kind == AHMC_ADAPT_NONE || i > n_adapts) return AHMC_OK;
+  if (i == n_adapts) c->adapting = false;
   const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
   const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
   const bool has_cov = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DENSE;  // WelfordCov
@@ -700,6 +728,50 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     HIPCHK(hipGetLastError());
     if (wv_reset) c->wv_n = 0;
   }
+  return AHMC_OK;
+}
+
+// A batch of k warm-up transitions i .. i+k-1 with the adaptor's adapt! done inside the kernel (k_nuts MODE 3); the host
+// only mirrors the bookkeeping that is the same for every chain (Stan window counter, Welford count).
+template <class T>
+int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, int64_t n_adapts, bool accum, T* samples_dev) {
+  const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
+  const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
+  if (c->adapt_kind == AHMC_ADAPT_STAN && i == 1) c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);  // initialize!
+  AdaptK<T> a;
+  memset(&a, 0, sizeof(a));
+  a.kind = c->adapt_kind;
+  a.has_ss = has_ss ? 1 : 0;
+  a.has_mm = has_mm ? 1 : 0;
+  a.nutpie = c->var_estimator == AHMC_VAR_NUTPIE ? 1 : 0;
+  a.i0 = i - 1;
+  a.n_adapts = n_adapts;
+  a.stan_i0 = c->stan_i;
+  a.window_start = c->windows.window_start;
+  a.window_end = c->windows.window_end;
+  a.n_splits = (int)std::min<size_t>(c->windows.splits.size(), 24);
+  for (int s2 = 0; s2 < a.n_splits; ++s2) a.splits[s2] = c->windows.splits[(size_t)s2];
+  a.wv_n0 = c->wv_n;
+  a.wv_nmin = c->wv_nmin;
+  a.delta = (T)c->da_delta; a.gamma = T(0.05); a.t0 = T(10); a.kappa = T(0.75);  // stepsize.jl:168-172
+  a.da_m = c->da_m; a.da_eps = c->da_eps; a.da_mu = c->da_mu; a.da_xbar = c->da_xbar; a.da_Hbar = c->da_Hbar;
+  a.wv_mu = c->wv_mu; a.wv_M = c->wv_M; a.wv_var = c->wv_var; a.wg_mu = c->wg_mu; a.wg_M = c->wg_M;
+  a.minv = c->minv; a.sqrt_minv = c->sqrt_minv; a.eps_nom = c->eps_nom;
+  int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, accum, k, samples_dev, &a);
+  if (rc) return rc;
+  for (int kt = 0; kt < k; ++kt) {  // the chain-independent part of adapt!'s state
+    if (c->adapt_kind == AHMC_ADAPT_STAN) {
+      c->stan_i += 1;
+      const bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
+      const bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
+      if (in_window && has_mm) c->wv_n += 1;
+      if (window_end && has_mm) c->wv_n = 0;
+    } else if (has_mm) {
+      c->wv_n += 1;
+    }
+  }
+  if (has_ss) { c->eps_scalar = false; c->order_valid = false; }
+  if (i + k - 1 >= n_adapts) c->adapting = false;
   return AHMC_OK;
 }
 
@@ -1168,6 +1240,21 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
         i += k;
         rc = order_by_work(false);  // (first batch of a fresh chain set: from now on schedule by measured work)
         if (rc) return rc;
+        continue;
+      }
+      static const bool fused_adapt = getenv("AHMC_ADAPT_FUSED") ? atoi(getenv("AHMC_ADAPT_FUSED")) != 0 : true;
+      if (adapting && fused_adapt && cfg->nuts && cfg->sampler == AHMC_TS_MULTINOMIAL && cfg->criterion == AHMC_TC_GENERALISED &&
+          !dense_engine(c) && c->integ_kind != AHMC_INTEGRATOR_TEMPERED && c->target_kind != AHMC_TARGET_EXTERNAL &&
+          (!so || !keep || so_on_device)) {
+        // warm-up in batches too: adapt! runs inside the kernel (k_nuts MODE 3), no per-transition launch
+        const int64_t left = n_adapts - i + 1, nb_left = (left + batch - 1) / batch;
+        const int64_t k = (left + nb_left - 1) / nb_left;
+        const int64_t j = i - (drop_warmup ? n_adapts : 0);
+        T* dst = (so && keep) ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
+        int rc = nuts_adapt_batch(c, cfg, (int)k, i, n_adapts, keep, dst);
+        if (rc) return rc;
+        if (keep) c->acc_ntrans += k;
+        i += k;
         continue;
       }
       int rc = cfg->nuts ? nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, keep)

@@ -37,6 +37,8 @@ int Inst<T, TK>::nuts_occupancy(int G, int E, int mode, size_t smem) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
     if (mode == 0) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 0, TK>, (GG > 64 ? GG : 64), smem);
     else if (mode == 1) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 1, TK>, (GG > 64 ? GG : 64), smem);
+    else if (mode == 3) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 3, TK>, (GG > 64 ? GG : 64), smem);
+    else if (mode == 4) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 4, TK>, (GG > 64 ? GG : 64), smem);
     else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 2, TK>, (GG > 64 ? GG : 64), smem);
   });
   return err == hipSuccess ? occ : 0;
@@ -48,6 +50,8 @@ void Inst<T, TK>::nuts_set_smem(int G, int E, int mode, size_t smem) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
     const void* f = mode == 0   ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 0, TK>)
                     : mode == 1 ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 1, TK>)
+                    : mode == 3 ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 3, TK>)
+                    : mode == 4 ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 4, TK>)
                                 : reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 2, TK>);
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
@@ -60,6 +64,8 @@ void Inst<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t sm
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
     if (mode == 0) hipLaunchKernelGGL((k_nuts<T, GG, EE, 0, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
     else if (mode == 1) hipLaunchKernelGGL((k_nuts<T, GG, EE, 1, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
+    else if (mode == 3) hipLaunchKernelGGL((k_nuts<T, GG, EE, 3, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
+    else if (mode == 4) hipLaunchKernelGGL((k_nuts<T, GG, EE, 4, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
     else hipLaunchKernelGGL((k_nuts<T, GG, EE, 2, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
   });
 }

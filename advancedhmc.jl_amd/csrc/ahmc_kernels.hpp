@@ -3,6 +3,7 @@
 #pragma once
 
 #include "ahmc_device.hpp"
+#include "ahmc_hip.h"
 
 namespace ahmc {
 
@@ -59,6 +60,7 @@ struct KP {
   T delta_max;
   int criterion, sampler;
   T* scratch;           // vector slots that do not fit in LDS
+  const void* adaptk;   // k_nuts MODE 3: AdaptK<T> in device memory (in-kernel adaptation), else null
   const int* order;     // k_nuts: chain handled by group slot i (longest expected trees first), or null = identity
   unsigned int n_chunks;
   int n_lds_levels;     // number of vector slots held in LDS (hottest first)
@@ -110,6 +112,15 @@ __device__ __forceinline__ void load_minv(const KP<T>& p, int64_t c, int d0, T (
 template <class T>
 __device__ __forceinline__ T chain_eps(const KP<T>& p, const Rng& rng, int64_t c) {
   T e0 = p.eps_nom()[c];
+  if (p.lf.kind == 1) {
+    T u = (T)rng.uniform(RNG_JITTER, 0);
+    return e0 * (1 + p.jitter * (2 * u - 1));
+  }
+  return e0;
+}
+
+template <class T>
+__device__ __forceinline__ T chain_eps_from(const KP<T>& p, const Rng& rng, T e0) {  // the same with ϵ0 in a register
   if (p.lf.kind == 1) {
     T u = (T)rng.uniform(RNG_JITTER, 0);
     return e0 * (1 + p.jitter * (2 * u - 1));
@@ -491,6 +502,80 @@ __global__ __launch_bounds__(G > 256 ? G : 256) void k_find_eps(KP<T> p, T* eps_
 // ------------------------------------------------------------------------------------------------
 // adaptation (src/adaptation/*.jl), element-wise over chains / (D,N)
 // ------------------------------------------------------------------------------------------------
+// The adaptation arithmetic, shared by the stand-alone kernels below and by the in-kernel adaptation of
+// k_nuts MODE 3 (ahmc_nuts.hpp).  Floating-point contraction is off inside, so both compile to the same
+// operations and a batched run reproduces the per-iteration one bit for bit.
+template <class T>
+struct DAState {
+  int32_t m;
+  T eps, mu, xbar, Hbar;
+};
+// adapt_stepsize! (src/adaptation/stepsize.jl:178-210)
+template <class T>
+__device__ __forceinline__ void da_step(DAState<T>& s, T alpha, T delta, T gamma, T t0, T kappa) {
+#pragma clang fp contract(off)
+  const int32_t m = s.m + 1;
+  const T eta_H = T(1) / ((T)m + t0);
+  const T Hbar = (T(1) - eta_H) * s.Hbar + eta_H * (delta - jl_min(T(1), alpha));
+  const T x = s.mu - Hbar * (sqrt((T)m) / gamma);
+  const T eta_x = pow((T)m, -kappa);
+  const T xbar = (T(1) - eta_x) * s.xbar + eta_x * x;
+  const T eps = exp(x);
+  if (is_finite(eps)) {  // otherwise the previous (m, ϵ, x̄, H̄) are kept (:199-203)
+    s.m = m;
+    s.eps = eps;
+    s.xbar = xbar;
+    s.Hbar = Hbar;
+  }
+}
+template <class T>
+__device__ __forceinline__ void da_reset(DAState<T>& s) {  // reset!(das) (:40-53)
+  s.m = 0;
+  s.mu = log(10 * s.eps);
+  s.xbar = 0;
+  s.Hbar = 0;
+}
+// push!(wv, s) (src/adaptation/massmatrix.jl:141-149), n = the count after this push
+template <class T>
+__device__ __forceinline__ void welford_push(T& mu, T& M, T x, T n) {
+#pragma clang fp contract(off)
+  const T delta = x - mu;
+  mu = mu + delta / n;
+  M = M + delta * delta * ((n - 1) / n);
+}
+// get_estimation(wv) (:152-157)
+template <class T>
+__device__ __forceinline__ T welford_estimate(T M, T n) {
+#pragma clang fp contract(off)
+  return n / ((n + 5) * (n - 1)) * M + T(1e-3) * (5 / (n + 5));
+}
+
+// In-kernel adaptation (k_nuts MODE 3): everything adapt!(h, κ, adaptor, i, n_adapts, z, α) needs for a batch of
+// consecutive warm-up transitions.  Step sizes and (Diag, per-chain) mass matrices are per chain and the Stan
+// window schedule depends on the iteration index only, so no chain ever needs another chain's data.
+template <class T>
+struct AdaptK {
+  int kind, has_ss, has_mm, nutpie;
+  int64_t i0;        // adaptation iterations done before this launch
+  int64_t n_adapts;
+  int64_t stan_i0;   // StanHMCAdaptor state.i before this launch
+  int64_t window_start, window_end;
+  int n_splits;
+  int64_t splits[24];
+  int64_t wv_n0, wv_nmin;
+  T delta, gamma, t0, kappa;
+  int32_t* da_m;
+  T *da_eps, *da_mu, *da_xbar, *da_Hbar;
+  T *wv_mu, *wv_M, *wv_var, *wg_mu, *wg_M;
+  T *minv, *sqrt_minv, *eps_nom;
+};
+
+// stream-ordered upload of a small argument block (the previous launch may still be reading *dst)
+template <class S>
+__global__ void k_put(S v, S* dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+
 template <class T>
 struct AdaptP {
   int64_t N, DN;
@@ -517,28 +602,11 @@ template <class T>
 __global__ __launch_bounds__(256) void k_adapt_da(AdaptP<T> a) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.N) return;
-  if (a.do_da) {
-    int32_t m = a.da_m[i] + 1;
-    T eta_H = T(1) / ((T)m + a.t0);
-    T Hbar = (T(1) - eta_H) * a.da_Hbar[i] + eta_H * (a.delta - jl_min(T(1), a.alpha[i]));
-    T x = a.da_mu[i] - Hbar * (sqrt((T)m) / a.gamma);
-    T eta_x = pow((T)m, -a.kappa);
-    T xbar = (T(1) - eta_x) * a.da_xbar[i] + eta_x * x;
-    T eps = exp(x);
-    if (is_finite(eps)) {  // otherwise the previous (m, ϵ, x̄, H̄) are kept (:199-203)
-      a.da_m[i] = m;
-      a.da_eps[i] = eps;
-      a.da_xbar[i] = xbar;
-      a.da_Hbar[i] = Hbar;
-    }
-  }
-  if (a.da_reset) {  // reset!(das) (:40-53)
-    a.da_m[i] = 0;
-    a.da_mu[i] = log(10 * a.da_eps[i]);
-    a.da_xbar[i] = 0;
-    a.da_Hbar[i] = 0;
-  }
-  if (a.da_finalize) a.da_eps[i] = exp(a.da_xbar[i]);  // finalize! (:55-62)
+  DAState<T> st{a.da_m[i], a.da_eps[i], a.da_mu[i], a.da_xbar[i], a.da_Hbar[i]};
+  if (a.do_da) da_step(st, a.alpha[i], a.delta, a.gamma, a.t0, a.kappa);
+  if (a.da_reset) da_reset(st);
+  if (a.da_finalize) st.eps = exp(st.xbar);  // finalize! (:55-62)
+  a.da_m[i] = st.m; a.da_eps[i] = st.eps; a.da_mu[i] = st.mu; a.da_xbar[i] = st.xbar; a.da_Hbar[i] = st.Hbar;
   a.eps_nom[i] = a.da_eps[i];
 }
 
@@ -551,22 +619,13 @@ __global__ __launch_bounds__(256) void k_adapt_wv(AdaptP<T> a) {
   if (a.nutpie) { mug = a.wg_mu[k]; Mg = a.wg_M[k]; }
   if (a.do_push) {
     const T n = a.wv_n;
-    T delta = a.th[k] - mu;
-    mu = mu + delta / n;
-    M = M + delta * delta * ((n - 1) / n);
-    if (a.nutpie) {  // push!(nv, z) (:238-243)
-      T dg = a.gr[k] - mug;
-      mug = mug + dg / n;
-      Mg = Mg + dg * dg * ((n - 1) / n);
-    }
+    welford_push(mu, M, a.th[k], n);
+    if (a.nutpie) welford_push(mug, Mg, a.gr[k], n);  // push!(nv, z) (:238-243)
   }
   if (a.do_update) {  // get_estimation (:152-157), only when n >= n_min (host decides)
     const T n = a.wv_n;
-    T var = n / ((n + 5) * (n - 1)) * M + T(1e-3) * (5 / (n + 5));
-    if (a.nutpie) {  // sqrt.(est(θ) ./ est(∇)) (:246-250)
-      T eg = n / ((n + 5) * (n - 1)) * Mg + T(1e-3) * (5 / (n + 5));
-      var = sqrt(var / eg);
-    }
+    T var = welford_estimate(M, n);
+    if (a.nutpie) var = sqrt(var / welford_estimate(Mg, n));  // sqrt.(est(θ) ./ est(∇)) (:246-250)
     a.wv_var[k] = var;
     a.minv[k] = var;
     a.sqrt_minv[k] = sqrt(var);

@@ -136,6 +136,11 @@ struct DrawStream {
 
 // MODE 0: multinomial + generalised, linear-domain weights (the default fast path)
 // MODE 1: multinomial + generalised, log-domain weights (redo pass for chains flagged by MODE 0)
+// MODE 3 / 4: MODE 0 / 1 plus the adaptor's adapt! after every transition, inside the kernel — the warm-up phase in
+//         batches (the host path launches per transition because adapt! needs every transition's α; step sizes
+//         and per-chain mass matrices never need another chain's data, so the kernel can do it itself).  MODE 4 is
+//         the redo pass of MODE 3, as MODE 1 is of MODE 0: a chain that bails out of the linear domain at
+//         transition kt saves its adaptation state and is resumed there.
 // MODE 2: any sampler / criterion chosen at run time, log-domain weights (the run-time variants
 //         cost registers: with them in the fast kernel (32,4) loses a wave per SIMD)
 // Minimum waves per SIMD (register cap): MEASURED, not derived — the compiler left to itself takes 168 / 231 /
@@ -155,8 +160,9 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   int gi = G >= 64 ? 0 : lane64 / G;
   int d0 = lane * E;
   const int NLEV = p.max_depth > 1 ? p.max_depth - 1 : 1;  // pending levels 0 .. NLEV-1
-  constexpr bool LINW = MODE == 0;
+  constexpr bool LINW = MODE == 0 || MODE == 3;
   constexpr bool GENERAL = MODE == 2;
+  constexpr bool ADAPT = MODE >= 3;  // MODE 0 / 1 + adapt!(…) after every transition, inside the kernel (AdaptK)
   const bool strict = GENERAL && p.criterion == 2;
   const int NV = strict ? 3 : 2;  // vectors per pending level: A, RF (, RL)
   const int n_slots = NV * NLEV + NUTS_DORMANT;
@@ -206,6 +212,43 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   load_minv<T, E>(p, cc, d0, minv);
   T th_cur[E];  // the chain's position, carried in registers from one transition to the next
   load_vec<T, E>(th_cur, p.th(), cc * p.D, d0, p.D, T(0));
+  // in-kernel adaptation state (MODE 3): dual averaging of this chain, its nominal step size, the Welford count
+  const AdaptK<T>* ak = ADAPT ? static_cast<const AdaptK<T>*>(p.adaptk) : nullptr;
+  DAState<T> das{0, T(0), T(0), T(0), T(0)};
+  T eps_nom_reg = p.eps_nom()[cc];
+  int64_t wv_n = 0;
+  // what adapt! does at batch-local transition kt2 (the same for every chain): push / update / reset of the variance
+  // estimator and reset of the dual averaging — `adapt` in ahmc_api.hip, stan_adaptor.jl:137-159
+  auto schedule = [&](int kt2, bool& do_push, bool& do_update, bool& wv_reset, bool& dareset) {
+    do_push = do_update = wv_reset = dareset = false;
+    if (ak->kind == AHMC_ADAPT_STAN) {
+      const int64_t si = ak->stan_i0 + kt2 + 1;
+      const bool in_window = si >= ak->window_start && si <= ak->window_end;
+      bool window_end = false;
+      for (int k2 = 0; k2 < ak->n_splits; ++k2) window_end = window_end || ak->splits[k2] == si;
+      if (in_window && ak->has_mm) { do_push = true; do_update = window_end; }
+      if (window_end) { dareset = true; wv_reset = ak->has_mm != 0; }
+    } else if (ak->has_mm) {
+      do_push = true;
+      do_update = true;
+    }
+  };
+  auto save_adapt_state = [&]() {  // dual averaging + nominal step size of this chain (the Welford vectors are always in memory)
+    if (ak->has_ss && lane == 0) {
+      ak->da_m[cc] = das.m; ak->da_eps[cc] = das.eps; ak->da_mu[cc] = das.mu; ak->da_xbar[cc] = das.xbar; ak->da_Hbar[cc] = das.Hbar;
+      ak->eps_nom[cc] = das.eps;
+    }
+  };
+  if constexpr (ADAPT) {
+    if (ak->has_ss) das = DAState<T>{ak->da_m[cc], ak->da_eps[cc], ak->da_mu[cc], ak->da_xbar[cc], ak->da_Hbar[cc]};
+    wv_n = ak->wv_n0;
+    for (int kt2 = 0; kt2 < kt0; ++kt2) {  // redo pass: the Welford count at the transition this chain resumes at
+      bool a1, a2, a3, a4;
+      schedule(kt2, a1, a2, a3, a4);
+      if (a1) wv_n += 1;
+      if (a3) wv_n = 0;
+    }
+  }
 
   for (int kt = 0; kt < p.n_trans; ++kt) {
     // Make the per-lane indices opaque once per transition: otherwise every address and every
@@ -221,7 +264,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     copy_vec(cur.th, th_cur);
     Rng rng = make_rng(p, cc);
     rng.iter = p.iteration + (uint32_t)kt;
-    const T eps = chain_eps(p, rng, cc);
+    const T eps = chain_eps_from(p, rng, eps_nom_reg);
     momentum_from_normals<T, E>(p, p.znorm + (int64_t)kt * p.D * p.N, cc, d0, cur.r);
     fill_caches<T, G, E, TK>(cur, minv, p.tp, lane, d0);
     if (on && kt > 0) store_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D);  // θ0 of this transition (re-integration, redo)
@@ -518,6 +561,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       if (on && redo) {
         // stop here: the log-domain kernel resumes this chain at transition kt (its θ0 is in p.th)
         if (lane == 0) p.redo[ce] = kt + 1;
+        if constexpr (ADAPT) save_adapt_state();  // as of before this transition: the redo pass resumes from it
         active = false;
       } else if (on) {
         if (p.redo_only && lane == 0 && kt == p.n_trans - 1) p.redo[ce] = 0;
@@ -539,9 +583,68 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         accumulate<T, E>(p, ce, d0, lane, zc.th, na_tree, numerical ? 1 : 0);
         if (p.samples_out) store_vec<T, E>(zc.th, p.samples_out + (int64_t)kt * p.D * p.N, ce * p.D, d0, p.D);
         copy_vec(th_cur, zc.th);
+        if constexpr (ADAPT) {
+          // adapt!(h, κ, adaptor, i, n_adapts, z, α) + update(h/κ, adaptor) (src/sampler.jl:72-90, :3-22) for this chain —
+          // the same decisions and the same arithmetic as the host path (`adapt` in ahmc_api.hip, k_adapt_da / k_adapt_wv)
+          const int64_t i = ak->i0 + kt + 1;
+          bool do_push, do_update, wv_reset, dareset;
+          schedule(kt, do_push, do_update, wv_reset, dareset);
+          if (ak->has_ss) {
+            da_step(das, sa_tree / (T)na_tree, ak->delta, ak->gamma, ak->t0, ak->kappa);
+            if (dareset) da_reset(das);
+            if (i == ak->n_adapts) das.eps = exp(das.xbar);  // finalize! (stepsize.jl:55-62)
+            eps_nom_reg = das.eps;                           // update(κ, adaptor): nominal step size ← getϵ
+          }
+          if (ak->has_mm && (do_push || wv_reset)) {
+            if (do_push) wv_n += 1;
+            const T n = (T)wv_n;
+            T mu[E], M2[E], mug[E], Mg[E];
+            load_vec<T, E>(mu, ak->wv_mu, ce * p.D, d0, p.D, T(0));
+            load_vec<T, E>(M2, ak->wv_M, ce * p.D, d0, p.D, T(0));
+            if (ak->nutpie) {
+              load_vec<T, E>(mug, ak->wg_mu, ce * p.D, d0, p.D, T(0));
+              load_vec<T, E>(Mg, ak->wg_M, ce * p.D, d0, p.D, T(0));
+            }
+            if (do_push) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                welford_push(mu[e], M2[e], zc.th[e], n);
+                if (ak->nutpie) welford_push(mug[e], Mg[e], zc.g[e], n);
+              }
+            }
+            if (do_update && wv_n >= ak->wv_nmin) {  // update!(ve): M⁻¹ ← estimate, √M⁻¹ recomputed (metric.jl:61-63)
+              T var[E], sq[E];
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                T v2 = welford_estimate(M2[e], n);
+                if (ak->nutpie) v2 = sqrt(v2 / welford_estimate(Mg[e], n));
+                var[e] = v2;
+                sq[e] = sqrt(v2);
+                if (d0 + e < p.D) minv[e] = v2;
+              }
+              store_vec<T, E>(var, ak->wv_var, ce * p.D, d0, p.D);
+              store_vec<T, E>(var, ak->minv, ce * p.D, d0, p.D);
+              store_vec<T, E>(sq, ak->sqrt_minv, ce * p.D, d0, p.D);
+            }
+            if (wv_reset) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) { mu[e] = 0; M2[e] = 0; mug[e] = 0; Mg[e] = 0; }
+              wv_n = 0;
+            }
+            store_vec<T, E>(mu, ak->wv_mu, ce * p.D, d0, p.D);
+            store_vec<T, E>(M2, ak->wv_M, ce * p.D, d0, p.D);
+            if (ak->nutpie) {
+              store_vec<T, E>(mug, ak->wg_mu, ce * p.D, d0, p.D);
+              store_vec<T, E>(Mg, ak->wg_M, ce * p.D, d0, p.D);
+            }
+          }
+        }
       }
     }
   }  // transitions of this launch
+  if constexpr (ADAPT) {
+    if (active) save_adapt_state();
+  }
 #undef S_W
 #undef S_SA
 #undef S_DH
