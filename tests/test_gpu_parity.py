@@ -603,6 +603,42 @@ def test_bulk_sample_equals_stepwise(hip, rng):
     np.testing.assert_allclose(acc["sumsq_theta"], (out ** 2).sum(axis=2), rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("case", ["stan", "stan_nutpie", "naive", "stepsize", "massmatrix", "stan_far_start", "stan_jitter_f32"])
+def test_fused_warmup_matches_stepwise(hip, rng, case):
+    """Warm-up in batches (adapt! inside k_nuts, MODE 3 / 4) == transition + adapt! per iteration, bit for bit:
+    every adaptor kind, NutpieVar, a start 30σ out (the linear-domain pass bails and the log-domain redo pass resumes
+    mid-batch with the chain's adaptation state), jittered step sizes in Float32"""
+    D, N, n_adapts, n = 8, 256, 160, 170  # Stan windows of 160 warm-up steps: one metric update, at 100
+    dtype = np.float32 if case.endswith("f32") else np.float64
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.DiagGaussian(np.zeros(D), 0.5 + np.arange(D) / 4.0))
+    lf = A.JitteredLeapfrog(np.full(N, 0.2), 0.3) if "jitter" in case else A.Leapfrog(np.full(N, 0.2))
+    pc = A.NutpieVar(metric) if "nutpie" in case else A.MassMatrixAdaptor(metric)
+    ssa = A.StepSizeAdaptor(0.8, lf)
+    ad = {"stan": A.StanHMCAdaptor(pc, ssa), "naive": A.NaiveHMCAdaptor(pc, ssa), "stepsize": ssa, "massmatrix": pc}[case.split("_")[0]]
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+    th = rng.normal(size=(D, N)) + (30.0 if "far" in case else 0.0)
+    a = A.Engine(h, N, dtype=dtype, rng=8, lib=hip)
+    b = A.Engine(h, N, dtype=dtype, rng=8, lib=hip)
+    for e in (a, b):
+        e.set_integrator(lf)
+        e.set_position(th)
+        e.adaptor_init(ad)
+    a.run(k, n, n_adapts)
+    for i in range(1, n + 1):
+        b.transition(k)
+        b.adapt(i, n_adapts)
+    np.testing.assert_array_equal(a.theta(), b.theta())
+    np.testing.assert_array_equal(a.get_stepsize(), b.get_stepsize())
+    ma, mb = a.get_metric(), b.get_metric()
+    np.testing.assert_array_equal(ma, mb)
+    sa, sb = a.stats(), b.stats()
+    for f in ("n_steps", "acceptance_rate", "hamiltonian_energy", "tree_depth"):
+        np.testing.assert_array_equal(sa[f], sb[f])
+    if case.split("_")[0] not in ("stepsize",):
+        assert np.abs(ma - 1).max() > 0.05  # the metric did adapt
+
+
 def test_same_rng_vector_gives_identical_chains(hip, rng):
     """test/sampler-vec.jl:69-80: a vector of identically seeded RNGs ⇒ all chains bit-identical"""
     D, N = 5, 5
