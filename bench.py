@@ -58,6 +58,21 @@ def measured_traffic(D, N):
         return None
 
 
+def measured_issue(D, N):
+    """What actually bounds the fused kernel: VALU issue.  SQ_ACTIVE_INST_VALU / SIMD cycles and instructions per
+    leapfrog from the committed PMC passes (profiles/r1_sq_counters.json), for the workload they were taken on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_sq_counters.json")) as f:
+            d = json.load(f)["derived"]
+        if (D, N) != (128, 65536):
+            return None
+        return {"valu_busy_fraction_of_simd_cycles": d["valu_busy_fraction_of_simd_cycles"],
+                "valu_instructions_per_leapfrog": d["valu_instructions_per_leapfrog"],
+                "mean_waves_per_simd": d["mean_waves_per_simd"], "source": "profiles/r1_sq_counters.json"}
+    except Exception:
+        return None
+
+
 def build_engine(A, lib, D, N, seed, chain_offset, stream=0, device=0):
     metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
     h = A.Hamiltonian(metric, A.IsoGaussian(D))
@@ -242,6 +257,9 @@ def main():
                 "launches": n_launches, "transitions_per_launch": args.steps / n_launches,
                 "timed_region_ms_on_stream": kernel_ms,
                 "leapfrogs_per_launch": n_leap / n_launches,
+                "note": "state-through-memory model of SURVEY 8d: a fused kernel keeps the trajectory in registers/LDS, so frac > 1 "
+                        "is expected; the kernel is VALU-issue bound (see issue_bound)",
+                "issue_bound": measured_issue(D, N),
             },
         }
         if not args.no_cpu_baseline:
