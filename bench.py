@@ -73,10 +73,10 @@ def measured_issue(D, N):
         return None
 
 
-def build_engine(A, lib, D, N, seed, chain_offset, stream=0, device=0):
+def build_engine(A, lib, D, N, seed, chain_offset, stream=0, device=0, dtype=np.float64):
     metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
     h = A.Hamiltonian(metric, A.IsoGaussian(D))
-    eng = A.Engine(h, N, dtype=np.float64, rng=A.PhiloxRNG(seed, chain_offset), lib=lib, device=device, stream=stream)
+    eng = A.Engine(h, N, dtype=dtype, rng=A.PhiloxRNG(seed, chain_offset), lib=lib, device=device, stream=stream)
     lf = A.Leapfrog(np.full(N, 0.1))
     eng.set_integrator(lf)
     th0 = np.random.default_rng(seed + chain_offset).random((D, N))
@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--cpu-chains", type=int, default=0, help="0 = 128 per host core, capped at --chains")
     ap.add_argument("--cpu-steps", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64", help="f64 = the reference default and the headline; f32 = what the "
+                    "reference's CUDA smoke test uses (test/CUDA/cuda.jl:18), reported for information")
     ap.add_argument("--ess", type=int, default=0, help="after the timed region: K more transitions with the draws kept in HBM, "
                     "ESS/sec (min over dimensions, Geyer estimator, 256-chain subset) reported under config.ess")
     args = ap.parse_args()
@@ -158,7 +160,8 @@ def main():
     lib = A.load_hip_library()  # raises if the HIP engine is not built: no fallback
     D, N = args.dim, args.chains
     stream = torch.cuda.Stream(device=local_rank)
-    eng, kernel = build_engine(A, lib, D, N, args.seed, rank * N, stream=stream.cuda_stream, device=local_rank)
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    eng, kernel = build_engine(A, lib, D, N, args.seed, rank * N, stream=stream.cuda_stream, device=local_rank, dtype=np_dtype)
 
     def barrier():
         eng.sync()
@@ -191,7 +194,7 @@ def main():
         # ESS/sec (BASELINE.json's secondary metric): draws (K, N, D) written by k_nuts straight into HBM
         from ahmc_amd.diagnostics import ess as ess_fn
 
-        draws = torch.empty((args.ess, N, D), dtype=torch.float64, device=f"cuda:{local_rank}")
+        draws = torch.empty((args.ess, N, D), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device=f"cuda:{local_rank}")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         eng.run(kernel, args.ess, 0, samples_out=draws.data_ptr())
@@ -220,7 +223,7 @@ def main():
     total_leap = float(tn[0].item())
 
     if rank == 0:
-        B_lf = algorithmic_bytes_per_leapfrog(D, True, 8)
+        B_lf = algorithmic_bytes_per_leapfrog(D, True, 8 if args.dtype == "f64" else 4)
         per_launch_s = nuts_ns / 1e9 / n_launches  # HIP events around k_nuts, engine stream
         achieved = (n_leap / n_launches) * B_lf / per_launch_s / 1e9  # this rank's dominant kernel
         traffic = measured_traffic(D, N)
@@ -238,7 +241,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"cfg2: D={D} iso Gaussian, DiagEuclideanMetric per-chain, NUTS(0.8) MultinomialTS+GeneralisedNoUTurn "
@@ -250,7 +253,7 @@ def main():
                 "ess": ess_info,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_nuts<double,%d,%d,mode 0,iso>" % (eng.info("group_lanes"), eng.info("elems_per_lane")),
+                "bound": "hbm", "kernel": "k_nuts<%s,%d,%d,mode 0,iso>" % ("double" if args.dtype == "f64" else "float", eng.info("group_lanes"), eng.info("elems_per_lane")),
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_leapfrog": B_lf, "avg_launch_ms": per_launch_s * 1e3,
