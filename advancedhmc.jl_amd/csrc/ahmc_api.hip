@@ -1247,7 +1247,7 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
           !dense_engine(c) && c->integ_kind != AHMC_INTEGRATOR_TEMPERED && c->target_kind != AHMC_TARGET_EXTERNAL &&
           (!so || !keep || so_on_device)) {
         // warm-up in batches too: adapt! runs inside the kernel (k_nuts MODE 3), no per-transition launch
-        const int64_t left = n_adapts - i + 1, nb_left = (left + batch - 1) / batch;
+        const int64_t left = std::min(n_adapts, n_samples) - i + 1, nb_left = (left + batch - 1) / batch;  // (a run may end mid-warm-up)
         const int64_t k = (left + nb_left - 1) / nb_left;
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
         T* dst = (so && keep) ? so + (size_t)(j - 1) * c->D * c->N : nullptr;

@@ -603,12 +603,14 @@ def test_bulk_sample_equals_stepwise(hip, rng):
     np.testing.assert_allclose(acc["sumsq_theta"], (out ** 2).sum(axis=2), rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("case", ["stan", "stan_nutpie", "naive", "stepsize", "massmatrix", "stan_far_start", "stan_jitter_f32"])
+@pytest.mark.parametrize("case", ["stan", "stan_nutpie", "naive", "stepsize", "massmatrix", "stan_far_start", "stan_jitter_f32", "stan_endsearly"])
 def test_fused_warmup_matches_stepwise(hip, rng, case):
     """Warm-up in batches (adapt! inside k_nuts, MODE 3 / 4) == transition + adapt! per iteration, bit for bit:
     every adaptor kind, NutpieVar, a start 30σ out (the linear-domain pass bails and the log-domain redo pass resumes
     mid-batch with the chain's adaptation state), jittered step sizes in Float32"""
     D, N, n_adapts, n = 8, 256, 160, 170  # Stan windows of 160 warm-up steps: one metric update, at 100
+    if "endsearly" in case:
+        n = 120  # the run stops inside the warm-up, after the metric update at 100
     dtype = np.float32 if case.endswith("f32") else np.float64
     metric = A.DiagEuclideanMetric((D, N))
     h = A.Hamiltonian(metric, A.DiagGaussian(np.zeros(D), 0.5 + np.arange(D) / 4.0))
