@@ -112,7 +112,11 @@ __device__ __forceinline__ void leapfrog_core(Point<T, E>& z, const T (&minv)[E]
 // draw k = 32-bit word k & 3 of Philox block k >> 2; uniform = (w + ½)·2⁻³² ∈ (0,1), boolean = top bit.
 // One Philox block (≈75 VALU) serves four draws; 32 bits of resolution are ample for tree sampling
 // (the momentum normals, jitter and the static-HMC draws keep 53-bit uniforms).
-struct DrawStream {
+// WIDE (a chain owns whole wavefronts, G >= 64): the four 16-lane rows of the wave run Philox on four consecutive
+// blocks at once, so one Philox evaluation (≈75 VALU) serves SIXTEEN draws; a draw is then one v_readlane from the
+// row that holds its block.  Same blocks, same words, same draw order as the narrow form — only who computes what.
+template <bool WIDE>
+struct DrawStreamT {
   Rng rng;
   uint32_t k;
   Philox4 blk;
@@ -120,12 +124,24 @@ struct DrawStream {
   __device__ __forceinline__ void resume(const Rng& r, uint32_t k0) {  // continue a stream at draw k0
     rng = r;
     k = k0;
-    if (k & 3u) blk = rng.raw(RNG_TRANSITION, k >> 2);
+    if constexpr (WIDE) {
+      if (k & 15u) blk = rng.raw(RNG_TRANSITION, ((k >> 4) << 2) + ((threadIdx.x & 63u) >> 4));
+    } else {
+      if (k & 3u) blk = rng.raw(RNG_TRANSITION, k >> 2);
+    }
   }
   __device__ __forceinline__ uint32_t word() {
-    if ((k & 3u) == 0u) blk = rng.raw(RNG_TRANSITION, k >> 2);
+    if constexpr (WIDE) {
+      if ((k & 15u) == 0u) blk = rng.raw(RNG_TRANSITION, (k >> 2) + ((threadIdx.x & 63u) >> 4));
+    } else {
+      if ((k & 3u) == 0u) blk = rng.raw(RNG_TRANSITION, k >> 2);
+    }
     const uint32_t lo = (k & 1u) ? blk.v[1] : blk.v[0], hi = (k & 1u) ? blk.v[3] : blk.v[2];
-    const uint32_t w = (k & 2u) ? hi : lo;
+    uint32_t w = (k & 2u) ? hi : lo;
+    if constexpr (WIDE) {
+      const int row = __builtin_amdgcn_readfirstlane((int)((k >> 2) & 3u));  // k is the same in every lane of the chain
+      w = (uint32_t)__builtin_amdgcn_readlane((int)w, row * 16);
+    }
     ++k;
     return w;
   }
@@ -133,6 +149,7 @@ struct DrawStream {
   __device__ __forceinline__ bool boolean() { return (word() >> 31) != 0; }
   __device__ __forceinline__ double randexp() { return -log(uniform()); }
 };
+typedef DrawStreamT<false> DrawStream;
 
 // MODE 0: multinomial + generalised, linear-domain weights (the default fast path)
 // MODE 1: multinomial + generalised, log-domain weights (redo pass for chains flagged by MODE 0)
@@ -269,7 +286,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     fill_caches<T, G, E, TK>(cur, minv, p.tp, lane, d0);
     if (on && kt > 0) store_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D);  // θ0 of this transition (re-integration, redo)
     const T H0 = -(cur.lp + cur.lk);
-    DrawStream ds;
+    DrawStreamT<(G >= 64)> ds;
     ds.init(rng);
     // both edges of the one-leaf tree are z0 (src/trajectory.jl:682-685)
     sl.store(DORM + SL_OTH_TH, cur.th);
