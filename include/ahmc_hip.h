@@ -249,10 +249,15 @@ typedef struct {
   double refresh_alpha;  /* 0 = FullMomentumRefreshment                                    */
 } ahmc_kernel_cfg;
 
-/* Runs n_samples transitions (+ adapt! for i <= n_adapts) without host synchronisation.
- * samples_out: NULL, or device/host buffer of (D, N, n_keep) receiving θ after each kept
- * transition (n_keep = n_samples - (drop_warmup ? n_adapts : 0)).
- * Accumulators (see ahmc_get_accum) are reset at the first kept transition.                  */
+/* Runs n_samples transitions (+ adapt! for i <= n_adapts): the loop body of `sample`
+ * (src/sampler.jl:182-228).  samples_out: NULL, or device/host buffer of (D, N, n_keep) receiving θ
+ * after each kept transition (n_keep = n_samples - (drop_warmup ? n_adapts : 0)).
+ * Accumulators (see ahmc_get_accum) are reset at the first kept transition.
+ * Chains are independent, so NUTS transitions are issued in batches (AHMC_INFO_NUTS_BATCH per kernel
+ * launch) — in the warm-up too, where adapt! then runs inside the kernel after every transition (step sizes
+ * and per-chain Diag mass matrices never need another chain's data).  The results are bit-identical to
+ * calling ahmc_nuts_transition + ahmc_adapt once per iteration.  After the call the ahmc_get_stat
+ * arrays hold the LAST transition's statistics.                                                   */
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples,
                     int64_t n_adapts, int32_t drop_warmup, void* samples_out);
 
