@@ -136,6 +136,8 @@ struct Ctx : CtxBase {
   int64_t dn_global_steps = 0, dn_chain_steps = 0;
   // WelfordCov of the shared dense metric: μ (D) [+ batch mean + column-sum partials], M, batch scatter, estimate
   T *wc_mu = nullptr, *wc_M = nullptr, *wc_S = nullptr, *wc_cov = nullptr;
+  T* dn_C = nullptr;   // M⁻¹·P (dense metric + dense target), see dn_refresh_fused
+  bool dn_fused_ok = false;
   T* stage = nullptr;  // device stage for ahmc_sample(samples_out = host buffer)
   size_t stage_elems = 0;
   int64_t wc_n = 0;
@@ -145,7 +147,7 @@ struct Ctx : CtxBase {
     if (stream) (void)hipStreamSynchronize(stream);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage};
+                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage, dn_C};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -275,6 +277,7 @@ int launch_kinetic(Ctx<T>* c) {
 
 template <class T>
 int set_metric(Ctx<T>* c, int kind, const T* minv, int64_t n) {
+  if (kind != AHMC_METRIC_DENSE) c->dn_fused_ok = false;
   if (kind == AHMC_METRIC_UNIT) {
     c->metric_kind = kind;
     c->minv_per_chain = false;
@@ -905,7 +908,7 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
     }
     c->target_kind = kind;
     c->have_point = false;
-    return AHMC_OK;
+    return dn_refresh_fused(c);
   });
 }
 

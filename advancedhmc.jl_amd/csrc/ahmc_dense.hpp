@@ -60,7 +60,8 @@ constexpr int GB_P = AHMC_GB_P;
 // P·16 MFMAs ≈ 1.7 µs of matrix work.  One barrier per tile.
 template <class T>
 __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N,
-                                               const int* __restrict__ idx) {  // idx: optional list of the N columns (chains) to process
+                                               const int* __restrict__ idx,  // idx: optional list of the N columns (chains) to process
+                                               const T* __restrict__ A2, T* __restrict__ Y2) {  // optional second product Y2 = A2·X in the same launch
   __shared__ T As[2][GB_K][GB_M + GB_PAD];
   __shared__ T Bs[2][GB_K][GB_N + GB_PAD];
   using M = Mfma<T>;
@@ -69,11 +70,18 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
   // the row blocks of ONE column block are given the same id mod 8 — they read the same X tile from
   // the same L2 instead of eight L2s each fetching it from the Infinity Cache.  (Launched as a 1-D grid
   // of row_blocks × 8·⌈col_blocks/8⌉ workgroups.)
-  const int nrb = (D + GB_M - 1) / GB_M;
+  const int nrb1 = (D + GB_M - 1) / GB_M;
+  const int nrb = A2 ? 2 * nrb1 : nrb1;  // two products: the row blocks of A2 follow those of A (same X tile, same L2)
   const unsigned lin = blockIdx.x;
   const unsigned xcd = lin & 7u, slot = lin >> 3;
   const int64_t cb = (int64_t)(slot / nrb) * 8 + xcd;
-  const int m0 = (int)(slot % nrb) * GB_M;
+  int rblk = (int)(slot % nrb);
+  if (rblk >= nrb1) {
+    rblk -= nrb1;
+    A = A2;
+    Y = Y2;
+  }
+  const int m0 = rblk * GB_M;
   const int64_t n0 = cb * GB_N;
   if (n0 >= N) return;
   const int wm = (w & 1) * 32, wn = (w >> 1) * 32;
@@ -156,13 +164,20 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
 // wave is 4× shorter (≈10 µs instead of ≈38 µs at D = 512).
 template <class T>
 __global__ __launch_bounds__(256) void k_dgemm_small(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N,
-                                                     const int* __restrict__ idx) {
+                                                     const int* __restrict__ idx, const T* __restrict__ A2, T* __restrict__ Y2) {
   constexpr int BN = 16;
   __shared__ T As[2][GB_K][GB_M + GB_PAD];
   __shared__ T Bs[2][GB_K][BN + 4];
   using M = Mfma<T>;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int m0 = blockIdx.x * GB_M;
+  const int nrb1 = (D + GB_M - 1) / GB_M;
+  int rblk = blockIdx.x;
+  if (rblk >= nrb1) {  // second product of the launch
+    rblk -= nrb1;
+    A = A2;
+    Y = Y2;
+  }
+  const int m0 = rblk * GB_M;
   const int64_t n0 = (int64_t)blockIdx.y * BN;
   typename M::acc_t acc = typename M::acc_t{0, 0, 0, 0};
   T ra[2][4], rb[2];

@@ -8,21 +8,21 @@ bool dense_engine(const Ctx<T>* c) {
 }
 
 template <class T>
-int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* list = nullptr) {
+int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* list = nullptr, const T* A2 = nullptr, T* Y2 = nullptr) {
   if (ncols <= 0) return AHMC_OK;
   // few columns: the 64×16-tile kernel puts 4× as many workgroups on the chip (same arithmetic per column,
-  // so results do not depend on which kernel ran)
-  const int64_t row_blocks = (c->D + GB_M - 1) / GB_M;
+  // so results do not depend on which kernel ran).  A2 / Y2: a second product on the same X in the same launch.
+  const int64_t row_blocks = (c->D + GB_M - 1) / GB_M * (A2 ? 2 : 1);
   static const int64_t small_below = getenv("AHMC_GEMM_SMALL_BELOW") ? atoll(getenv("AHMC_GEMM_SMALL_BELOW")) : 1;  // measured D=512: N=512 22 vs 38 µs, N=2048 38 vs 40, N=4096 67 vs 59
   if (row_blocks * ((ncols + GB_N - 1) / GB_N) < small_below * c->n_cu) {
     dim3 grid((unsigned)row_blocks, (unsigned)((ncols + 15) / 16));
-    hipLaunchKernelGGL((k_dgemm_small<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list);
+    hipLaunchKernelGGL((k_dgemm_small<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2);
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   }
   const int64_t cb8 = ((ncols + GB_N - 1) / GB_N + 7) / 8 * 8;  // column blocks padded to the 8 XCDs (see k_dgemm)
   dim3 grid((unsigned)(row_blocks * cb8));
-  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list);
+  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -41,6 +41,20 @@ DP<T> make_dp(Ctx<T>* c) {
   q.n_list = c->N;
   q.dense_metric = c->metric_kind == AHMC_METRIC_DENSE ? 1 : 0;
   return q;
+}
+
+// C = M⁻¹·P for the dense metric + dense target pair: w′ = M⁻¹g′ = (M⁻¹P)θ′ is then a second product on the SAME
+// θ′ as g′ = Pθ′, and one launch serves both (one X tile read, twice the workgroups — what matters when few
+// chains are still running).  Rebuilt whenever the metric or the target changes.
+template <class T>
+int dn_refresh_fused(Ctx<T>* c) {
+  c->dn_fused_ok = false;
+  if (c->metric_kind != AHMC_METRIC_DENSE || c->target_kind != AHMC_TARGET_DENSE_GAUSS || !c->dn_minv || !c->tparams) return AHMC_OK;
+  if (!c->dn_C) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_C), sizeof(T) * c->D * c->D));
+  int rc = dn_gemm(c, c->dn_minv, c->tparams, c->dn_C, c->D);  // P's columns as the "chains"
+  if (rc) return rc;
+  c->dn_fused_ok = true;
+  return AHMC_OK;
 }
 
 // workspace for trees of up to max_depth doublings
@@ -233,7 +247,7 @@ int dn_set_metric(Ctx<T>* c, const T* minv_in) {
   c->metric_kind = AHMC_METRIC_DENSE;
   c->minv_per_chain = false;
   c->minv_n = D * D;
-  return AHMC_OK;
+  return dn_refresh_fused(c);
 }
 
 template <class T>
@@ -354,11 +368,16 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     for (int s = 0; s < CHUNK; ++s) {
       // one global step = g′ = Pθ′ (or the built-in family's kernel), w′ = M⁻¹g′, then the fused
       // second-half / tree / first-half kernel: three launches
-      rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, n_list, list) : launch_fill_caches_builtin(c);
-      if (rc) return rc;
-      if (dm) {
-        rc = dn_gemm(c, c->dn_minv, c->g, Wcur, n_list, list);
+      if (dt && dm && c->dn_fused_ok) {
+        rc = dn_gemm(c, c->tparams, c->th, c->g, n_list, list, c->dn_C, Wcur);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
         if (rc) return rc;
+      } else {
+        rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, n_list, list) : launch_fill_caches_builtin(c);
+        if (rc) return rc;
+        if (dm) {
+          rc = dn_gemm(c, c->dn_minv, c->g, Wcur, n_list, list);
+          if (rc) return rc;
+        }
       }
       hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c, n_list)), dim3(256), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 1);
     }
