@@ -438,6 +438,32 @@ def test_dense_covariance_adaptation(hip, oracle, rng):
     np.testing.assert_allclose(var, np.diag(Sigma), rtol=0.1)
 
 
+@pytest.mark.parametrize("name", ["nuts_iso_diag", "nuts_funnel_slice", "hmc_endpoint", "hmc_multinomial"])
+def test_against_committed_fixtures(hip, name):
+    """HIP engine vs tests/golden/oracle_fixtures.npz (the oracle's results on fixed seeded inputs, committed with the
+    script that made them: tests/golden/make_oracle_fixtures.py) — no oracle build needed on the GPU box"""
+    import importlib.util
+    import os
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(here, "make_oracle_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys_path = list(__import__("sys").path)
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        __import__("sys").path[:] = sys_path
+    ref = np.load(os.path.join(here, "oracle_fixtures.npz"))
+    got = mod.run_case(name, hip)
+    n = mod.CASES[name][6]
+    for it in range(n):
+        same = got[f"{name}/n_steps{it}"] == ref[f"{name}/n_steps{it}"]
+        assert same.mean() >= (0.99 if it == 0 else 0.9)
+        np.testing.assert_allclose(got[f"{name}/theta{it}"][:, same], ref[f"{name}/theta{it}"][:, same], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(got[f"{name}/H{it}"][same], ref[f"{name}/H{it}"][same], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(got[f"{name}/acc{it}"][same], ref[f"{name}/acc{it}"][same], rtol=1e-7, atol=1e-9)
+
+
 def test_max_depth_and_single_leaf(hip, oracle, rng):
     """max_depth = 1 (one leaf) and a tiny step size that always hits max_depth"""
     D, N = 5, 64

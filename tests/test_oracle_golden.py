@@ -400,3 +400,25 @@ def test_rng_free_golden(oracle, source):
             e.adapt(i + 1, 1000, theta=np.array(x)[:, None], alpha=np.ones(1), grad=np.array(g)[:, None])
         np.testing.assert_allclose(e.get_metric()[:, 0], fix(w[key]), rtol=1e-12)
         e.close()
+
+
+def test_oracle_reproduces_committed_fixtures(oracle):
+    """tests/golden/oracle_fixtures.npz (what the GPU parity test checks the HIP engine against without an oracle
+    build) is still what the oracle produces: a change of the oracle or of the RNG spec must regenerate it"""
+    import importlib.util
+    import os
+    import sys
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(here, "make_oracle_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    saved = list(sys.path)
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path[:] = saved
+    ref = np.load(os.path.join(here, "oracle_fixtures.npz"))
+    for name in mod.CASES:
+        got = mod.run_case(name, oracle)
+        for key, val in got.items():
+            np.testing.assert_array_equal(val, ref[key], err_msg=key)
