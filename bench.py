@@ -124,8 +124,8 @@ def cpu_baseline(A, D, n_adapt, steps, seed, chains, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--adapt", type=int, default=200, help="untimed Stan adaptation transitions")

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd $R
-CMD="python bench.py --steps 64 --warmup 16 --no-cpu-baseline"
+CMD="python bench.py --no-cpu-baseline"
 $CMD > $O/bench_plain.json 2> $O/bench_plain.err
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/bench_under_rocprof.json 2> $O/kt.err
 pmc() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d $O/$name -o $name -- $CMD > $O/$name.json 2> $O/$name.err; }

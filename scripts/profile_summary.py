@@ -4,7 +4,7 @@ import glob, json, os, sqlite3, sys
 from collections import defaultdict
 
 O = sys.argv[1]
-N_TIMED = int(os.environ.get("N_TIMED_LAUNCHES", "2"))
+N_TIMED = int(os.environ.get("N_TIMED_LAUNCHES", "4"))  # bench.py default: 128 timed transitions = 4 launches of 32
 out = {}
 
 
