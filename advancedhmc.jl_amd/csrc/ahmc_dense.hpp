@@ -399,10 +399,28 @@ __device__ __forceinline__ void vcopy(T* __restrict__ dst, const T* __restrict__
 // (leaf, merges, end of subtree, end of doubling, end of transition, start of the next transition)
 // and publish the signed step of its next leapfrog.  MultinomialTS / SliceTS with
 // GeneralisedNoUTurn; log-domain weights as the reference (src/trajectory.jl:144-206,626-742).
+constexpr int DT_THREADS = 256;  // threads per chain in k_d_tree
+// all-reduce of a pair over the DT_THREADS threads of the workgroup (every decision of d_tree_advance is taken on
+// such sums or on per-chain scalars, so all threads follow the same control flow and reach the barriers together)
+template <class T>
+__device__ __forceinline__ void block_allsum2(T& a, T& b) {
+  __shared__ double xb[DT_THREADS / 64][2];
+  wave_allsum2<64>(a, b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { xb[w][0] = (double)a; xb[w][1] = (double)b; }
+  __syncthreads();
+  T sa = 0, sb = 0;
+#pragma unroll
+  for (int k = 0; k < DT_THREADS / 64; ++k) { sa += (T)xb[k][0]; sb += (T)xb[k][1]; }  // fixed order: same bits in every wave
+  __syncthreads();
+  a = sa;
+  b = sb;
+}
+
 // Returns the signed step of the chain's next leapfrog (0 = motionless step or idle).  lp_in / lk_in: ℓπ, ℓκ of the
 // point the leapfrog that has just completed arrived at (registers, uniform across the wave).
 template <class T>
-__device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int64_t c, int lane, T lp_in, T lk_in) {
+__device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int64_t c, int lane /* thread of the chain's workgroup, 0 .. DT_THREADS-1 */, T lp_in, T lk_in) {
   DChain<T>& S = q.S[c];
   const int D = p.D;
   const bool slice = p.sampler == 2;
@@ -423,8 +441,9 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
     // too and let the first leapfrog go
     const T* Wc = dslot(q, p, DS_CUR_W, c);
     T* o_w = dslot(q, p, DS_OTH_W, c);
-    for (int d = lane; d < D; d += 64) o_w[d] = Wc[d];
+    for (int d = lane; d < D; d += DT_THREADS) o_w[d] = Wc[d];
     const T e_first = S.v < 0 ? -S.eps : S.eps;
+    __syncthreads();  // (every thread has read the phase before thread 0 changes it)
     if (lane == 0) S.phase = DPH_RUN;
     return e_first;
   }
@@ -451,6 +470,10 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       sub_term = !(-H0 < p.delta_max + ne);
     }
     bool numerical = S.numerical != 0 || sub_term;
+    const int cur_is_left_in = S.cur_is_left;
+    // every thread has now read the chain's scalars of this call: only from here on may thread 0 update them
+    // (an odd leaf parks without any reduction, i.e. without any other barrier in between)
+    __syncthreads();
     // The subtree being assembled lives only inside this call, so its vectors are VIEWS: a fresh leaf's
     // ρ, v_first and candidate are the moving edge itself; after a merge ρ is in the SUB_RHO slot and
     // v_first / the candidate may point into a pending level.  Data is copied only when it must
@@ -490,7 +513,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
       // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
       T dots[2] = {0, 0};
-      for (int d = lane; d < D; d += 64) {
+      for (int d = lane; d < D; d += DT_THREADS) {
         const T rho = p_rho[d] + rho_v[d];
         dots[0] += rho * p_vf[d];
         dots[1] += rho * V[d];
@@ -498,7 +521,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       }
       rho_v = s_rho;
       vf_v = p_vf;
-      wave_allsum2<64>(dots[0], dots[1]);
+      block_allsum2(dots[0], dots[1]);
       sub_term = (dots[0] <= 0) || (dots[1] <= 0);
       merged = lvl + 1;
     }
@@ -521,7 +544,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       T* p_cth = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 2, c);
       T* p_cr = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 3, c);
       T* p_cg = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 4, c);
-      for (int d = lane; d < D; d += 64) {
+      for (int d = lane; d < D; d += DT_THREADS) {
         p_rho[d] = rho_v[d];
         p_vf[d] = vf_v[d];
         p_cth[d] = cth_v[d];
@@ -556,7 +579,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         T* c_th = dslot(q, p, DS_CAND_TH, c);
         T* c_r = dslot(q, p, DS_CAND_R, c);
         T* c_g = dslot(q, p, DS_CAND_G, c);
-        for (int d = lane; d < D; d += 64) {
+        for (int d = lane; d < D; d += DT_THREADS) {
           c_th[d] = cth_v[d];
           c_r[d] = cr_v[d];
           c_g[d] = cg_v[d];
@@ -575,20 +598,20 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       T* t_rho = dslot(q, p, DS_TREE_RHO, c);
       const T* o_v = dslot(q, p, DS_OTH_V, c);
       T dots[2] = {0, 0};
-      for (int d = lane; d < D; d += 64) {
+      for (int d = lane; d < D; d += DT_THREADS) {
         const T rho = t_rho[d] + rho_v[d];
         dots[0] += rho * V[d];
         dots[1] += rho * o_v[d];
         t_rho[d] = rho;
       }
-      wave_allsum2<64>(dots[0], dots[1]);
+      block_allsum2(dots[0], dots[1]);
       turn = (dots[0] <= 0) || (dots[1] <= 0);
     }
     const bool done = sub_term || turn || (jw + 1 >= p.max_depth);
     if (!done) {
       // ---- next doubling: direction (:693), edge selection ----
       const bool vleft = ds.boolean();
-      const bool cur_is_left = S.cur_is_left != 0;
+      const bool cur_is_left = cur_is_left_in != 0;
       if (vleft != cur_is_left) {  // continue from the other edge: swap the two edge points
         T* o_th = dslot(q, p, DS_OTH_TH, c);
         T* o_r = dslot(q, p, DS_OTH_R, c);
@@ -596,7 +619,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         T* o_v = dslot(q, p, DS_OTH_V, c);
         T* o_w = dslot(q, p, DS_OTH_W, c);
         T* Wc = dslot(q, p, DS_CUR_W, c);
-        for (int d = lane; d < D; d += 64) {
+        for (int d = lane; d < D; d += DT_THREADS) {
           T t;
           t = o_th[d]; o_th[d] = th[d]; th[d] = t;
           t = o_r[d]; o_r[d] = r[d]; r[d] = t;
@@ -625,7 +648,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       T* s1 = p.acc_sum() + c * D;
       T* s2 = p.acc_sumsq() + c * D;
       T* so = p.samples_out ? p.samples_out + ((int64_t)it * p.N + c) * D : nullptr;
-      for (int d = lane; d < D; d += 64) {
+      for (int d = lane; d < D; d += DT_THREADS) {
         const T t = c_th[d];
         th[d] = t;
         r[d] = c_r[d];
@@ -681,7 +704,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
     T* c_r = dslot(q, p, DS_CAND_R, c);
     T* c_g = dslot(q, p, DS_CAND_G, c);
     T dots[2] = {0, 0};
-    for (int d = lane; d < D; d += 64) {
+    for (int d = lane; d < D; d += DT_THREADS) {
       const T rd = rb[d], vd = vb[d], td = th[d], gd = g[d];
       dots[0] += rd * vd;
       r[d] = rd;
@@ -690,7 +713,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       t_rho[d] = rd;
       c_th[d] = td; c_r[d] = rd; c_g[d] = gd;
     }
-    wave_allsum2<64>(dots[0], dots[1]);
+    block_allsum2(dots[0], dots[1]);
     const T lp = lp_start;
     const T lk = sanitize(-dots[0] / 2);
     const T H0 = -(lp + lk);
@@ -720,10 +743,12 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
 // One global step of the NUTS batch for every listed chain, fused (one wave per chain):
 //   second half of the leapfrog that the GEMMs have just served (k_d_post) → d_tree_advance → first half of the
 //   next leapfrog (k_d_pre).  `do_post` = 0 for the very first call of a batch (no leapfrog in flight yet).
+// One chain per workgroup of 256 threads (2 elements per thread at D = 512): the kernel is a chain of dependent
+// memory round trips, so more threads per chain = fewer trips (one wave per chain: 75 µs per call, this: see DESIGN).
 template <class T>
-__global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
-  const int lane = threadIdx.x & 63;
-  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(DT_THREADS) void k_d_tree(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
+  const int lane = threadIdx.x;  // one chain per workgroup of DT_THREADS threads
+  const int64_t j = blockIdx.x;
   if (j >= q.n_list) return;
   const int64_t c = q.list ? q.list[j] : j;
   if (q.S[c].phase == DPH_IDLE) return;
@@ -737,7 +762,7 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q, const T* __res
   if (do_post) {
     const T e = q.es[c];
     T s[2] = {0, 0};
-    for (int d = lane; d < D; d += 64) {
+    for (int d = lane; d < D; d += DT_THREADS) {
       const T gd = g[d];
       T rn = r[d], vn;
       if (e != T(0)) rn = rn - e / 2 * gd;
@@ -747,7 +772,7 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q, const T* __res
       s[0] += rn * vn;
       s[1] += th[d] * gd;
     }
-    wave_allsum2<64>(s[0], s[1]);
+    block_allsum2(s[0], s[1]);
     lk = sanitize(-s[0] / 2);
     if (dense_target) lp = sanitize(-s[1] / 2);
     if (lane == 0) {
@@ -758,7 +783,7 @@ __global__ __launch_bounds__(256) void k_d_tree(KP<T> p, DP<T> q, const T* __res
   const T e = d_tree_advance(p, q, c, lane, lp, lk);
   if (lane == 0) q.es[c] = e;
   if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237)
-    for (int d = lane; d < D; d += 64) {
+    for (int d = lane; d < D; d += DT_THREADS) {
       const T rh = r[d] - e / 2 * g[d];
       const T vh = W ? V[d] - e / 2 * W[d] : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
       r[d] = rh;

@@ -352,7 +352,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   const int pc = c->minv_per_chain ? 1 : 0;
   T* Wcur = dm ? c->dn_W + (size_t)DS_CUR_W * c->D * c->N : nullptr;
   // start of transition 0 (and, for Unit/Diag metrics, the first half of its first leapfrog)
-  hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 0);
+  hipLaunchKernelGGL((k_d_tree<T>), dim3((unsigned)c->N), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 0);
   HIPCHK(hipGetLastError());
   // global steps until every chain has finished the batch.  Every CHUNK steps the list of chains
   // still running is compacted and its length read back, so the tail of the batch (few chains with
@@ -379,7 +379,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
           if (rc) return rc;
         }
       }
-      hipLaunchKernelGGL((k_d_tree<T>), dim3(dn_grid_chains(c, n_list)), dim3(256), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 1);
+      hipLaunchKernelGGL((k_d_tree<T>), dim3((unsigned)n_list), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 1);
     }
     done_steps += CHUNK;
     c->dn_global_steps += CHUNK;
