@@ -47,7 +47,7 @@ def _sources_digest() -> str:
 
 def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     digest = _sources_digest()
-    stamp = os.path.join(OBJ, "digest.txt")
+    stamp = OUT + ".digest"  # next to the .so (csrc/build/ holds only objects and does not travel to the GPU box)
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == digest:
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -73,6 +73,9 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    for f in os.listdir(CSRC):  # unbundled device images an interrupted link may leave behind
+        if f.startswith("libahmc_hip.so.") and f != "libahmc_hip.so.digest":
+            os.remove(os.path.join(CSRC, f))
     with open(stamp, "w") as f:
         f.write(digest)
     if verbose:
