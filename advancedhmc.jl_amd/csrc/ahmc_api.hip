@@ -1196,7 +1196,7 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
     // this call's first batch (below).  Counting sort on the stream, no host synchronisation.
     auto order_by_work = [&](bool refresh) -> int {
       if (!cfg->nuts || dense_engine(c) || !c->order_valid || (c->order_from_work && !refresh) || c->acc_ntrans < 4) return AHMC_OK;
-      int rc2 = build_order(c, 1);
+      int rc2 = build_order(c, (int)std::min<int64_t>(c->acc_ntrans, 1 << 20));
       if (!rc2) c->order_from_work = true;
       return rc2;
     };

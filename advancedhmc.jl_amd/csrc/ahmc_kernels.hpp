@@ -665,13 +665,13 @@ __global__ __launch_bounds__(256) void k_normals(KP<T> p, T* __restrict__ out, i
 // ------------------------------------------------------------------------------------------------
 // Dispatch order of k_nuts (LPT: chains with the most expected work first).  A counting sort on 16-bit keys,
 // entirely on the stream: key = bin index, smaller bin = earlier.  by_work = 0: ascending step size (the
-// 8 exponent + 8 top mantissa bits of float(ϵ)); by_work = 1: descending Σ n_steps of the previous sampling call.
+// 8 exponent + 8 top mantissa bits of float(ϵ)); by_work = n > 0: descending Σ n_steps over the last n kept transitions.
 // Chains inside one bin land in arbitrary order (atomics) — the order only schedules, results do not depend on it.
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __device__ __forceinline__ unsigned order_key(const T* eps, const long long* work, int by_work, int64_t i) {
-  if (by_work) {
-    long long w = work[i];
+  if (by_work) {  // by_work = number of transitions the counts cover: key = mean leapfrogs per transition, in 1/16ths
+    long long w = work[i] * 16 / by_work;
     return 65535u - (unsigned)(w < 0 ? 0 : (w > 65535 ? 65535 : w));
   }
   return (__float_as_uint((float)eps[i]) >> 15) & 0xFFFFu;
