@@ -167,6 +167,10 @@ typedef DrawStreamT<false> DrawStream;
 template <class T, int G, int E, int MODE, int TK>
 __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) : (E <= 2 ? 4 : (E <= 4 ? 3 : 2)))) void k_nuts(KP<T> p) {
   constexpr int CPW = G >= 64 ? 1 : 64 / G;  // chains per wave (G > 64: one chain per workgroup of G/64 waves)
+  // A chain that owns whole waves makes every per-chain predicate wave-uniform; saying so (a ballot is uniform by
+  // construction) turns the exec-mask save/restore of divergent branches into scalar branches and keeps the
+  // predicates in SGPRs instead of VGPR 0/1 values.
+#define AHMC_UNI(b) (CPW == 1 ? (__builtin_amdgcn_ballot_w64(b) != 0) : (b))
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
   constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -272,7 +276,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     // constant derived from them is loop-invariant w.r.t. this loop, gets hoisted out of it and
     // stays live through the whole tree (measured: +50 VGPRs, one wave per SIMD less).
     asm volatile("" : "+v"(cc), "+v"(d0), "+v"(lane), "+v"(gi), "+v"(sl.lane_off));
-    const bool on = active && kt >= kt0;
+    const bool on = AHMC_UNI(active && kt >= kt0);
     if (__builtin_amdgcn_ballot_w64(on) == 0) continue;
     // ---- transition prologue (src/sampler.jl:54-57): jitter, fresh momentum, caches.  The standard
     // normals come from k_normals (same Philox stream): keeping the f64 Box–Muller out of this
@@ -314,9 +318,9 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
       // ---- direction (:693) and edge selection ----
       bool vleft = false;
-      if (!done) vleft = ds.boolean();
+      if (!done) vleft = AHMC_UNI(ds.boolean());
       const int v = vleft ? -1 : 1;
-      const bool need_swap = !done && (vleft != cur_is_left);
+      const bool need_swap = AHMC_UNI(!done && (vleft != cur_is_left));
       if (__builtin_amdgcn_ballot_w64(need_swap) != 0) {
         if (need_swap) {
           if (jw > 0) {  // at jw == 0 both edges are z0
@@ -360,7 +364,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           ck_c = pos_cur;
           if (slice) {
             w_c = (lu <= ne) ? T(1) : T(0);
-            sub_term = !(lu < p.delta_max + ne);  // Termination(::SliceTS, ...) (:500-502)
+            sub_term = AHMC_UNI(!(lu < p.delta_max + ne));  // Termination(::SliceTS, ...) (:500-502)
           } else {
             if constexpr (LINW) {
               // multinomial weights in the linear domain: W = exp(ℓw), ℓw = H0 - H′ = -ΔH.  Then
@@ -371,11 +375,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               const T lw = H0 + ne;
               w_c = exp(lw);
               sa_c = jl_min(T(1), w_c);
-              redo = redo || (lw > (sizeof(T) == 4 ? T(60) : T(LINW_LIMIT)));
+              redo = redo || AHMC_UNI(lw > (sizeof(T) == 4 ? T(60) : T(LINW_LIMIT)));
             } else {
               w_c = H0 + ne;
             }
-            sub_term = !(-H0 < p.delta_max + ne);  // Termination(::MultinomialTS, ...) (:503-507)
+            sub_term = AHMC_UNI(!(-H0 < p.delta_max + ne));  // Termination(::MultinomialTS, ...) (:503-507)
           }
           numerical = numerical || sub_term;
           if (classic) copy_vec(A_c, cur.th); else copy_vec(A_c, cur.r);
@@ -384,7 +388,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         // merges: one per trailing zero bit of `leaf` (:649-673); trip count is wave-uniform
         const int nm = __builtin_ctz(leaf);
         for (int lvl = 0; lvl < nm; ++lvl) {
-          const bool m = alive && !sub_term;
+          const bool m = AHMC_UNI(alive && !sub_term);
           if (__builtin_amdgcn_ballot_w64(m) == 0) break;
           if (m) {
             T A_p[E], RF_p[E];
@@ -396,10 +400,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             T w_new;
             if (slice) {
               w_new = w_p + w_c;
-              keep_first = w_new * (T)ds.uniform() < w_p;
+              keep_first = AHMC_UNI(w_new * (T)ds.uniform() < w_p);
             } else {
               if constexpr (LINW) w_new = w_p + w_c; else w_new = logaddexp(w_p, w_c);
-              if constexpr (LINW) keep_first = (T)ds.uniform() * w_new < w_p; else keep_first = w_new < w_p + (T)ds.randexp();
+              if constexpr (LINW) keep_first = AHMC_UNI((T)ds.uniform() * w_new < w_p); else keep_first = AHMC_UNI(w_new < w_p + (T)ds.randexp());
             }
             if (keep_first) ck_c = S_CK(lvl);
             w_c = w_new;
@@ -432,7 +436,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
                 dots[1] += A_c[e] * (minv[e] * cur.r[e]);
               }
               group_allsum<G>(dots);
-              sub_term = (dots[0] <= 0) || (dots[1] <= 0);  // generalised_uturn_criterion (:619-621)
+              sub_term = AHMC_UNI((dots[0] <= 0) || (dots[1] <= 0));  // generalised_uturn_criterion (:619-621)
             } else {
               // StrictGeneralisedNoUTurn (:579-617).  F = the pending (first-built) half, S = the half
               // just completed; in built order the two extra checks are symmetric in the direction:
@@ -491,8 +495,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           ++depth;
           bool acc;  // mh_accept(rng, sampler, sampler′): biased progressive sampling (:202-206)
           if (slice) acc = w_tree * (T)ds.uniform() < w_c;
-          else if constexpr (LINW) acc = (T)ds.uniform() * w_tree < w_c;
-          else acc = w_tree < w_c + (T)ds.randexp();
+          else if constexpr (LINW) acc = AHMC_UNI((T)ds.uniform() * w_tree < w_c);
+          else acc = AHMC_UNI(w_tree < w_c + (T)ds.randexp());
           if (acc) ck_tree = ck_c;
         }
         sa_tree = sa_tree + sa_c;
@@ -529,7 +533,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               dots[1] += A_tree[e] * (minv[e] * oth_r[e]);
             }
             group_allsum<G>(dots);
-            turn = (dots[0] <= 0) || (dots[1] <= 0);
+            turn = AHMC_UNI((dots[0] <= 0) || (dots[1] <= 0));
           } else {
             // strict at the top: (ρ_tree + r_sub.first ; ends other edge, sub.first) and
             //                    (r_start + ρ_sub ; ends start edge, current edge)
@@ -571,7 +575,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       const int steps = on ? (ck_tree < 0 ? -ck_tree : ck_tree) : 0;
       const T es = ck_tree < 0 ? -eps : eps;
       for (int s = 0;; ++s) {
-        const bool go = s < steps;
+        const bool go = AHMC_UNI(s < steps);
         if (__builtin_amdgcn_ballot_w64(go) == 0) break;
         if (go) leapfrog_core<T, G, E, TK, GENERAL>(zc, minv, es, p.tp, p.lf, lane, d0);
       }
@@ -667,6 +671,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #undef S_DH
 #undef S_NA
 #undef S_CK
+#undef AHMC_UNI
 }
 
 }  // namespace ahmc
