@@ -138,16 +138,24 @@ struct Ctx : CtxBase {
   T *wc_mu = nullptr, *wc_M = nullptr, *wc_S = nullptr, *wc_cov = nullptr;
   T* dn_C = nullptr;   // M⁻¹·P (dense metric + dense target), see dn_refresh_fused
   bool dn_fused_ok = false;
-  T* stage = nullptr;  // device stage for ahmc_sample(samples_out = host buffer)
-  size_t stage_elems = 0;
+  // ahmc_sample(samples_out = host buffer): two device stages; the D2H copy of one batch's draws runs on copy_stream
+  // while k_nuts fills the other stage
+  T* stage[2] = {nullptr, nullptr};
+  size_t stage_elems[2] = {0, 0};
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t stage_ready[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
   int64_t wc_n = 0;
 
   ~Ctx() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    for (hipEvent_t e : {stage_ready[0], stage_ready[1], stage_free[0], stage_free[1]})
+      if (e) (void)hipEventDestroy(e);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage, dn_C};
+                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -736,6 +744,33 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
 
 // A batch of k warm-up transitions i .. i+k-1 with the adaptor's adapt! done inside the kernel (k_nuts MODE 3); the host
 // only mirrors the bookkeeping that is the same for every chain (Stan window counter, Welford count).
+// Stage `slot` of ahmc_sample's host-output path, at least `need` elements, not in use by a copy any more
+// (device-side wait: the next k_nuts that writes it is ordered after the D2H copy that reads it).
+template <class T>
+int stage_acquire(Ctx<T>* c, int slot, size_t need) {
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int s = 0; s < 2; ++s) {
+      HIPCHK(hipEventCreateWithFlags(&c->stage_ready[s], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->stage_free[s], hipEventDisableTiming));
+    }
+  }
+  if (need > c->stage_elems[slot]) {
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->stage[slot]) HIPCHK(hipFree(c->stage[slot]));
+    c->stage[slot] = nullptr;
+    c->stage_elems[slot] = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->stage[slot]), need * sizeof(T)));
+    c->stage_elems[slot] = need;
+    c->stage_busy[slot] = false;
+  } else if (c->stage_busy[slot]) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->stage_free[slot], 0));
+    c->stage_busy[slot] = false;
+  }
+  return AHMC_OK;
+}
+
 template <class T>
 int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, int64_t n_adapts, bool accum, T* samples_dev) {
   const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
@@ -1204,6 +1239,19 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
       int rc2 = order_by_work(true);  // the previous call's counts are the freshest estimate there is
       if (rc2) return rc2;
     }
+    int64_t n_staged = 0;
+    T* pend_dst = nullptr;
+    int pend_slot = 0;
+    size_t pend_bytes = 0;
+    auto flush_pending = [&]() -> int {
+      if (!pend_dst) return AHMC_OK;
+      HIPCHK(hipStreamWaitEvent(c->copy_stream, c->stage_ready[pend_slot], 0));
+      HIPCHK(hipMemcpyAsync(pend_dst, c->stage[pend_slot], pend_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(hipEventRecord(c->stage_free[pend_slot], c->copy_stream));
+      c->stage_busy[pend_slot] = true;
+      pend_dst = nullptr;
+      return AHMC_OK;
+    };
     for (int64_t i = 1; i <= n_samples;) {  // src/sampler.jl:182-228
       const bool keep = !drop_warmup || i > n_adapts;
       if (keep && !reset_done) {
@@ -1222,22 +1270,24 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
         T* dst = so ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
         T* dev_dst = dst;
-        if (so && !so_on_device) {  // host buffer: the kernel writes the batch's draws into a device stage
-          const size_t need = (size_t)k * c->D * c->N;
-          if (need > c->stage_elems) {
-            if (c->stage) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->stage)); }
-            c->stage = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->stage), need * sizeof(T)));
-            c->stage_elems = need;
-          }
-          dev_dst = c->stage;
+        const bool via_stage = so && !so_on_device;
+        const int slot = (int)(n_staged & 1);
+        if (via_stage) {  // host buffer: the kernel writes the batch's draws into a device stage
+          int rc1 = stage_acquire(c, slot, (size_t)k * c->D * c->N);
+          if (rc1) return rc1;
+          dev_dst = c->stage[slot];
         }
         int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, true,
                                  (int)k, dev_dst);
         if (rc) return rc;
-        if (so && !so_on_device) {
-          HIPCHK(hipMemcpyAsync(dst, c->stage, nb * (size_t)k, hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(hipStreamSynchronize(c->stream));  // the stage is reused by the next batch; pageable host memory anyway
+        if (via_stage) {
+          HIPCHK(hipEventRecord(c->stage_ready[slot], c->stream));
+          // the PREVIOUS batch's draws go to the host while this batch computes (a copy to pageable memory blocks the
+          // calling thread, so it is issued after this batch's launch, not before)
+          rc = flush_pending();
+          if (rc) return rc;
+          pend_dst = dst; pend_slot = slot; pend_bytes = nb * (size_t)k;
+          ++n_staged;
         }
         c->acc_ntrans += k;
         i += k;
@@ -1273,6 +1323,15 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
         }
       }
       ++i;
+    }
+    {  // last staged batch; the context's stream then waits for the copies, so ahmc_sync covers them
+      int rc = flush_pending();
+      if (rc) return rc;
+      for (int s = 0; s < 2; ++s)
+        if (c->stage_busy[s]) {
+          HIPCHK(hipStreamWaitEvent(c->stream, c->stage_free[s], 0));
+          c->stage_busy[s] = false;
+        }
     }
     return AHMC_OK;
   });

@@ -257,7 +257,10 @@ typedef struct {
  * launch) — in the warm-up too, where adapt! then runs inside the kernel after every transition (step sizes
  * and per-chain Diag mass matrices never need another chain's data).  The results are bit-identical to
  * calling ahmc_nuts_transition + ahmc_adapt once per iteration.  After the call the ahmc_get_stat
- * arrays hold the LAST transition's statistics.                                                   */
+ * arrays hold the LAST transition's statistics.  A HOST samples_out is filled through two device stages,
+ * the D2H copy of one batch overlapping the next batch's kernel on a second stream; the copies are
+ * ordered before anything enqueued on the context's stream afterwards, so ahmc_sync() covers them
+ * (pinned host memory keeps the call asynchronous; a pageable buffer must stay valid until then too). */
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples,
                     int64_t n_adapts, int32_t drop_warmup, void* samples_out);
 

@@ -629,6 +629,39 @@ def test_bulk_sample_equals_stepwise(hip, rng):
     np.testing.assert_allclose(acc["sumsq_theta"], (out ** 2).sum(axis=2), rtol=1e-12, atol=1e-12)
 
 
+def test_host_draws_double_buffered(hip, rng):
+    """ahmc_sample with a HOST samples_out: batches go through two device stages, the D2H copy of one overlapping the
+    next batch's kernel; the draws equal those written straight into a device buffer (several batches, ragged last one)"""
+    import torch
+    D, N, n = 12, 300, 150
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.25))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn()))
+    th = rng.normal(size=(D, N))
+    outs = []
+    for where in ("host", "pinned", "device", "host_twice"):
+        e = A.Engine(h, N, rng=11, lib=hip)
+        e.set_integrator(lf)
+        e.set_position(th)
+        if where == "device":
+            buf = torch.zeros(n * D * N, dtype=torch.float64, device="cuda")
+        elif where == "pinned":
+            buf = torch.zeros(n * D * N, dtype=torch.float64).pin_memory()
+        else:
+            buf = np.zeros(n * D * N)
+        if where == "host_twice":  # a second call reuses the stages while the first call's copies may be in flight
+            e.run(k, 70, samples_out=buf)
+            e.run(k, n - 70, samples_out=buf[70 * D * N:])
+        else:
+            e.run(k, n, samples_out=buf)
+        e.sync()
+        outs.append(buf.cpu().numpy() if hasattr(buf, "cpu") else buf)
+        assert np.all(np.isfinite(outs[-1])) and np.abs(outs[-1][-D * N:]).max() > 0
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+
+
 @pytest.mark.parametrize("case", ["stan", "stan_nutpie", "naive", "stepsize", "massmatrix", "stan_far_start", "stan_jitter_f32", "stan_endsearly"])
 def test_fused_warmup_matches_stepwise(hip, rng, case):
     """Warm-up in batches (adapt! inside k_nuts, MODE 3 / 4) == transition + adapt! per iteration, bit for bit:
