@@ -1,4 +1,4 @@
-"""wall time of the adaptation phase of cfg2 (per-transition launches: adapt! needs every transition's α)"""
+"""wall time of the adaptation phase of cfg2 (fused warm-up batches, or AHMC_ADAPT_FUSED=0 for per-transition launches)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ahmc_amd as A
