@@ -113,6 +113,39 @@ template <class T> __device__ __forceinline__ T logaddexp(T x, T y) {
   T d = (x == y) ? T(0) : fabs(x - y);
   return jl_max(x, y) + log1p(exp(-d));
 }
+// exp for the leaf weight of the linear-domain NUTS kernels, one call per leapfrog.  Float64: the ROCm device library's
+// own algorithm (2^n range reduction with a two-part ln 2, degree-11 minimax Horner, ldexp; same constants, same
+// operation order, so the same bits as `exp`), with the Horner steps issued as three-address v_fma_f64.  The
+// compiler's version of that loop re-materialises each coefficient in front of a two-address v_fmac_f64 — 9 extra
+// VALU instructions per leaf of a kernel that is VALU-issue bound.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ double leaf_exp(double x) {
+  constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+  const double dn = __builtin_rint(x * C(0x3ff71547652b82feULL));                 // x·log2(e)
+  double t = __builtin_fma(dn, C(0xbfe62e42fefa39efULL), x);                      // − n·ln2 (high part)
+  t = __builtin_fma(dn, C(0xbc7abc9e3b39803fULL), t);                             // − n·ln2 (low part)
+  double q = __builtin_fma(t, C(0x3e5ade156a5dcb37ULL), C(0x3e928af3fca7ab0cULL));
+  q = fma3(t, q, C(0x3ec71dee623fde64ULL));
+  q = fma3(t, q, C(0x3efa01997c89e6b0ULL));
+  q = fma3(t, q, C(0x3f2a01a014761f6eULL));
+  q = fma3(t, q, C(0x3f56c16c1852b7b0ULL));
+  q = fma3(t, q, C(0x3f81111111122322ULL));
+  q = fma3(t, q, C(0x3fa55555555502a1ULL));
+  q = fma3(t, q, C(0x3fc5555555555511ULL));
+  q = fma3(t, q, C(0x3fe000000000000bULL));
+  q = __builtin_fma(t, q, 1.0);
+  q = __builtin_fma(t, q, 1.0);
+  double z = __builtin_ldexp(q, (int)dn);
+  z = x > 1024.0 ? Lim<double>::inf() : z;
+  z = x < -1075.0 ? 0.0 : z;
+  return z;
+}
+__device__ __forceinline__ float leaf_exp(float x) { return exp(x); }
+
 template <class T> __device__ __forceinline__ T maxabs(T a, T b) { return fabs(a) > fabs(b) ? a : b; }  // :526
 
 // ------------------------------------------------------------------------------------------------

@@ -373,7 +373,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               // instead of exp + log1p + log per merge.  Valid while no weight can overflow; a
               // chain that meets -ΔH > 600 is flagged and redone by the log-domain kernel.
               const T lw = H0 + ne;
-              w_c = exp(lw);
+              w_c = leaf_exp(lw);
               sa_c = jl_min(T(1), w_c);
               redo = redo || AHMC_UNI(lw > (sizeof(T) == 4 ? T(60) : T(LINW_LIMIT)));
             } else {
