@@ -382,15 +382,18 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             sub_term = AHMC_UNI(!(-H0 < p.delta_max + ne));  // Termination(::MultinomialTS, ...) (:503-507)
           }
           numerical = numerical || sub_term;
-          if (classic) copy_vec(A_c, cur.th); else copy_vec(A_c, cur.r);
-          copy_vec(RF_c, cur.r);
+          // a one-leaf subtree has ρ = r (Classic: θ) and first-built r = r of this leaf.  The general kernel copies
+          // them into A_c / RF_c here; the fast kernels read cur.r in their place until the first merge (below)
+          if constexpr (GENERAL) {
+            if (classic) copy_vec(A_c, cur.th); else copy_vec(A_c, cur.r);
+            copy_vec(RF_c, cur.r);
+          }
         }
         // merges: one per trailing zero bit of `leaf` (:649-673); trip count is wave-uniform
         const int nm = __builtin_ctz(leaf);
-        for (int lvl = 0; lvl < nm; ++lvl) {
-          const bool m = AHMC_UNI(alive && !sub_term);
-          if (__builtin_amdgcn_ballot_w64(m) == 0) break;
-          if (m) {
+        // A_in / RF_in: ρ (Classic: θ of the first-built leaf) and first-built r of the half just completed
+        auto merge_level = [&](const int lvl, const T (&A_in)[E], const T (&RF_in)[E]) {
+          {
             T A_p[E], RF_p[E];
             sl.load(NV * lvl, A_p);
             sl.load(NV * lvl + 1, RF_p);
@@ -431,7 +434,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               T dots[2] = {0, 0};
 #pragma unroll
               for (int e = 0; e < E; ++e) {
-                A_c[e] = A_p[e] + A_c[e];  // ρ = ρ_left + ρ_right
+                A_c[e] = A_p[e] + A_in[e];  // ρ = ρ_left + ρ_right
                 dots[0] += A_c[e] * (minv[e] * RF_p[e]);
                 dots[1] += A_c[e] * (minv[e] * cur.r[e]);
               }
@@ -446,13 +449,13 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               T dots[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
               for (int e = 0; e < E; ++e) {
-                const T rho = A_p[e] + A_c[e];
-                const T rho2 = A_p[e] + RF_c[e];
-                const T rho3 = RL_p[e] + A_c[e];
+                const T rho = A_p[e] + A_in[e];
+                const T rho2 = A_p[e] + RF_in[e];
+                const T rho3 = RL_p[e] + A_in[e];
                 dots[0] += rho * (minv[e] * RF_p[e]);
                 dots[1] += rho * (minv[e] * cur.r[e]);
                 dots[2] += rho2 * (minv[e] * RF_p[e]);
-                dots[3] += rho2 * (minv[e] * RF_c[e]);
+                dots[3] += rho2 * (minv[e] * RF_in[e]);
                 dots[4] += rho3 * (minv[e] * RL_p[e]);
                 dots[5] += rho3 * (minv[e] * cur.r[e]);
                 A_c[e] = rho;
@@ -462,6 +465,24 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             }
             copy_vec(RF_c, RF_p);
             merged = lvl + 1;
+          }
+        };
+        if constexpr (GENERAL) {
+          for (int lvl = 0; lvl < nm; ++lvl) {
+            const bool m = AHMC_UNI(alive && !sub_term);
+            if (__builtin_amdgcn_ballot_w64(m) == 0) break;
+            if (m) merge_level(lvl, A_c, RF_c);
+          }
+        } else if (nm > 0) {
+          // first merge peeled: the completed half is the single leaf `cur`; later merges carry A_c / RF_c
+          bool m = AHMC_UNI(alive && !sub_term);
+          if (__builtin_amdgcn_ballot_w64(m) != 0) {
+            if (m) merge_level(0, cur.r, cur.r);
+            for (int lvl = 1; lvl < nm; ++lvl) {
+              m = AHMC_UNI(alive && !sub_term);
+              if (__builtin_amdgcn_ballot_w64(m) == 0) break;
+              if (m) merge_level(lvl, A_c, RF_c);
+            }
           }
         }
         if (alive && sub_term) {
@@ -479,8 +500,13 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           alive = false;
         } else if (alive && leaf < nleaf) {
           // park the finished level-nm subtree until its sibling is built
-          sl.store(NV * nm, A_c);
-          sl.store(NV * nm + 1, RF_c);
+          if (GENERAL || nm > 0) {
+            sl.store(NV * nm, A_c);
+            sl.store(NV * nm + 1, RF_c);
+          } else {
+            sl.store(0, cur.r);
+            sl.store(1, cur.r);
+          }
           if (strict) sl.store(NV * nm + 2, cur.r);  // r of its last-built leaf
           S_W(nm) = w_c;
           S_SA(nm) = sa_c;
@@ -490,6 +516,12 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         }
       }
       // ---- top level of the doubling loop (:708-722) ----
+      if constexpr (!GENERAL) {
+        if (jw == 0) {  // the one-leaf subtree of the first doubling never went through a merge
+          copy_vec(A_c, cur.r);
+          copy_vec(RF_c, cur.r);
+        }
+      }
       if (!done) {
         if (!sub_term) {
           ++depth;
