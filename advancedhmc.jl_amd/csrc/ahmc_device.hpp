@@ -220,10 +220,34 @@ __device__ __forceinline__ void wave_allsum2(T& a, T& b) {
   b = dpp_mov<0x151>(x);  // row_newbcast:1
 }
 
+// the same for FOUR values: two transposed exchanges (lane & 1, then lane & 2) leave one value per lane, lanes 0..3 of
+// the row are broadcast back.  14 + 7 + 3 + 3 (+5 +5) + 8 = 45 VALU for G = 64 against 2 x 30, and the additions each
+// value goes through are those of wave_allsum2 (a, b as there; c, d as a second pair), so the results are bit-identical.
+template <int G, class T>
+__device__ __forceinline__ void wave_allsum4(T& a, T& b, T& c, T& d) {
+  static_assert(G == 16 || G == 32 || G == 64, "quad reduction needs whole 16-lane rows");
+  const bool odd = (threadIdx.x & 1u) != 0, up = (threadIdx.x & 2u) != 0;
+  const T x = (odd ? b : a) + dpp_mov<0xB1>(odd ? a : b);  // quad_perm [1,0,3,2]
+  const T y = (odd ? d : c) + dpp_mov<0xB1>(odd ? c : d);
+  T z = (up ? y : x) + dpp_mov<0x4E>(up ? x : y);          // quad_perm [2,3,0,1]
+  z += dpp_mov<0x124>(z);                                   // row_ror:4
+  z += dpp_mov<0x128>(z);                                   // row_ror:8
+  if constexpr (G >= 32) z = xor16_sum(z);
+  if constexpr (G >= 64) z = xor32_sum(z);
+  a = dpp_mov<0x150>(z);  // row_newbcast:0..3
+  b = dpp_mov<0x151>(z);
+  c = dpp_mov<0x152>(z);
+  d = dpp_mov<0x153>(z);
+}
+
 // all-reduce (sum) of K independent values across the G lanes of each group
 template <int G, class T, int K>
 __device__ __forceinline__ void wave_allsum(T (&v)[K]) {
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group size");
+  if constexpr (G >= 16 && K == 4) {
+    wave_allsum4<G>(v[0], v[1], v[2], v[3]);
+    return;
+  }
   if constexpr (G >= 16 && K % 2 == 0) {
 #pragma unroll
     for (int k = 0; k < K; k += 2) wave_allsum2<G>(v[k], v[k + 1]);
@@ -489,6 +513,31 @@ __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E]
   group_allsum<G>(red);
   z.lp = sanitize(red[0]);
   z.lk = sanitize(-red[1] / 2);
+}
+
+// leapfrog_step (untempered) that sums two more caller-supplied partials of the UPDATED point in the same all-reduce
+// as ℓπ and the kinetic energy: the NUTS kernels pass the two U-turn dot products of the merge that follows the
+// leaf, which saves one of the two reductions of such a leaf (15 of 60 VALU; a barrier pair in the multi-wave groups).
+// Every value takes exactly the additions it would take in a reduction of its own, so the bits do not change.
+template <class T, int G, int E, int TK, class F>
+__device__ __forceinline__ void leapfrog_step_plus2(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp, int lane, int d0,
+                                                    T (&extra)[2], F&& partials) {
+  const T eh = eps / 2;
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
+  T red[4];
+  red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+  red[1] = kinetic_partial(z.r, minv);
+  partials(red[2], red[3]);
+  group_allsum<G>(red);
+  z.lp = sanitize(red[0]);
+  z.lk = sanitize(-red[1] / 2);
+  extra[0] = red[2];
+  extra[1] = red[3];
 }
 
 // phasepoint(h, θ, r): fill the caches at the current (θ, r) (src/hamiltonian.jl:115-119)

@@ -24,6 +24,8 @@
 // removes every candidate copy from the merge path.
 #pragma once
 
+#include <type_traits>
+
 #include "ahmc_kernels.hpp"
 
 namespace ahmc {
@@ -183,6 +185,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   const int NLEV = p.max_depth > 1 ? p.max_depth - 1 : 1;  // pending levels 0 .. NLEV-1
   constexpr bool LINW = MODE == 0 || MODE == 3;
   constexpr bool GENERAL = MODE == 2;
+  // Fast kernels of the multi-wave groups: the first merge's U-turn dot products are reduced together with the leaf's
+  // energies (one barrier pair less per such leaf; cfg5 +7 %).  Measured SLOWER for one wave per chain (cfg2 2.12e9 ->
+  // 1.87e9 although 216 -> 212 VALU per leapfrog), so G <= 64 keeps two reductions.
+  constexpr bool FUSE_M0 = !GENERAL && G > 64;
   constexpr bool ADAPT = MODE >= 3;  // MODE 0 / 1 + adapt!(…) after every transition, inside the kernel (AdaptK)
   const bool strict = GENERAL && p.criterion == 2;
   const int NV = strict ? 3 : 2;  // vectors per pending level: A, RF (, RL)
@@ -352,9 +358,31 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       for (uint32_t leaf = 1; leaf <= nleaf; ++leaf) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
         int merged = 0;
+        // merges after this leaf: one per trailing zero bit of `leaf` (:649-673); the count is wave-uniform
+        const int nm = __builtin_ctz(leaf);
+        T dots_m0[2] = {0, 0}, RF_m0[E];  // fast kernels: U-turn dot products / first-built r of the FIRST merge
         if (alive) {
           // leaf: one leapfrog step in direction v (:638-647)
-          leapfrog_step<T, G, E, TK, GENERAL>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+          if constexpr (GENERAL) {
+            leapfrog_step<T, G, E, TK, true>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+          } else if (FUSE_M0 && nm > 0) {
+            // a merge follows: its two dot products ride in the leaf's all-reduce (they only need the new r)
+            leapfrog_step_plus2<T, G, E, TK>(cur, minv, v > 0 ? eps : -eps, p.tp, lane, d0, dots_m0, [&](T& s0, T& s1) {
+              T A_p[E];
+              sl.load(0, A_p);
+              sl.load(1, RF_m0);
+              s0 = 0;
+              s1 = 0;
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                A_c[e] = A_p[e] + cur.r[e];  // ρ = ρ_left + ρ_right
+                s0 += A_c[e] * (minv[e] * RF_m0[e]);
+                s1 += A_c[e] * (minv[e] * cur.r[e]);
+              }
+            });
+          } else {
+            leapfrog_step<T, G, E, TK, false>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+          }
           pos_cur += v;
           const T ne = cur.lp + cur.lk;  // neg_energy(z′)
           const T dH = -ne - H0;
@@ -389,14 +417,15 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             copy_vec(RF_c, cur.r);
           }
         }
-        // merges: one per trailing zero bit of `leaf` (:649-673); trip count is wave-uniform
-        const int nm = __builtin_ctz(leaf);
-        // A_in / RF_in: ρ (Classic: θ of the first-built leaf) and first-built r of the half just completed
-        auto merge_level = [&](const int lvl, const T (&A_in)[E], const T (&RF_in)[E]) {
+        // A_in / RF_in: ρ (Classic: θ of the first-built leaf) and first-built r of the half just completed;
+        // pre: the first merge of a fast kernel — A_c, the dot products and RF_p were made with the leaf (above)
+        auto merge_level = [&](const int lvl, const T (&A_in)[E], const T (&RF_in)[E], auto pre) {
           {
             T A_p[E], RF_p[E];
-            sl.load(NV * lvl, A_p);
-            sl.load(NV * lvl + 1, RF_p);
+            if constexpr (!pre.value) {
+              sl.load(NV * lvl, A_p);
+              sl.load(NV * lvl + 1, RF_p);
+            }
             const T w_p = S_W(lvl);
             // combine(rng, sampler′, sampler′′): `first` = the half built first (:178-195)
             bool keep_first;
@@ -431,15 +460,19 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               group_allsum<G>(dots);
               sub_term = (dots[0] >= 0) || (dots[1] >= 0);
             } else if (!strict) {
-              T dots[2] = {0, 0};
+              T dots[2] = {dots_m0[0], dots_m0[1]};
+              if constexpr (!pre.value) {
+                dots[0] = 0;
+                dots[1] = 0;
 #pragma unroll
-              for (int e = 0; e < E; ++e) {
-                A_c[e] = A_p[e] + A_in[e];  // ρ = ρ_left + ρ_right
-                dots[0] += A_c[e] * (minv[e] * RF_p[e]);
-                dots[1] += A_c[e] * (minv[e] * cur.r[e]);
+                for (int e = 0; e < E; ++e) {
+                  A_c[e] = A_p[e] + A_in[e];  // ρ = ρ_left + ρ_right
+                  dots[0] += A_c[e] * (minv[e] * RF_p[e]);
+                  dots[1] += A_c[e] * (minv[e] * cur.r[e]);
+                }
+                group_allsum<G>(dots);
               }
-              group_allsum<G>(dots);
-              sub_term = AHMC_UNI((dots[0] <= 0) || (dots[1] <= 0));  // generalised_uturn_criterion (:619-621)
+              sub_term = AHMC_UNI(dots[0] <= 0) || AHMC_UNI(dots[1] <= 0);  // generalised_uturn_criterion (:619-621)
             } else {
               // StrictGeneralisedNoUTurn (:579-617).  F = the pending (first-built) half, S = the half
               // just completed; in built order the two extra checks are symmetric in the direction:
@@ -463,7 +496,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               group_allsum<G>(dots);
               sub_term = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
             }
-            copy_vec(RF_c, RF_p);
+            if constexpr (pre.value) copy_vec(RF_c, RF_m0); else copy_vec(RF_c, RF_p);
             merged = lvl + 1;
           }
         };
@@ -471,17 +504,18 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           for (int lvl = 0; lvl < nm; ++lvl) {
             const bool m = AHMC_UNI(alive && !sub_term);
             if (__builtin_amdgcn_ballot_w64(m) == 0) break;
-            if (m) merge_level(lvl, A_c, RF_c);
+            if (m) merge_level(lvl, A_c, RF_c, std::false_type{});
           }
         } else if (nm > 0) {
-          // first merge peeled: the completed half is the single leaf `cur`; later merges carry A_c / RF_c
+          // first merge peeled: the completed half is the single leaf `cur` (its vector work was done with the leaf);
+          // later merges carry A_c / RF_c
           bool m = AHMC_UNI(alive && !sub_term);
           if (__builtin_amdgcn_ballot_w64(m) != 0) {
-            if (m) merge_level(0, cur.r, cur.r);
+            if (m) merge_level(0, cur.r, cur.r, std::bool_constant<FUSE_M0>{});
             for (int lvl = 1; lvl < nm; ++lvl) {
               m = AHMC_UNI(alive && !sub_term);
               if (__builtin_amdgcn_ballot_w64(m) == 0) break;
-              if (m) merge_level(lvl, A_c, RF_c);
+              if (m) merge_level(lvl, A_c, RF_c, std::false_type{});
             }
           }
         }
@@ -565,7 +599,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               dots[1] += A_tree[e] * (minv[e] * oth_r[e]);
             }
             group_allsum<G>(dots);
-            turn = AHMC_UNI((dots[0] <= 0) || (dots[1] <= 0));
+            turn = AHMC_UNI(dots[0] <= 0) || AHMC_UNI(dots[1] <= 0);
           } else {
             // strict at the top: (ρ_tree + r_sub.first ; ends other edge, sub.first) and
             //                    (r_start + ρ_sub ; ends start edge, current edge)
