@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 # --- enums (mirror include/ahmc_hip.h) --------------------------------------------------------
-AHMC_ABI_VERSION = 1
+AHMC_ABI_VERSION = 2
 OK, ERR_ARGUMENT, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_STATE = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
@@ -112,6 +112,11 @@ SIGNATURES = {
     "ahmc_get_accum": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
     "ahmc_reset_accum": (_i32, [_vp]),
     "ahmc_get_info": (_i32, [_vp, _i32, C.POINTER(_i64)]),
+    "ahmc_ext_begin": (_i32, [_vp, C.POINTER(KernelCfg), _i32]),
+    "ahmc_ext_find_good_stepsize_begin": (_i32, [_vp, _f64, _i32]),
+    "ahmc_ext_pending": (_i32, [_vp, C.POINTER(_i64), _vp, _vp]),
+    "ahmc_ext_advance": (_i32, [_vp, _vp, _vp]),
+    "ahmc_ext_cancel": (_i32, [_vp]),
 }
 
 

@@ -184,12 +184,17 @@ def DenseGaussian(P):
 @dataclass
 class ExternalTarget:
     """User log-density evaluated by the caller: `fn(θ (D,N)) -> (ℓπ (N,), ∇ℓπ (D,N))`, the
-    signature of `∂ℓπ∂θ` at test/common.jl:64-74.  Leapfrog runs through the split-step pair
-    ahmc_lf_pre / ahmc_lf_post around this callback."""
+    signature of `∂ℓπ∂θ` at test/common.jl:64-74 (what `Hamiltonian(metric, ℓπ, ∂ℓπ∂θ)` /
+    LogDensityProblems hand the reference, src/AdvancedHMC.jl:163-186).  `Engine.step` runs through the
+    split-step pair ahmc_lf_pre / ahmc_lf_post around this callback; whole transitions and
+    find_good_stepsize run through the ask / tell calls ahmc_ext_* (`Engine._ext_drive`).  `fn` may
+    also accept `fn(θ, chains)` — the indices of the columns that need evaluating — when
+    `takes_chains` is set; the other columns of its result are ignored."""
     D: int
     fn: object
     kind: int = capi.TARGET_EXTERNAL
     params: Optional[np.ndarray] = None
+    takes_chains: bool = False
 
 
 @dataclass
@@ -576,6 +581,10 @@ class Engine:
     def transition(self, kernel: HMCKernel):
         """transition(rng, h, κ, z) (src/sampler.jl:48-58)"""
         k = kernel.cfg()
+        if self._external:
+            self._call("ahmc_ext_begin", C.byref(k), 1)
+            self._ext_drive()
+            return
         if k.refresh_alpha != 0.0:
             raise capi.UnsupportedError(capi.ERR_UNSUPPORTED, "PartialMomentumRefreshment runs through Engine.sample")
         if k.nuts:
@@ -597,8 +606,41 @@ class Engine:
 
     def find_good_stepsize(self, initial_step_size=0.1, max_n_iters=100):
         """find_good_stepsize(rng, h, θ) per chain (src/trajectory.jl:768-837)"""
-        self._call("ahmc_find_good_stepsize", float(initial_step_size), int(max_n_iters))
+        if self._external:
+            self._call("ahmc_ext_find_good_stepsize_begin", float(initial_step_size), int(max_n_iters))
+            self._ext_drive()
+        else:
+            self._call("ahmc_find_good_stepsize", float(initial_step_size), int(max_n_iters))
         return self.get_stepsize()
+
+    # -- external target: the ask / tell loop (include/ahmc_hip.h, ahmc_ext_*) --
+    def _ext_drive(self):
+        """Serve the engine's evaluation requests with the user's `fn` until the run started by
+        ahmc_ext_begin / ahmc_ext_find_good_stepsize_begin is complete.  Returns the number of
+        round trips (= evaluations of `fn`)."""
+        n = C.c_int64()
+        chains = np.empty(self.N, dtype=np.int32)
+        theta = self._out()
+        lp_buf = np.zeros(self.N, dtype=self.dtype)
+        g_buf = np.zeros((self.D, self.N), dtype=self.dtype, order="F")
+        trips = 0
+        try:
+            while True:
+                self._call("ahmc_ext_pending", C.byref(n), capi.as_ptr(chains), capi.as_ptr(theta))
+                if n.value == 0:
+                    return trips
+                idx = chains[:n.value]
+                if self.h.target.takes_chains:
+                    lp, grad = self.h.target.fn(theta, idx)
+                else:
+                    lp, grad = self.h.target.fn(theta)
+                lp_buf[idx] = np.asarray(lp, dtype=self.dtype).reshape(self.N)[idx]
+                g_buf[:, idx] = -np.asarray(grad, dtype=self.dtype).reshape(self.D, self.N)[:, idx]
+                self._call("ahmc_ext_advance", capi.as_ptr(lp_buf), capi.as_ptr(g_buf))
+                trips += 1
+        except BaseException:
+            self.lib.dll.ahmc_ext_cancel(self._ctx)
+            raise
 
     # -- adaptation --
     def adaptor_init(self, adaptor):
@@ -622,8 +664,16 @@ class Engine:
 
     # -- bulk driver --
     def run(self, kernel: HMCKernel, n_samples, n_adapts=0, drop_warmup=False, samples_out=None):
-        """The whole `sample` loop enqueued by one C call (no host synchronisation inside)."""
+        """The whole `sample` loop enqueued by one C call (no host synchronisation inside).  With an
+        ExternalTarget the loop runs here, one ask / tell transition + adapt! per iteration."""
         k = kernel.cfg()
+        if self._external:
+            if samples_out is not None:
+                raise capi.UnsupportedError(capi.ERR_UNSUPPORTED, "samples_out with an ExternalTarget: use sample()")
+            for i in range(1, int(n_samples) + 1):
+                self.transition(kernel)
+                self.adapt(i, int(n_adapts))
+            return
         self._call("ahmc_sample", C.byref(k), int(n_samples), int(n_adapts), 1 if drop_warmup else 0,
                    capi.as_ptr(samples_out))
 
@@ -695,7 +745,10 @@ def sample(rng, h: Hamiltonian, kernel: HMCKernel, theta, n_samples: int, adapto
         thetas, stats = [], []
         one = capi.KernelCfg.from_buffer_copy(k)
         for i in range(1, n_samples + 1):
-            eng._call("ahmc_sample", C.byref(one), 1, 0, 0, None)  # transition(rng, h, κ, t.z) (:184)
+            if eng._external:
+                eng.transition(kernel)  # the same transition with the user's ∂ℓπ∂θ served through ahmc_ext_*
+            else:
+                eng._call("ahmc_sample", C.byref(one), 1, 0, 0, None)  # transition(rng, h, κ, t.z) (:184)
             st = eng.stats()
             isadapted = i <= n_adapts and not isinstance(adaptor, NoAdaptation)
             eng.adapt(i, n_adapts)

@@ -3,7 +3,9 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
 git-ignored but travels with the repo snapshot to the GPU box.
 
-Translation units (compiled in parallel, objects cached under csrc/build/):
+Translation units (compiled in parallel; objects cached under csrc/build/, each with the digest of the
+files it was compiled from — taken from the compiler's own dependency list — so that a change to the host
+side or to the dense engine does not recompile the eight log-density instantiations):
   ahmc_api.hip                      host side of the C ABI + the target-independent kernels
   ahmc_inst.hip  × {f32,f64} × {iso,diag,funnel,hier}
                                     the kernels that evaluate a built-in log-density family, which is
@@ -55,13 +57,42 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc not found: cannot build the HIP engine (and there is no fallback)")
     os.makedirs(OBJ, exist_ok=True)
 
+    def unit_digest(depfile, defs):
+        """sha256 over the unit's flags and the project files the compiler read for it (None if unknown)"""
+        try:
+            words = open(depfile).read().replace("\\\n", " ").split()
+        except OSError:
+            return None
+        roots = (os.path.realpath(CSRC), os.path.realpath(INCLUDE))
+        files = sorted({os.path.realpath(w) for w in words[1:] if os.path.realpath(w).startswith(roots)})
+        if not files:
+            return None
+        h = hashlib.sha256(" ".join(FLAGS + defs).encode())
+        for f in files:
+            if not os.path.exists(f):
+                return None
+            h.update(f.encode())
+            h.update(open(f, "rb").read())
+        return h.hexdigest()
+
     def compile_one(unit):
         name, src, defs = unit
         obj = os.path.join(OBJ, name + ".o")
-        cmd = [hipcc, *FLAGS, *defs, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        dep, dig = obj + ".d", obj + ".digest"
+        if not force and os.path.exists(obj) and os.path.exists(dig):
+            d = unit_digest(dep, defs)
+            if d is not None and d == open(dig).read():
+                if verbose:
+                    print("up to date", name)
+                return obj
+        cmd = [hipcc, *FLAGS, *defs, "-I", INCLUDE, "-MD", "-MF", dep, "-c", os.path.join(CSRC, src), "-o", obj]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed on {name}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        d = unit_digest(dep, defs)
+        if d is not None:
+            with open(dig, "w") as f:
+                f.write(d)
         if verbose:
             print("compiled", name)
         return obj

@@ -60,6 +60,22 @@ StanWindows stan_windows(int64_t init_buffer, int64_t term_buffer, int64_t windo
   return w;
 }
 
+// an ahmc_ext_* run in progress (external target, ask / tell: ahmc_ext_host.hpp)
+enum { EXT_IDLE = 0, EXT_NUTS = 1, EXT_HMC = 2, EXT_FINDEPS = 3 };
+struct ExtRun {
+  int mode = EXT_IDLE;
+  ahmc_kernel_cfg cfg{};
+  int n_trans = 0;
+  int it = 0;            // static HMC: transition in progress
+  int64_t L = 0, l = 0;  // static HMC: leapfrogs per transition / completed in this one
+  const int* list = nullptr;  // device list of the chains the engine waits for (null = all N)
+  int64_t n_list = 0;
+  int pp = 0;  // which half of dn_list the next compaction writes
+  int64_t steps = 0, max_steps = 0;
+  double fe_init = 0;
+  int fe_max = 0, fe_it = 0, fe_total = 0;
+};
+
 template <class T>
 struct Ctx : CtxBase {
   int64_t D = 0, N = 0;
@@ -146,6 +162,9 @@ struct Ctx : CtxBase {
   hipEvent_t stage_ready[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
   bool stage_busy[2] = {false, false};
   int64_t wc_n = 0;
+  // external target, ask / tell (ahmc_ext_host.hpp): the run in progress; staging for a caller's host (ℓπ, -∇ℓπ)
+  ExtRun ext;
+  T *ext_gstage = nullptr, *ext_lpstage = nullptr;
 
   ~Ctx() override {
     (void)hipSetDevice(device);
@@ -155,7 +174,7 @@ struct Ctx : CtxBase {
       if (e) (void)hipEventDestroy(e);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C};
+                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C, ext_gstage, ext_lpstage};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending})
@@ -262,6 +281,7 @@ int launch_fill_caches_builtin(Ctx<T>* c) {
 }
 
 #include "ahmc_dense_host.hpp"
+#include "ahmc_ext_host.hpp"
 
 template <class T>
 int launch_fill_caches(Ctx<T>* c) {
@@ -824,6 +844,14 @@ int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, in
     else { using T = double; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ }                         \
   } while (0)
 
+// entry points that change the context: refused while an ahmc_ext_* run is in progress
+#define FOR_CTX_MUT(ctx, ...)                                                                                        \
+  FOR_CTX(ctx, {                                                                                                     \
+    if (c->ext.mode != EXT_IDLE)                                                                                     \
+      return fail(c, AHMC_ERR_STATE, std::string(__func__) + ": an ahmc_ext_* run is in progress (finish it or call ahmc_ext_cancel)"); \
+    __VA_ARGS__                                                                                                      \
+  })
+
 template <class T>
 static int32_t create_impl(int32_t device, int32_t dtype, int64_t D, int64_t N, void* stream, ahmc_ctx** out) {
   auto* c = new Ctx<T>();
@@ -923,7 +951,7 @@ void* ahmc_stream(ahmc_ctx* ctx) {
 }
 
 int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     int64_t need = 0;
     switch (kind) {
       case AHMC_TARGET_ISO_GAUSS: case AHMC_TARGET_FUNNEL: case AHMC_TARGET_HIER_GAUSS: case AHMC_TARGET_EXTERNAL: need = 0; break;
@@ -948,7 +976,7 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
 }
 
 int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n) {
-  FOR_CTX(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
+  FOR_CTX_MUT(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
 }
 
 int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
@@ -962,7 +990,7 @@ int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
 }
 
 int32_t ahmc_set_stepsize(ahmc_ctx* ctx, const void* eps, int64_t n) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!eps || (n != 1 && n != c->N)) return fail(c, AHMC_ERR_ARGUMENT, "set_stepsize: need 1 or N step sizes");
     if (n == 1) {
       T v;
@@ -990,7 +1018,7 @@ int32_t ahmc_get_stepsize(ahmc_ctx* ctx, void* out) {
 }
 
 int32_t ahmc_set_integrator(ahmc_ctx* ctx, int32_t kind, double param) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (kind < AHMC_INTEGRATOR_LEAPFROG || kind > AHMC_INTEGRATOR_TEMPERED) return fail(c, AHMC_ERR_ARGUMENT, "set_integrator: unknown kind");
     c->integ_kind = kind;
     c->integ_param = param;
@@ -999,14 +1027,14 @@ int32_t ahmc_set_integrator(ahmc_ctx* ctx, int32_t kind, double param) {
 }
 
 int32_t ahmc_seed(ahmc_ctx* ctx, uint64_t seed, uint64_t chain_offset, uint64_t chain_stride, uint64_t iteration) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     c->seed = seed; c->chain_offset = chain_offset; c->chain_stride = chain_stride; c->iteration = iteration;
     return AHMC_OK;
   });
 }
 
 int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!theta) return fail(c, AHMC_ERR_ARGUMENT, "set_position: theta is NULL");
     int rc = dense_engine(c) ? dn_check(c, "set_position", 0) : check_builtin(c, "set_position");
     if (rc) return rc;
@@ -1023,7 +1051,7 @@ int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r) {
 }
 
 int32_t ahmc_set_phasepoint(ahmc_ctx* ctx, const void* theta, const void* r, const void* lp, const void* grad) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!theta || !r || !lp || !grad) return fail(c, AHMC_ERR_ARGUMENT, "set_phasepoint: NULL argument");
     const size_t nb = sizeof(T) * c->D * c->N;
     HIPCHK(hipMemcpyAsync(c->th, theta, nb, hipMemcpyDefault, c->stream));
@@ -1052,7 +1080,7 @@ int32_t ahmc_get_phasepoint(ahmc_ctx* ctx, void* theta, void* r, void* lp, void*
 }
 
 int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "refresh before set_position");
     if (dense_engine(c)) return dn_refresh(c, alpha);
     int rc = check_builtin(c, "refresh_momentum");
@@ -1066,7 +1094,7 @@ int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
 }
 
 int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "leapfrog before set_position");
     if (dense_engine(c)) return dn_leapfrog(c, n_steps);
     int rc = check_builtin(c, "leapfrog");
@@ -1080,7 +1108,7 @@ int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
 }
 
 int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "lf_pre before set_phasepoint");
     if (c->metric_kind == AHMC_METRIC_DENSE) return fail(c, AHMC_ERR_UNSUPPORTED, "lf_pre/lf_post are not implemented for DenseEuclideanMetric");
     KP<T> p = make_kp(c);
@@ -1092,7 +1120,7 @@ int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps) {
 }
 
 int32_t ahmc_lf_post(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps, const void* lp, const void* grad_neg) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!lp || !grad_neg) return fail(c, AHMC_ERR_ARGUMENT, "lf_post: NULL argument");
     const int64_t DN = c->D * c->N;
     // stage the caller's arrays (host or device) through c->g / c->lp
@@ -1124,11 +1152,11 @@ void* ahmc_theta_ptr(ahmc_ctx* ctx) {
 }
 
 int32_t ahmc_hmc_transition(ahmc_ctx* ctx, int64_t L, double lambda, int32_t sampler) {
-  FOR_CTX(ctx, { return hmc_transition(c, L, lambda, sampler, 0.0, false); });
+  FOR_CTX_MUT(ctx, { return hmc_transition(c, L, lambda, sampler, 0.0, false); });
 }
 
 int32_t ahmc_nuts_transition(ahmc_ctx* ctx, int32_t max_depth, double delta_max, int32_t criterion, int32_t sampler) {
-  FOR_CTX(ctx, { return nuts_transition(c, max_depth, delta_max, criterion, sampler, 0.0, false); });
+  FOR_CTX_MUT(ctx, { return nuts_transition(c, max_depth, delta_max, criterion, sampler, 0.0, false); });
 }
 
 int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
@@ -1157,7 +1185,7 @@ int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
 }
 
 int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "find_good_stepsize before set_position");
     if (dense_engine(c)) return dn_find_eps(c, initial_step_size, max_n_iters);
     int rc = check_builtin(c, "find_good_stepsize");
@@ -1176,18 +1204,18 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
 }
 
 int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t init_buffer, int32_t term_buffer, int32_t window_size) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (kind < AHMC_ADAPT_NONE || kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: unknown adaptor kind");
     return adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
   });
 }
 
 int32_t ahmc_adapt_point(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* grad, const void* alpha) {
-  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha), static_cast<const T*>(grad)); });
+  FOR_CTX_MUT(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha), static_cast<const T*>(grad)); });
 }
 
 int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t est) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (est != AHMC_VAR_WELFORD && est != AHMC_VAR_NUTPIE) return fail(c, AHMC_ERR_ARGUMENT, "set_var_estimator: unknown estimator");
     c->var_estimator = est;
     return AHMC_OK;
@@ -1195,7 +1223,7 @@ int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t est) {
 }
 
 int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* alpha) {
-  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha)); });
+  FOR_CTX_MUT(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha)); });
 }
 
 int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size, int64_t n_adapts,
@@ -1210,7 +1238,7 @@ int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t wind
 }
 
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup, void* samples_out) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample: cfg is NULL");
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "sample before set_position");
     if (drop_warmup && c->adapt_kind == AHMC_ADAPT_NONE)
@@ -1337,6 +1365,31 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
   });
 }
 
+// ---- external target: ask / tell (ahmc_ext_host.hpp) ----
+int32_t ahmc_ext_begin(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int32_t n_trans) {
+  FOR_CTX(ctx, { return ext_begin(c, cfg, (int)n_trans); });
+}
+
+int32_t ahmc_ext_find_good_stepsize_begin(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
+  FOR_CTX(ctx, { return ext_find_eps_begin(c, initial_step_size, (int)max_n_iters); });
+}
+
+int32_t ahmc_ext_pending(ahmc_ctx* ctx, int64_t* n_pending, int32_t* chains_out, void* theta_out) {
+  FOR_CTX(ctx, { return ext_pending(c, n_pending, chains_out, theta_out); });
+}
+
+int32_t ahmc_ext_advance(ahmc_ctx* ctx, const void* lp, const void* grad_neg) {
+  FOR_CTX(ctx, { return ext_advance(c, lp, grad_neg); });
+}
+
+int32_t ahmc_ext_cancel(ahmc_ctx* ctx) {
+  FOR_CTX(ctx, {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->ext = ExtRun();
+    return AHMC_OK;
+  });
+}
+
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
   FOR_CTX(ctx, {
     if (!out) return fail(c, AHMC_ERR_ARGUMENT, "get_info: out is NULL");
@@ -1377,7 +1430,7 @@ int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transit
 }
 
 int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
-  FOR_CTX(ctx, { return reset_accum(c); });
+  FOR_CTX_MUT(ctx, { return reset_accum(c); });
 }
 
 }  // extern "C"

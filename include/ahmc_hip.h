@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHMC_ABI_VERSION 1
+#define AHMC_ABI_VERSION 2
 
 typedef struct ahmc_ctx ahmc_ctx;
 
@@ -55,8 +55,9 @@ enum { AHMC_F32 = 0, AHMC_F64 = 1 };
 enum { AHMC_METRIC_UNIT = 0, AHMC_METRIC_DIAG = 1, AHMC_METRIC_DENSE = 2 };
 
 /* built-in log-density families evaluated inside the kernels (SURVEY.md §8d synthetic inputs);
- * AHMC_TARGET_EXTERNAL = caller computes (ℓπ, ∇ℓπ) between ahmc_lf_pre and ahmc_lf_post, i.e.
- * the `h.∂ℓπ∂θ(θ)` callback of src/hamiltonian.jl:45-48 stays on the Julia side.             */
+ * AHMC_TARGET_EXTERNAL = the caller computes (ℓπ, ∇ℓπ): the `h.∂ℓπ∂θ(θ)` callback of
+ * src/hamiltonian.jl:45-48 stays on the Julia side — single leapfrogs between ahmc_lf_pre and
+ * ahmc_lf_post, whole transitions through the ask / tell calls ahmc_ext_*.                   */
 enum {
   AHMC_TARGET_ISO_GAUSS = 0,  /* ℓπ = Σ -(log2π + θ²)/2           test/common.jl:40-44, m=0,s=1 */
   AHMC_TARGET_DIAG_GAUSS = 1, /* params: m[D], s[D]                test/common.jl:35-77           */
@@ -269,6 +270,49 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
 int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transitions,
                        int64_t* n_divergent, void* sum_theta, void* sumsq_theta);
 int32_t ahmc_reset_accum(ahmc_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------ */
+/* whole transitions with an EXTERNAL target: ask / tell                                      */
+/*
+ * With AHMC_TARGET_EXTERNAL the user's log-density — the `h.∂ℓπ∂θ(θ)` callback of
+ * src/hamiltonian.jl:45-48, i.e. LogDensityProblems.logdensity_and_gradient behind
+ * src/AdvancedHMC.jl:163-186 — stays with the caller; everything else of
+ * transition(rng, h, κ, z) (src/sampler.jl:48-58; static :271-300, NUTS :677-742) and of
+ * find_good_stepsize (:768-837) runs in the engine.  The engine advances every running chain to
+ * the point where its next leapfrog needs (ℓπ, ∇ℓπ), then hands control back:
+ *
+ *     ahmc_ext_begin(ctx, &cfg, n_trans);              // or ahmc_ext_find_good_stepsize_begin
+ *     for (;;) {
+ *       ahmc_ext_pending(ctx, &n, chains, theta);      // n == 0: finished
+ *       if (n == 0) break;
+ *       // caller: lp[c], grad_neg[:, c] = ℓπ(θ[:, c]), -∇ℓπ(θ[:, c]) for the n listed chains
+ *       ahmc_ext_advance(ctx, lp, grad_neg);
+ *     }
+ *
+ * Chains run asynchronously through the n_trans transitions (a chain that ends one starts its next
+ * in the same call); the statistics, the phase point and the iteration counter are those of
+ * n_trans calls of ahmc_*_transition.  The engine reuses the cached (ℓπ, ∇ℓπ) of the start point
+ * where the reference's `refresh` re-evaluates it (src/hamiltonian.jl:213-220 → phasepoint :115-119):
+ * identical for a deterministic log-density (the CPU oracle asks for that evaluation, as the
+ * reference does).  HIP engine: runs on the step-synchronous engine of the dense metric — Unit /
+ * Diag / Dense metric, Leapfrog / JitteredLeapfrog, full refreshment, static EndPointTS, NUTS with
+ * MultinomialTS / SliceTS + GeneralisedNoUTurn; anything else is AHMC_ERR_UNSUPPORTED.
+ * Any other call that changes the context between begin and the end of the loop is
+ * AHMC_ERR_STATE; ahmc_ext_cancel abandons the run (the phase point is then unspecified: set it
+ * again).                                                                                      */
+int32_t ahmc_ext_begin(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int32_t n_trans);
+/* find_good_stepsize(rng, h, θ) per chain (src/trajectory.jl:768-837) with the caller's ℓπ     */
+int32_t ahmc_ext_find_good_stepsize_begin(ahmc_ctx* ctx, double initial_step_size,
+                                          int32_t max_n_iters);
+/* What the engine waits for.  *n_pending chains (0 = the run is complete); chains_out (int32[N],
+ * host, may be NULL) receives their indices in unspecified order; theta_out ((D,N), host or device,
+ * may be NULL) receives the positions to evaluate — only the listed columns are meaningful.  On
+ * the HIP engine they are also in place at ahmc_theta_ptr(ctx) for zero-copy evaluation.       */
+int32_t ahmc_ext_pending(ahmc_ctx* ctx, int64_t* n_pending, int32_t* chains_out, void* theta_out);
+/* lp T[N], grad_neg (D,N) = -∇ℓπ (the sign convention of ahmc_lf_post): the entries of the pending
+ * chains are read, the others ignored.  A non-finite ℓπ becomes -Inf (src/hamiltonian.jl:95-104). */
+int32_t ahmc_ext_advance(ahmc_ctx* ctx, const void* lp, const void* grad_neg);
+int32_t ahmc_ext_cancel(ahmc_ctx* ctx);
 
 /* Engine introspection (no reference counterpart; used by bench.py to price the roofline per launch
  * and by the tests to assert which thread geometry ran).                                        */

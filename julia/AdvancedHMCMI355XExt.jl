@@ -53,6 +53,9 @@ struct DiagGaussian{T} <: DeviceTarget
 end
 struct Funnel <: DeviceTarget end
 struct HierGaussian <: DeviceTarget end
+"The Hamiltonian's own `∂ℓπ∂θ` closure (any LogDensityProblems model, src/AdvancedHMC.jl:163-186): evaluated in Julia,
+served to the engine through the ask / tell calls `ahmc_ext_*`."
+struct UserDensity <: DeviceTarget end
 
 """
     MI355XChains{T}
@@ -64,12 +67,13 @@ mutable struct MI355XChains{T<:AbstractFloat}
     ctx::Ptr{Cvoid}
     D::Int
     N::Int
+    user_density::Bool   # target = UserDensity(): transitions go through ahmc_ext_* with h.∂ℓπ∂θ
     function MI355XChains{T}(D::Int, N::Int; device::Int=0) where {T}
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         code = ccall((:ahmc_create, LIB), Cint, (Cint, Cint, Int64, Int64, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
                      device, T === Float32 ? F32 : F64, D, N, C_NULL, ref)
         code == 0 || throw(AHMCError(code, unsafe_string(ccall((:ahmc_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL))))
-        z = new{T}(ref[], D, N)
+        z = new{T}(ref[], D, N, false)
         finalizer(z -> ccall((:ahmc_destroy, LIB), Cint, (Ptr{Cvoid},), z.ctx), z)
         return z
     end
@@ -82,6 +86,10 @@ set_target!(z::MI355XChains, ::Funnel) =
     check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), z.ctx, TARGET_FUNNEL, C_NULL, 0))
 set_target!(z::MI355XChains, ::HierGaussian) =
     check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), z.ctx, TARGET_HIER_GAUSS, C_NULL, 0))
+function set_target!(z::MI355XChains, ::UserDensity)
+    check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), z.ctx, TARGET_EXTERNAL, C_NULL, 0))
+    z.user_density = true
+end
 function set_target!(z::MI355XChains{T}, t::DiagGaussian) where {T}
     p = T[t.m; t.s]
     check(z.ctx, ccall((:ahmc_set_target, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{T}, Int64), z.ctx, TARGET_DIAG_GAUSS, p, length(p)))
@@ -141,15 +149,80 @@ criterion_code(::ClassicNoUTurn) = TC_CLASSIC
 criterion_code(::GeneralisedNoUTurn) = TC_GENERALISED
 criterion_code(::StrictGeneralisedNoUTurn) = TC_STRICT
 
+# --- user log-densities: ask / tell (include/ahmc_hip.h, ahmc_ext_*) ------------------------------------
+# PhasePoint(θ, r, ℓπ, ℓκ) with the caches computed by the Hamiltonian's own closure (src/hamiltonian.jl:115-119)
+function set_position!(z::MI355XChains{T}, h::Hamiltonian, θ::AbstractMatrix{T}) where {T}
+    size(θ) == (z.D, z.N) || throw(ArgumentError("θ has size $(size(θ)), expected $((z.D, z.N))"))
+    ℓπ, ∇ℓπ = h.∂ℓπ∂θ(θ)                                  # ((N,), (D,N)) — test/common.jl:64-74
+    r = zeros(T, z.D, z.N)
+    check(z.ctx, ccall((:ahmc_set_phasepoint, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
+                       z.ctx, Matrix{T}(θ), r, Vector{T}(ℓπ), Matrix{T}(-∇ℓπ)))
+end
+
+# Serve the engine's evaluation requests with h.∂ℓπ∂θ until the run started by ahmc_ext_begin /
+# ahmc_ext_find_good_stepsize_begin is complete.  Only the pending columns are read by the engine, so a closure
+# that evaluates all N columns (the sampler-vec convention) is served as is.
+function ext_drive!(z::MI355XChains{T}, h::Hamiltonian) where {T}
+    n = Ref{Int64}(0)
+    θ = Matrix{T}(undef, z.D, z.N)
+    try
+        while true
+            check(z.ctx, ccall((:ahmc_ext_pending, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{T}), z.ctx, n, C_NULL, θ))
+            n[] == 0 && return nothing
+            ℓπ, ∇ℓπ = h.∂ℓπ∂θ(θ)                          # ∂H∂θ(h, θ) — src/hamiltonian.jl:45-48
+            check(z.ctx, ccall((:ahmc_ext_advance, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), z.ctx, Vector{T}(ℓπ), Matrix{T}(-∇ℓπ)))
+        end
+    catch
+        ccall((:ahmc_ext_cancel, LIB), Cint, (Ptr{Cvoid},), z.ctx)
+        rethrow()
+    end
+end
+
+kernel_cfg(κ::HMCKernel) = begin
+    tc = κ.τ.termination_criterion
+    nuts = tc isa AdvancedHMC.DynamicTerminationCriterion
+    λ = tc isa FixedIntegrationTime ? Float64(tc.λ) : 0.0
+    # struct ahmc_kernel_cfg { int32 nuts, sampler, criterion, max_depth; double delta_max; int64 L; double lambda, refresh_alpha; }
+    (Cint(nuts), sampler_code(typeof(κ.τ).parameters[1]), nuts ? criterion_code(tc) : Cint(0),
+     Cint(nuts ? tc.max_depth : 0), nuts ? Float64(tc.Δ_max) : 0.0, Int64(tc isa FixedNSteps ? tc.L : 0), λ,
+     κ.refreshment isa PartialMomentumRefreshment ? Float64(κ.refreshment.α) : 0.0)
+end
+
+"""
+    transition_user_density(h, κ, z)
+
+`transition(rng, h, κ, z)` (src/sampler.jl:48-58) for a context whose target is `UserDensity()`: momentum refresh,
+the whole static / NUTS trajectory, acceptance and statistics run in the engine, `h.∂ℓπ∂θ` runs here.
+"""
+function transition_user_density(h::Hamiltonian, κ::HMCKernel, z::MI355XChains{T}) where {T}
+    set_integrator!(z, κ.τ.integrator)
+    cfg = Ref(kernel_cfg(κ))
+    check(z.ctx, ccall((:ahmc_ext_begin, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), z.ctx, cfg, 1))
+    ext_drive!(z, h)
+end
+
+"find_good_stepsize(rng, h, θ) per chain (src/trajectory.jl:768-837) with the Hamiltonian's own closure"
+function find_good_stepsize_user_density(h::Hamiltonian, z::MI355XChains{T}; initial_step_size=0.1, max_n_iters::Int=100) where {T}
+    check(z.ctx, ccall((:ahmc_ext_find_good_stepsize_begin, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cint), z.ctx, Float64(initial_step_size), max_n_iters))
+    ext_drive!(z, h)
+    ϵ = Vector{T}(undef, z.N)
+    check(z.ctx, ccall((:ahmc_get_stepsize, LIB), Cint, (Ptr{Cvoid}, Ptr{T}), z.ctx, ϵ))
+    return ϵ
+end
+
 # --- the hook: transition(rng, h, κ::HMCKernel, z) (src/sampler.jl:48-58) ----------------------------
 # static HMC
 function AdvancedHMC.transition(
     ::Union{AbstractRNG,AbstractVector{<:AbstractRNG}}, h::Hamiltonian,
     κ::HMCKernel{<:FullMomentumRefreshment,<:Trajectory{TS,I,<:FixedNSteps}}, z::MI355XChains{T},
 ) where {TS,I,T}
-    set_integrator!(z, κ.τ.integrator)
-    check(z.ctx, ccall((:ahmc_hmc_transition, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cint),
-                       z.ctx, κ.τ.termination_criterion.L, 0.0, sampler_code(TS)))
+    if z.user_density
+        transition_user_density(h, κ, z)
+    else
+        set_integrator!(z, κ.τ.integrator)
+        check(z.ctx, ccall((:ahmc_hmc_transition, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cint),
+                           z.ctx, κ.τ.termination_criterion.L, 0.0, sampler_code(TS)))
+    end
     tstat = (
         n_steps=κ.τ.termination_criterion.L,
         is_accept=getstat(z, 1, Int32) .!= 0,
@@ -170,9 +243,13 @@ function AdvancedHMC.transition(
     κ::HMCKernel{<:FullMomentumRefreshment,<:Trajectory{TS,I,TC}}, z::MI355XChains{T},
 ) where {TS,I,TC<:AdvancedHMC.DynamicTerminationCriterion,T}
     tc = κ.τ.termination_criterion
-    set_integrator!(z, κ.τ.integrator)
-    check(z.ctx, ccall((:ahmc_nuts_transition, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint),
-                       z.ctx, tc.max_depth, Float64(tc.Δ_max), criterion_code(tc), sampler_code(TS)))
+    if z.user_density
+        transition_user_density(h, κ, z)
+    else
+        set_integrator!(z, κ.τ.integrator)
+        check(z.ctx, ccall((:ahmc_nuts_transition, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint),
+                           z.ctx, tc.max_depth, Float64(tc.Δ_max), criterion_code(tc), sampler_code(TS)))
+    end
     tstat = (
         n_steps=getstat(z, 0, Int32),
         is_accept=trues(z.N),
@@ -226,12 +303,7 @@ function sample_device(seed::Integer, h::Hamiltonian, κ::HMCKernel, θ::Matrix{
     z = MI355XChains{T}(D, N)
     set_target!(z, target); set_metric!(z, h.metric); set_integrator!(z, κ.τ.integrator)
     seed!(z, seed); set_position!(z, θ); adaptor_init!(z, adaptor, δ)
-    tc = κ.τ.termination_criterion
-    nuts = tc isa AdvancedHMC.DynamicTerminationCriterion
-    # struct ahmc_kernel_cfg { int32 nuts, sampler, criterion, max_depth; double delta_max; int64 L; double lambda, refresh_alpha; }
-    cfg = Ref((Cint(nuts), sampler_code(typeof(κ.τ).parameters[1]), nuts ? criterion_code(tc) : Cint(0),
-               Cint(nuts ? tc.max_depth : 0), nuts ? Float64(tc.Δ_max) : 0.0, Int64(nuts ? 0 : tc.L), 0.0,
-               κ.refreshment isa PartialMomentumRefreshment ? Float64(κ.refreshment.α) : 0.0))
+    cfg = Ref(kernel_cfg(κ))
     n_keep = n_samples - (drop_warmup ? n_adapts : 0)
     out = Array{T}(undef, D, N, n_keep)
     check(z.ctx, ccall((:ahmc_sample, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{T}),

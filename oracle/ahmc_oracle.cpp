@@ -15,8 +15,9 @@
 // combine (:143-177), energy identities (test/hamiltonian.jl:54-79), U-turn equivalences
 // (test/trajectory.jl:249-325), step-loop ≡ step(n) (test/integrator.jl:17-32), the harmonic
 // oscillator bound (:108-153), seed self-consistency (test/sampler-vec.jl:69-80) and the
-// statistical checks (test/sampler-vec.jl:43,66).  A second, independent literal restatement in
-// Python (oracle/ahmc_ref.py) must agree with this file to 1e-12 (tests/test_oracle_cross.py).
+// statistical checks (test/sampler-vec.jl:43,66).  An independent numpy restatement of the RNG-free
+// formulas (tests/golden/make_independent_golden.py -> independent_golden.json) is replayed against
+// this file by the same test module.
 //
 // Each function cites the reference lines it follows (paths relative to the AdvancedHMC.jl
 // checkout).  Batch semantics: every chain is run through the reference's *scalar* (vector θ)
@@ -34,6 +35,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+
+#include <ucontext.h>  // coroutines of the external-target ask / tell protocol (ahmc_ext_*)
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -188,6 +191,9 @@ template <class T>
 struct Target {
   int kind = AHMC_TARGET_ISO_GAUSS;
   std::vector<T> params;
+  // AHMC_TARGET_EXTERNAL: while an ahmc_ext_* run is in progress, the evaluation is a hand-over to the caller
+  T (*ext_eval)(void* self, int64_t D, const T* th, T* g) = nullptr;
+  void* ext_self = nullptr;
 };
 
 // (ℓπ(θ), ∇ℓπ(θ)) — the user callback `h.∂ℓπ∂θ(θ)` of src/hamiltonian.jl:46.  `g` receives +∇ℓπ.
@@ -261,6 +267,9 @@ T logdensity_and_gradient(const Target<T>& tg, int64_t D, const T* th, T* g) {
       for (int64_t i = 0; i < D; ++i) v += th[i] * g[i];
       return v / 2;
     }
+    case AHMC_TARGET_EXTERNAL:
+      if (tg.ext_eval) return tg.ext_eval(tg.ext_self, D, th, g);  // the caller's h.∂ℓπ∂θ(θ) (ask / tell)
+      [[fallthrough]];  // outside an ahmc_ext_* run there is nobody to ask
     default:
       for (int64_t d = 0; d < D; ++d) g[d] = std::numeric_limits<T>::quiet_NaN();
       return std::numeric_limits<T>::quiet_NaN();
@@ -793,6 +802,30 @@ struct Ctx : CtxBase {
   int64_t acc_nsteps = 0, acc_ntrans = 0, acc_ndiv = 0;
   std::vector<T> acc_sum, acc_sumsq;
   bool ref_compat = false;
+  // External target, ask / tell (ahmc_ext_*): every chain runs the ordinary scalar code of this file inside its own
+  // coroutine; the target evaluation of an AHMC_TARGET_EXTERNAL context parks the coroutine until the caller has
+  // supplied (ℓπ, -∇ℓπ) for the position it published.  One chain runs at a time (no OpenMP in this mode).
+  struct ExtCo {
+    ucontext_t uc;
+    std::vector<char> stack;
+    int state = 0;  // 0 runnable, 1 waiting for the caller's evaluation, 2 finished
+    int k = 0;      // transition of the batch this chain is in
+  };
+  struct Ext {
+    int mode = 0;  // 0 idle, 1 NUTS, 2 static HMC, 3 find_good_stepsize
+    ahmc_kernel_cfg cfg{};
+    int n_trans = 0;
+    uint64_t iter0 = 0;
+    double fe_init = 0;
+    int fe_iters = 0;
+    ucontext_t main_uc;
+    std::vector<ExtCo> co;
+    int64_t cur = -1;
+    std::vector<T> theta;  // (D,N): the positions the waiting chains want evaluated
+    const T* in_lp = nullptr;
+    const T* in_g = nullptr;
+    std::vector<T> fe_out;
+  } ext;
 
   MetricView<T> metric_view(int64_t c) const {
     MetricView<T> m;
@@ -1141,6 +1174,144 @@ std::vector<T> find_good_stepsize_all(Ctx<T>* c, T init, int max_n_iters) {
   return out;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// External target: ask / tell (include/ahmc_hip.h, ahmc_ext_*).  The transition code above is used
+// unchanged; only the target evaluation differs (Target::ext_eval).
+// ---------------------------------------------------------------------------------------------
+thread_local void* g_ext_entry_arg = nullptr;
+
+template <class T>
+T ext_eval_thunk(void* self, int64_t D, const T* th, T* g) {
+  auto* c = static_cast<Ctx<T>*>(self);
+  auto& x = c->ext;
+  const int64_t i = x.cur;
+  std::copy(th, th + D, x.theta.begin() + i * D);
+  x.co[i].state = 1;
+  swapcontext(&x.co[i].uc, &x.main_uc);  // back to ahmc_ext_begin / ahmc_ext_advance
+  // resumed by ahmc_ext_advance: the caller's arrays hold this chain's evaluation
+  for (int64_t d = 0; d < D; ++d) g[d] = -x.in_g[i * D + d];  // in_g is -∇ℓπ; this function returns +∇ℓπ
+  return x.in_lp[i];
+}
+
+template <class T>
+void jitter_chain(Ctx<T>* c, int64_t i) {  // apply_jitter for one chain
+  if (c->integ_kind == AHMC_INTEGRATOR_JITTERED) {
+    T u = (T)c->rng(i, c->iteration).uniform(RNG_JITTER, 0);
+    c->eps_cur[i] = c->eps_nom[i] * (1 + c->integ_param * (2 * u - 1));
+  } else {
+    c->eps_cur[i] = c->eps_nom[i];
+  }
+}
+
+// everything chain i does in an ext run (c->iteration is set to the chain's own transition before every resume)
+template <class T>
+void ext_chain_body(Ctx<T>* c, int64_t i) {
+  auto& x = c->ext;
+  if (x.mode == 3) {
+    x.fe_out[i] = find_good_stepsize_chain(c, i, (T)x.fe_init, x.fe_iters);
+    return;
+  }
+  for (int k = 0; k < x.n_trans; ++k) {
+    x.co[i].k = k;
+    c->iteration = x.iter0 + (uint64_t)k;
+    jitter_chain(c, i);
+    if (x.mode == 1) {
+      NutsCfg<T> cfg;
+      cfg.sampler = x.cfg.sampler;
+      cfg.criterion = x.cfg.criterion;
+      cfg.max_depth = x.cfg.max_depth;
+      cfg.delta_max = (T)x.cfg.delta_max;
+      MetricView<T> m = c->metric_view(i);
+      LeapfrogCfg<T> lf = c->lfcfg(i);
+      Rng rng = c->rng(i, c->iteration);
+      PhasePoint<T> z = refresh(c, i, c->load(i), (T)x.cfg.refresh_alpha);
+      NutsEnv<T> e{&lf, &c->target, &m, &cfg, &rng, 0};
+      PhasePoint<T> zc = nuts_transition(e, z, c->stat[i]);
+      c->store(i, zc);
+    } else {
+      int64_t L = resolve_L(c, x.cfg.L, x.cfg.lambda);
+      if (L < 0) L = -L;
+      int64_t n_fwd = 0;
+      if (x.cfg.sampler == AHMC_TS_MULTINOMIAL) {  // rand_coupled: the same draw for every chain (hmc_transition)
+        Rng shared = c->rng(0, c->iteration);
+        shared.chain = COUPLED_CHAIN;
+        double u = shared.uniform(RNG_TRANSITION, 0);
+        n_fwd = (int64_t)std::floor(u * (double)(L + 1));
+        if (n_fwd > L) n_fwd = L;
+      }
+      hmc_transition_chain(c, i, L, x.cfg.sampler, n_fwd, (T)x.cfg.refresh_alpha, -1);
+    }
+  }
+}
+
+template <class T>
+void ext_co_entry() {
+  auto* c = static_cast<Ctx<T>*>(g_ext_entry_arg);
+  const int64_t i = c->ext.cur;
+  ext_chain_body(c, i);
+  c->ext.co[i].state = 2;
+  // returning resumes uc_link = main_uc
+}
+
+template <class T>
+void ext_resume(Ctx<T>* c, int64_t i) {
+  auto& x = c->ext;
+  x.cur = i;
+  c->iteration = x.iter0 + (uint64_t)x.co[i].k;
+  g_ext_entry_arg = c;
+  x.co[i].state = 0;
+  swapcontext(&x.main_uc, &x.co[i].uc);
+  x.cur = -1;
+}
+
+template <class T>
+void ext_finish_if_done(Ctx<T>* c) {
+  auto& x = c->ext;
+  for (auto& co : x.co)
+    if (co.state != 2) return;
+  if (x.mode == 3) {
+    c->iteration = x.iter0;
+    c->eps_nom = x.fe_out;
+    c->eps_cur = x.fe_out;
+    c->eps_scalar = false;
+  } else {
+    c->iteration = x.iter0 + (uint64_t)x.n_trans;
+  }
+  x.mode = 0;
+  x.co.clear();
+  c->target.ext_eval = nullptr;
+  c->target.ext_self = nullptr;
+}
+
+template <class T>
+int ext_start(Ctx<T>* c, int mode) {
+  auto& x = c->ext;
+  x.mode = mode;
+  x.iter0 = c->iteration;
+  x.theta.assign(c->D * c->N, T(0));
+  x.fe_out.assign(c->N, T(0));
+  x.in_lp = nullptr;
+  x.in_g = nullptr;
+  c->target.ext_eval = &ext_eval_thunk<T>;
+  c->target.ext_self = c;
+  x.co.clear();
+  x.co.resize((size_t)c->N);
+  const size_t stack_bytes = (size_t)1 << 19;  // build_tree recurses max_depth deep; its vectors live on the heap
+  for (int64_t i = 0; i < c->N; ++i) {
+    auto& co = x.co[(size_t)i];
+    co.stack.resize(stack_bytes);
+    getcontext(&co.uc);
+    co.uc.uc_stack.ss_sp = co.stack.data();
+    co.uc.uc_stack.ss_size = co.stack.size();
+    co.uc.uc_link = &x.main_uc;
+    makecontext(&co.uc, (void (*)())&ext_co_entry<T>, 0);
+  }
+  for (int64_t i = 0; i < c->N; ++i) ext_resume(c, i);  // every chain runs to its first evaluation request
+  ext_finish_if_done(c);
+  return AHMC_OK;
+}
+
 // --- adaptation ------------------------------------------------------------------------------
 template <class T>
 void da_reset(Ctx<T>* c) {  // reset!(das) (src/adaptation/stepsize.jl:40-53)
@@ -1343,6 +1514,15 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
     else { using T = double; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ }                 \
   } while (0)
 
+// entry points that change the context: refused while an ahmc_ext_* run is in progress (the parked coroutines hold
+// references into it)
+#define FOR_CTX_MUT(ctx, ...)                                                                                        \
+  FOR_CTX(ctx, {                                                                                                     \
+    if (c->ext.mode != 0)                                                                                            \
+      return fail(c, AHMC_ERR_STATE, std::string(__func__) + ": an ahmc_ext_* run is in progress (finish it or call ahmc_ext_cancel)"); \
+    __VA_ARGS__                                                                                                      \
+  })
+
 extern "C" {
 
 int32_t ahmc_abi_version(void) { return AHMC_ABI_VERSION; }
@@ -1395,7 +1575,7 @@ int32_t ahmco_set_ref_compat(ahmc_ctx* ctx, int32_t on) {
 }
 
 int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     int64_t need = 0;
     switch (kind) {
       case AHMC_TARGET_ISO_GAUSS: case AHMC_TARGET_FUNNEL: case AHMC_TARGET_HIER_GAUSS: need = 0; break;
@@ -1416,7 +1596,7 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
 }
 
 int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n) {
-  FOR_CTX(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
+  FOR_CTX_MUT(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
 }
 
 int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
@@ -1429,7 +1609,7 @@ int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
 }
 
 int32_t ahmc_set_stepsize(ahmc_ctx* ctx, const void* eps, int64_t n) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!eps || (n != 1 && n != c->N)) return fail(c, AHMC_ERR_ARGUMENT, "set_stepsize: need 1 or N step sizes");
     const T* e = static_cast<const T*>(eps);
     for (int64_t i = 0; i < c->N; ++i) c->eps_nom[i] = e[n == 1 ? 0 : i];
@@ -1444,7 +1624,7 @@ int32_t ahmc_get_stepsize(ahmc_ctx* ctx, void* out) {
 }
 
 int32_t ahmc_set_integrator(ahmc_ctx* ctx, int32_t kind, double param) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (kind < AHMC_INTEGRATOR_LEAPFROG || kind > AHMC_INTEGRATOR_TEMPERED) return fail(c, AHMC_ERR_ARGUMENT, "set_integrator: unknown kind");
     c->integ_kind = kind;
     c->integ_param = (T)param;
@@ -1453,11 +1633,11 @@ int32_t ahmc_set_integrator(ahmc_ctx* ctx, int32_t kind, double param) {
 }
 
 int32_t ahmc_seed(ahmc_ctx* ctx, uint64_t seed, uint64_t chain_offset, uint64_t chain_stride, uint64_t iteration) {
-  FOR_CTX(ctx, { c->seed = seed; c->chain_offset = chain_offset; c->chain_stride = chain_stride; c->iteration = iteration; return AHMC_OK; });
+  FOR_CTX_MUT(ctx, { c->seed = seed; c->chain_offset = chain_offset; c->chain_stride = chain_stride; c->iteration = iteration; return AHMC_OK; });
 }
 
 int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!theta) return fail(c, AHMC_ERR_ARGUMENT, "set_position: theta is NULL");
     if (c->target.kind == AHMC_TARGET_EXTERNAL) return fail(c, AHMC_ERR_STATE, "set_position needs a built-in target; use set_phasepoint");
     const T* th = static_cast<const T*>(theta);
@@ -1473,7 +1653,7 @@ int32_t ahmc_set_position(ahmc_ctx* ctx, const void* theta, const void* r) {
 }
 
 int32_t ahmc_set_phasepoint(ahmc_ctx* ctx, const void* theta, const void* r, const void* lp, const void* grad) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!theta || !r || !lp || !grad) return fail(c, AHMC_ERR_ARGUMENT, "set_phasepoint: NULL argument");
     std::memcpy(c->th.data(), theta, sizeof(T) * c->D * c->N);
     std::memcpy(c->r.data(), r, sizeof(T) * c->D * c->N);
@@ -1501,7 +1681,7 @@ int32_t ahmc_get_phasepoint(ahmc_ctx* ctx, void* theta, void* r, void* lp, void*
 }
 
 int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "refresh before set_position");
     for (int64_t i = 0; i < c->N; ++i) c->store(i, refresh(c, i, c->load(i), (T)alpha));
     return AHMC_OK;
@@ -1509,7 +1689,7 @@ int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
 }
 
 int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "leapfrog before set_position");
     c->eps_cur = c->eps_nom;
     bool fwd = n_steps > 0;
@@ -1536,7 +1716,7 @@ int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
 }
 
 int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "lf_pre before set_phasepoint");
     for (int64_t k = 0; k < c->N; ++k) {
       LeapfrogCfg<T> lf = c->lfcfg(k);
@@ -1556,7 +1736,7 @@ int32_t ahmc_lf_pre(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps) {
 }
 
 int32_t ahmc_lf_post(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps, const void* lp, const void* grad_neg) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!lp || !grad_neg) return fail(c, AHMC_ERR_ARGUMENT, "lf_post: NULL argument");
     const T* l = static_cast<const T*>(lp);
     const T* gn = static_cast<const T*>(grad_neg);
@@ -1585,12 +1765,96 @@ void* ahmc_theta_ptr(ahmc_ctx* ctx) {
   return static_cast<Ctx<double>*>(b)->th.data();
 }
 
+// ---- external target: ask / tell ----
+int32_t ahmc_ext_begin(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int32_t n_trans) {
+  FOR_CTX(ctx, {
+    if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: cfg is NULL");
+    if (n_trans < 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: n_trans must be >= 1");
+    if (c->target.kind != AHMC_TARGET_EXTERNAL) return fail(c, AHMC_ERR_STATE, "ext_begin: the target is not AHMC_TARGET_EXTERNAL");
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "ext_begin before set_phasepoint");
+    if (c->ext.mode != 0) return fail(c, AHMC_ERR_STATE, "ext_begin: a run is already in progress");
+    if (cfg->nuts) {
+      if (cfg->sampler != AHMC_TS_MULTINOMIAL && cfg->sampler != AHMC_TS_SLICE) return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
+      if (cfg->criterion < AHMC_TC_CLASSIC || cfg->criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
+    } else {
+      if (cfg->sampler != AHMC_TS_ENDPOINT && cfg->sampler != AHMC_TS_MULTINOMIAL)
+        return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
+      if (cfg->lambda > 0 && !c->eps_scalar)
+        return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
+    }
+    c->ext.cfg = *cfg;
+    c->ext.n_trans = n_trans;
+    return ext_start(c, cfg->nuts ? 1 : 2);
+  });
+}
+
+int32_t ahmc_ext_find_good_stepsize_begin(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
+  FOR_CTX(ctx, {
+    if (c->target.kind != AHMC_TARGET_EXTERNAL) return fail(c, AHMC_ERR_STATE, "ext_find_good_stepsize_begin: the target is not AHMC_TARGET_EXTERNAL");
+    if (!c->have_point) return fail(c, AHMC_ERR_STATE, "ext_find_good_stepsize_begin before set_phasepoint");
+    if (c->ext.mode != 0) return fail(c, AHMC_ERR_STATE, "ext_find_good_stepsize_begin: a run is already in progress");
+    c->ext.fe_init = initial_step_size;
+    c->ext.fe_iters = max_n_iters;
+    c->ext.n_trans = 1;
+    return ext_start(c, 3);
+  });
+}
+
+int32_t ahmc_ext_pending(ahmc_ctx* ctx, int64_t* n_pending, int32_t* chains_out, void* theta_out) {
+  FOR_CTX(ctx, {
+    if (!n_pending) return fail(c, AHMC_ERR_ARGUMENT, "ext_pending: n_pending is NULL");
+    int64_t n = 0;
+    if (c->ext.mode != 0) {
+      for (int64_t i = 0; i < c->N; ++i)
+        if (c->ext.co[(size_t)i].state == 1) {
+          if (chains_out) chains_out[n] = (int32_t)i;
+          ++n;
+        }
+      if (theta_out && n > 0) std::memcpy(theta_out, c->ext.theta.data(), sizeof(T) * c->D * c->N);
+    }
+    *n_pending = n;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_ext_advance(ahmc_ctx* ctx, const void* lp, const void* grad_neg) {
+  FOR_CTX(ctx, {
+    if (c->ext.mode == 0) return fail(c, AHMC_ERR_STATE, "ext_advance: no run in progress");
+    if (!lp || !grad_neg) return fail(c, AHMC_ERR_ARGUMENT, "ext_advance: NULL argument");
+    c->ext.in_lp = static_cast<const T*>(lp);
+    c->ext.in_g = static_cast<const T*>(grad_neg);
+    std::vector<int64_t> waiting;
+    for (int64_t i = 0; i < c->N; ++i)
+      if (c->ext.co[(size_t)i].state == 1) waiting.push_back(i);
+    for (int64_t i : waiting) ext_resume(c, i);
+    c->ext.in_lp = nullptr;
+    c->ext.in_g = nullptr;
+    ext_finish_if_done(c);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_ext_cancel(ahmc_ctx* ctx) {
+  FOR_CTX(ctx, {
+    if (c->ext.mode != 0) {
+      // the parked coroutines are simply dropped: what lives on their stacks are PhasePoint / tree vectors whose heap
+      // blocks leak (bounded by the tree state of N chains); a test-infrastructure shortcut
+      c->iteration = c->ext.iter0;
+      c->ext.mode = 0;
+      c->ext.co.clear();
+      c->target.ext_eval = nullptr;
+      c->target.ext_self = nullptr;
+    }
+    return AHMC_OK;
+  });
+}
+
 int32_t ahmc_hmc_transition(ahmc_ctx* ctx, int64_t L, double lambda, int32_t sampler) {
-  FOR_CTX(ctx, { return hmc_transition(c, L, lambda, sampler, T(0)); });
+  FOR_CTX_MUT(ctx, { return hmc_transition(c, L, lambda, sampler, T(0)); });
 }
 
 int32_t ahmc_nuts_transition(ahmc_ctx* ctx, int32_t max_depth, double delta_max, int32_t criterion, int32_t sampler) {
-  FOR_CTX(ctx, { return nuts_transition_all(c, max_depth, delta_max, criterion, sampler, T(0)); });
+  FOR_CTX_MUT(ctx, { return nuts_transition_all(c, max_depth, delta_max, criterion, sampler, T(0)); });
 }
 
 int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
@@ -1620,7 +1884,7 @@ int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
 }
 
 int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "find_good_stepsize before set_position");
     std::vector<T> out = find_good_stepsize_all(c, (T)initial_step_size, max_n_iters);
     c->eps_nom = out;
@@ -1631,22 +1895,22 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
 }
 
 int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t init_buffer, int32_t term_buffer, int32_t window_size) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (kind < AHMC_ADAPT_NONE || kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: unknown adaptor kind");
     return adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
   });
 }
 
 int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* alpha) {
-  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha)); });
+  FOR_CTX_MUT(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha)); });
 }
 
 int32_t ahmc_adapt_point(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta, const void* grad, const void* alpha) {
-  FOR_CTX(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha), static_cast<const T*>(grad)); });
+  FOR_CTX_MUT(ctx, { return adapt(c, i, n_adapts, static_cast<const T*>(theta), static_cast<const T*>(alpha), static_cast<const T*>(grad)); });
 }
 
 int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t est) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (est != AHMC_VAR_WELFORD && est != AHMC_VAR_NUTPIE) return fail(c, AHMC_ERR_ARGUMENT, "set_var_estimator: unknown estimator");
     c->var_estimator = est;
     return AHMC_OK;
@@ -1665,7 +1929,7 @@ int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t wind
 }
 
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup, void* samples_out) {
-  FOR_CTX(ctx, {
+  FOR_CTX_MUT(ctx, {
     if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample: cfg is NULL");
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "sample before set_position");
     if (drop_warmup && c->adapt_kind == AHMC_ADAPT_NONE)
@@ -1702,7 +1966,7 @@ int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transit
 }
 
 int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
-  FOR_CTX(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); return AHMC_OK; });
+  FOR_CTX_MUT(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); return AHMC_OK; });
 }
 
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {

@@ -1,0 +1,152 @@
+"""GPU side of the ask / tell protocol (ahmc_ext_*): the HIP engine driven with a user log-density must
+reproduce the oracle running the same density built in (Float64: 1e-9 on energies / positions, discrete
+statistics identical on >= 99.9 % of chains — the bars of test_gpu_parity.py).
+
+This file sorts last on purpose and its tests are xfail(strict=False): the ahmc_ext_* host code was written
+after this round's GPU minutes were spent, so it has been exercised on the CPU oracle only
+(tests/test_external_target.py).  The device kernels it launches are the dense engine's, unchanged — verified by
+scripts/isa_digest.py against the build that passed the GPU suite.  A pass shows up as XPASS; the markers go
+once a GPU run has confirmed them.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ahmc_amd as A
+from test_external_target import TARGETS, iso_fn, make_metric
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="ahmc_ext_* host path not yet run on a GPU (round 1 GPU budget spent)")]
+
+RT = 1e-9
+
+
+def engines(hip, oracle, target, metric, N, lf, seed=7):
+    fn, builtin = TARGETS[target]
+    D = metric.D
+    e_ext = A.Engine(A.Hamiltonian(metric, A.ExternalTarget(D, lambda th: fn(np.asarray(th, dtype=np.float64)))), N, rng=seed, lib=hip)
+    e_ref = A.Engine(A.Hamiltonian(metric, builtin(D)), N, rng=seed, lib=oracle)
+    for e in (e_ext, e_ref):
+        e.set_integrator(lf)
+    return e_ext, e_ref
+
+
+def assert_close_state(e_ext, e_ref, min_match=0.999):
+    sa, sb = e_ext.stats(), e_ref.stats()
+    same = (sa["n_steps"] == sb["n_steps"]) & (sa["is_accept"] == sb["is_accept"]) & (sa["tree_depth"] == sb["tree_depth"])
+    assert same.mean() >= min_match, same.mean()
+    za, zb = e_ext.phasepoint(), e_ref.phasepoint()
+    np.testing.assert_allclose(za.theta[:, same], zb.theta[:, same], rtol=RT, atol=RT)
+    np.testing.assert_allclose(za.r[:, same], zb.r[:, same], rtol=RT, atol=RT)
+    np.testing.assert_allclose(za.lp.gradient[:, same], zb.lp.gradient[:, same], rtol=RT, atol=RT)
+    for k in ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error", "max_hamiltonian_energy_error", "step_size"):
+        np.testing.assert_allclose(sa[k][same], sb[k][same], rtol=1e-8, atol=1e-8, err_msg=k)
+    return same
+
+
+@pytest.mark.parametrize("target", ["iso", "funnel"])
+@pytest.mark.parametrize("metric", ["unit", "diag_chain", "diag_shared", "dense"])
+@pytest.mark.parametrize("TS", [A.MultinomialTS, A.SliceTS])
+def test_hip_nuts_with_user_density(hip, oracle, rng, target, metric, TS):
+    D, N = 10, 200
+    m = make_metric(metric, D, N, rng)
+    lf = A.Leapfrog(np.full(N, 0.25) * (0.5 + rng.random(N)))
+    e_ext, e_ref = engines(hip, oracle, target, m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.GeneralisedNoUTurn(max_depth=7)))
+    for _ in range(3):
+        e_ext.transition(kernel)
+        e_ref.transition(kernel)
+        same = assert_close_state(e_ext, e_ref, min_match=0.99)
+        if not same.all():  # a chain that took another decision carries on from another state: re-align it
+            e_ext.set_position(e_ref.phasepoint().theta)
+    assert e_ext.info("iteration") == e_ref.info("iteration") == 3
+    e_ext.close(); e_ref.close()
+
+
+@pytest.mark.parametrize("metric", ["unit", "diag_chain", "dense"])
+def test_hip_static_hmc_with_user_density(hip, oracle, rng, metric):
+    D, N = 12, 130
+    m = make_metric(metric, D, N, rng)
+    lf = A.JitteredLeapfrog(0.15, 0.3)
+    e_ext, e_ref = engines(hip, oracle, "funnel", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(9)))
+    for _ in range(3):
+        e_ext.transition(kernel)
+        e_ref.transition(kernel)
+        same = assert_close_state(e_ext, e_ref)
+        assert same.all()
+    e_ext.close(); e_ref.close()
+
+
+@pytest.mark.parametrize("metric", ["unit", "diag_chain", "dense"])
+def test_hip_find_good_stepsize_with_user_density(hip, oracle, rng, metric):
+    D, N = 16, 96
+    m = make_metric(metric, D, N, rng)
+    e_ext, e_ref = engines(hip, oracle, "iso", m, N, A.Leapfrog(0.1))
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    eps_a, eps_b = e_ext.find_good_stepsize(), e_ref.find_good_stepsize()
+    assert (eps_a == eps_b).mean() >= 0.99  # powers of two times bisection midpoints: equal unless a test sat on a tie
+    np.testing.assert_allclose(e_ext.phasepoint().theta, th0, rtol=0, atol=0)
+    assert e_ext.info("iteration") == 0
+    e_ext.close(); e_ref.close()
+
+
+def test_hip_batch_of_transitions_and_device_arrays(hip, oracle, rng):
+    """n_trans = 4 in one run; the evaluation is done with torch on the device, reading θ at ahmc_theta_ptr and
+    handing device pointers to ahmc_ext_advance (no host staging)"""
+    import torch
+
+    D, N = 8, 300
+    m = A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+    lf = A.Leapfrog(np.full(N, 0.3))
+    e_ext, e_ref = engines(hip, oracle, "iso", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=6)))
+    k = kernel.cfg()
+    e_ext._call("ahmc_ext_begin", C.byref(k), 4)
+    n = C.c_int64()
+    theta_dev = torch.empty((N, D), dtype=torch.float64, device="cuda")  # row c = chain c: the (D,N) column-major layout
+    trips = 0
+    while True:
+        e_ext._call("ahmc_ext_pending", C.byref(n), None, theta_dev.data_ptr())
+        if n.value == 0:
+            break
+        lp = (-(1.8378770664093454835606594728112 + theta_dev * theta_dev) / 2).sum(dim=1)
+        gneg = theta_dev.clone()  # -∇ℓπ = θ
+        torch.cuda.synchronize()
+        e_ext._call("ahmc_ext_advance", lp.data_ptr(), gneg.data_ptr())
+        trips += 1
+    for _ in range(4):
+        e_ref.transition(kernel)
+    assert e_ext.info("iteration") == 4 and trips > 4
+    assert_close_state(e_ext, e_ref, min_match=0.99)  # (torch's reduction order differs from the oracle's loop)
+    e_ext.close(); e_ref.close()
+
+
+def test_hip_unsupported_combinations_and_state_errors(hip, rng):
+    D, N = 4, 8
+    lf = A.Leapfrog(0.1)
+    e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.ExternalTarget(D, iso_fn)), N, lib=hip)
+    e.set_integrator(lf)
+    e.set_position(rng.normal(size=(D, N)))
+    for kernel in (A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.ClassicNoUTurn())),
+                   A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.FixedNSteps(4)))):
+        with pytest.raises(A.UnsupportedError):
+            e.transition(kernel)
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn())).cfg()
+    e._call("ahmc_ext_begin", C.byref(k), 1)
+    with pytest.raises(A.AHMCError, match="run is in progress"):
+        e.set_integrator(lf)
+    e._call("ahmc_ext_cancel")
+    e.set_integrator(lf)
+    e.close()
