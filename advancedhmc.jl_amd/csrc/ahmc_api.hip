@@ -5,6 +5,7 @@
 #include "ahmc_hip.h"
 #include "ahmc_inst.hpp"
 #include "ahmc_dense.hpp"
+#include "ahmc_dense_mn.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -59,6 +60,13 @@ StanWindows stan_windows(int64_t init_buffer, int64_t term_buffer, int64_t windo
   if (!w.splits.empty() && w.splits.back() == n_adapts) w.splits.pop_back();
   return w;
 }
+
+// static HMC with MultinomialTS on the step-synchronous engine: the transition in progress (ahmc_dense_mn_host.hpp)
+struct MnRun {
+  int phase = 0;  // MN_NONE / BWD / FWD / REINT / DONE
+  int64_t L = 0, n_bwd = 0, n_fwd = 0, i = 0, left = 0;
+  bool accum = false;
+};
 
 // an ahmc_ext_* run in progress (external target, ask / tell: ahmc_ext_host.hpp)
 enum { EXT_IDLE = 0, EXT_NUTS = 1, EXT_HMC = 2, EXT_FINDEPS = 3 };
@@ -164,6 +172,7 @@ struct Ctx : CtxBase {
   int64_t wc_n = 0;
   // external target, ask / tell (ahmc_ext_host.hpp): the run in progress; staging for a caller's host (ℓπ, -∇ℓπ)
   ExtRun ext;
+  MnRun mn;
   T *ext_gstage = nullptr, *ext_lpstage = nullptr;
 
   ~Ctx() override {
@@ -281,6 +290,7 @@ int launch_fill_caches_builtin(Ctx<T>* c) {
 }
 
 #include "ahmc_dense_host.hpp"
+#include "ahmc_dense_mn_host.hpp"
 #include "ahmc_ext_host.hpp"
 
 template <class T>

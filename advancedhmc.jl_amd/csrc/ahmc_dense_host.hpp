@@ -286,11 +286,12 @@ int dn_leapfrog(Ctx<T>* c, int64_t n_steps) {
 }
 
 template <class T>
+int dn_hmc_multinomial(Ctx<T>* c, int64_t L, bool accum);  // ahmc_dense_mn_host.hpp
+
+template <class T>
 int dn_hmc_transition(Ctx<T>* c, int64_t L, int sampler, double refresh_alpha, bool accum) {
   int rc = dn_check(c, "hmc_transition", refresh_alpha);
   if (rc) return rc;
-  if (sampler != AHMC_TS_ENDPOINT)
-    return fail(c, AHMC_ERR_UNSUPPORTED, "hmc_transition: the dense engine implements EndPointTS (static MultinomialTS is not implemented)");
   rc = dn_ensure(c, 2);
   if (rc) return rc;
   rc = dn_momenta(c, 1, c->r, (T*)nullptr);  // refresh (src/sampler.jl:54-57)
@@ -304,6 +305,13 @@ int dn_hmc_transition(Ctx<T>* c, int64_t L, int sampler, double refresh_alpha, b
   rc = dn_prepare_w(c);
   if (rc) return rc;
   hipLaunchKernelGGL((k_d_hmc_begin<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+  if (sampler == AHMC_TS_MULTINOMIAL) {  // energies-only passes + randcat + re-integration (ahmc_dense_mn.hpp)
+    HIPCHK(hipGetLastError());
+    rc = dn_hmc_multinomial(c, L, accum);
+    if (rc) return rc;
+    c->iteration += 1;
+    return AHMC_OK;
+  }
   for (int64_t i = 0; i < L; ++i) {
     rc = dn_step(c);
     if (rc) return rc;

@@ -10,7 +10,8 @@
 //               first half of the next leapfrog  →  compaction of the running chains
 // and the positions the next leapfrog needs are in c->th when it returns.  The kernels are those of the dense
 // engine, unchanged (dense_target = 0: ℓπ is taken from the context, where ingest put it); Unit / Diag / Dense
-// metric.  Static HMC (EndPointTS) and find_good_stepsize drive k_d_pre / k_d_post the same way.
+// metric.  Static HMC (EndPointTS; MultinomialTS through the state machine of ahmc_dense_mn_host.hpp) and
+// find_good_stepsize drive k_d_pre / k_d_post the same way.
 #pragma once
 
 // lp[c] ← sanitize(lp_in[c]) (PhasePoint: non-finite ℓπ → -Inf, src/hamiltonian.jl:95-104), g[:, c] ← g_in[:, c]
@@ -69,35 +70,6 @@ DP<T> ext_dp(Ctx<T>* c) {
   return q;
 }
 
-// first half of a leapfrog of every chain (k_d_pre): static HMC / find_good_stepsize
-template <class T>
-int ext_pre(Ctx<T>* c) {
-  const bool dm = c->metric_kind == AHMC_METRIC_DENSE;
-  T* V = c->dn_W + (size_t)DS_CUR_V * c->D * c->N;
-  T* W = dm ? c->dn_W + (size_t)DS_CUR_W * c->D * c->N : nullptr;
-  const T* minv = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
-  hipLaunchKernelGGL((k_d_pre<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->th, c->r, c->g, V, W, minv, c->minv_per_chain ? 1 : 0, c->dn_es,
-                     (int)c->D, c->N, (const int*)nullptr);
-  HIPCHK(hipGetLastError());
-  return AHMC_OK;
-}
-// second half (the caller's g′ and ℓπ are in place): w′ = M⁻¹g′ for the dense metric, then k_d_post
-template <class T>
-int ext_post(Ctx<T>* c) {
-  const bool dm = c->metric_kind == AHMC_METRIC_DENSE;
-  T* V = c->dn_W + (size_t)DS_CUR_V * c->D * c->N;
-  T* W = dm ? c->dn_W + (size_t)DS_CUR_W * c->D * c->N : nullptr;
-  const T* minv = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
-  if (dm) {
-    int rc = dn_gemm(c, c->dn_minv, c->g, W, c->N);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL((k_d_post<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, c->th, c->r, c->g, V, W, minv, c->minv_per_chain ? 1 : 0, c->dn_es,
-                     c->lp, c->lk, 0, (int)c->D, c->N, (const int*)nullptr);
-  HIPCHK(hipGetLastError());
-  return AHMC_OK;
-}
-
 // start of static-HMC transition c->iteration (dn_hmc_transition up to its first dn_step, with the target caches
 // taken as they are: the previous transition — or set_phasepoint — left ℓπ and -∇ℓπ of θ in place)
 template <class T>
@@ -113,7 +85,8 @@ int ext_hmc_start(Ctx<T>* c) {
   hipLaunchKernelGGL((k_d_hmc_begin<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
   HIPCHK(hipGetLastError());
   c->ext.l = 0;
-  return ext_pre(c);
+  if (c->ext.cfg.sampler == AHMC_TS_MULTINOMIAL) return mn_begin(c, c->ext.L, false);  // (does the first half-step itself)
+  return dn_pre_all(c);
 }
 
 template <class T>
@@ -167,8 +140,6 @@ int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
   // static HMC
   if (cfg->sampler != AHMC_TS_ENDPOINT && cfg->sampler != AHMC_TS_MULTINOMIAL)
     return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
-  if (cfg->sampler != AHMC_TS_ENDPOINT)
-    return fail(c, AHMC_ERR_UNSUPPORTED, "ext_begin: the step-synchronous engine implements EndPointTS (static MultinomialTS is not implemented)");
   int64_t L = cfg->L;
   if (cfg->lambda > 0) {  // nsteps(τ) for FixedIntegrationTime (src/trajectory.jl:241-243)
     if (!c->eps_scalar) return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
@@ -217,7 +188,7 @@ int ext_find_eps_begin(Ctx<T>* c, double init_eps, int max_iters) {
   if (rc) return bail(rc);
   hipLaunchKernelGGL((k_d_fe_begin<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q, c->dn_active);
   HIPCHK(hipGetLastError());
-  rc = ext_pre(c);
+  rc = dn_pre_all(c);
   return rc ? bail(rc) : AHMC_OK;
 }
 
@@ -310,19 +281,25 @@ int ext_advance(Ctx<T>* c, const void* lp_in, const void* g_in) {
     return AHMC_OK;
   }
   if (x.mode == EXT_HMC) {
-    rc = ext_post(c);
+    rc = dn_post_all(c, false);
     if (rc) { finish(); return rc; }
-    hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
-    x.l += 1;
-    if (x.l < x.L) {
-      rc = ext_pre(c);
-      if (rc) finish();
-      return rc;
+    if (x.cfg.sampler == AHMC_TS_MULTINOMIAL) {
+      rc = mn_after_step(c);  // records / counts the leapfrog and starts the next one, if any
+      if (rc) { finish(); return rc; }
+      if (c->mn.phase != MN_DONE) return AHMC_OK;
+    } else {
+      hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
+      x.l += 1;
+      if (x.l < x.L) {
+        rc = dn_pre_all(c);
+        if (rc) finish();
+        return rc;
+      }
+      KP<T> p = ext_kp(c);
+      DP<T> q = ext_dp(c);
+      hipLaunchKernelGGL((k_d_hmc_end<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
+      HIPCHK(hipGetLastError());
     }
-    KP<T> p = ext_kp(c);
-    DP<T> q = ext_dp(c);
-    hipLaunchKernelGGL((k_d_hmc_end<T>), dim3(dn_grid_chains(c)), dim3(256), 0, c->stream, p, q);
-    HIPCHK(hipGetLastError());
     c->iteration += 1;
     x.it += 1;
     if (x.it >= x.n_trans) {
@@ -334,7 +311,7 @@ int ext_advance(Ctx<T>* c, const void* lp_in, const void* g_in) {
     return rc;
   }
   // find_good_stepsize: the leapfrog at the step size under test is complete; decide, rewind, next evaluation
-  rc = ext_post(c);
+  rc = dn_post_all(c, false);
   if (rc) { finish(); return rc; }
   KP<T> p = ext_kp(c);
   DP<T> q = ext_dp(c);
@@ -353,7 +330,7 @@ int ext_advance(Ctx<T>* c, const void* lp_in, const void* g_in) {
     finish();
     return AHMC_OK;
   }
-  rc = ext_pre(c);
+  rc = dn_pre_all(c);
   if (rc) finish();
   return rc;
 }

@@ -265,7 +265,7 @@ def main():
                 "issue_bound": measured_issue(D, N),
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (the contract: rank 0 at N = 1 only)
             try:
                 cores = usable_cores()
                 # bounded sample sized to the host: 256 chains per usable core (capped at the GPU's own

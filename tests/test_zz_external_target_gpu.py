@@ -66,8 +66,9 @@ def test_hip_nuts_with_user_density(hip, oracle, rng, target, metric, TS):
     e_ext.close(); e_ref.close()
 
 
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
 @pytest.mark.parametrize("metric", ["unit", "diag_chain", "dense"])
-def test_hip_static_hmc_with_user_density(hip, oracle, rng, metric):
+def test_hip_static_hmc_with_user_density(hip, oracle, rng, metric, TS):
     D, N = 12, 130
     m = make_metric(metric, D, N, rng)
     lf = A.JitteredLeapfrog(0.15, 0.3)
@@ -75,13 +76,53 @@ def test_hip_static_hmc_with_user_density(hip, oracle, rng, metric):
     th0 = rng.normal(size=(D, N))
     e_ext.set_position(th0)
     e_ref.set_position(th0)
-    kernel = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(9)))
-    for _ in range(3):
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(9)))
+    for _ in range(4):  # (the coupled forward / backward split differs from transition to transition)
         e_ext.transition(kernel)
         e_ref.transition(kernel)
         same = assert_close_state(e_ext, e_ref)
         assert same.all()
     e_ext.close(); e_ref.close()
+
+
+@pytest.mark.parametrize("metric,target", [("dense", "dense"), ("dense", "funnel"), ("diag", "dense"), ("unit", "dense")])
+def test_dense_engine_static_multinomial(hip, oracle, rng, metric, target):
+    """static HMC with MultinomialTS (src/trajectory.jl:369-390) on the step-synchronous engine — energies-only
+    passes, randcat, re-integration (csrc/ahmc_dense_mn.hpp) — against the oracle's stored trajectories"""
+    D, N = 24, 150
+    B = rng.normal(size=(D, D))
+    P = B @ B.T / D + np.eye(D)
+    tgt = A.DenseGaussian(P) if target == "dense" else A.Funnel(D)
+    if metric == "dense":
+        C2 = rng.normal(size=(D, D))
+        m = A.DenseEuclideanMetric(C2 @ C2.T / D + np.eye(D))
+    elif metric == "diag":
+        m = A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+    else:
+        m = A.UnitEuclideanMetric(D)
+    lf = A.Leapfrog(np.full(N, 0.12) * (0.5 + rng.random(N)))
+    h = A.Hamiltonian(m, tgt)
+    e_g = A.Engine(h, N, rng=5, lib=hip)
+    e_o = A.Engine(h, N, rng=5, lib=oracle)
+    th0 = rng.normal(size=(D, N)) * 0.5
+    for e in (e_g, e_o):
+        e.set_integrator(lf)
+        e.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.FixedNSteps(8)))
+    for _ in range(4):
+        e_g.transition(kernel)
+        e_o.transition(kernel)
+        sa, sb = e_g.stats(), e_o.stats()
+        za, zb = e_g.phasepoint(), e_o.phasepoint()
+        close = np.all(np.isclose(za.theta, zb.theta, rtol=1e-8, atol=1e-8), axis=0)  # (a different categorical pick shows as a different point)
+        assert close.mean() >= 0.99, close.mean()
+        np.testing.assert_allclose(sa["acceptance_rate"], sb["acceptance_rate"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(sa["hamiltonian_energy"][close], sb["hamiltonian_energy"][close], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(za.r[:, close], zb.r[:, close], rtol=1e-8, atol=1e-8)
+        assert (sa["n_steps"] == 8).all() and sa["is_accept"].all()
+        if not close.all():
+            e_g.set_position(zb.theta)
+    e_g.close(); e_o.close()
 
 
 @pytest.mark.parametrize("metric", ["unit", "diag_chain", "dense"])
@@ -139,10 +180,8 @@ def test_hip_unsupported_combinations_and_state_errors(hip, rng):
     e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.ExternalTarget(D, iso_fn)), N, lib=hip)
     e.set_integrator(lf)
     e.set_position(rng.normal(size=(D, N)))
-    for kernel in (A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.ClassicNoUTurn())),
-                   A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.FixedNSteps(4)))):
-        with pytest.raises(A.UnsupportedError):
-            e.transition(kernel)
+    with pytest.raises(A.UnsupportedError):
+        e.transition(A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.ClassicNoUTurn())))
     k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn())).cfg()
     e._call("ahmc_ext_begin", C.byref(k), 1)
     with pytest.raises(A.AHMCError, match="run is in progress"):
