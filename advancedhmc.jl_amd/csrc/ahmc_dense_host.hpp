@@ -204,8 +204,42 @@ int dn_check(Ctx<T>* c, const char* what, double refresh_alpha) {
     return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": DenseEuclideanMetric with AHMC_TARGET_EXTERNAL is not implemented");
   if (c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
     return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the dense engine");
-  if (refresh_alpha != 0)
-    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": partial momentum refreshment is not implemented in the dense engine");
+  if (refresh_alpha < 0 || refresh_alpha >= 1)
+    return fail(c, AHMC_ERR_ARGUMENT, std::string(what) + ": PartialMomentumRefreshment needs 0 <= α < 1");
+  return AHMC_OK;
+}
+
+// buffers for the fresh momenta of n_trans transitions (and their velocities)
+template <class T>
+int dn_ensure_batch(Ctx<T>* c, int n_trans) {
+  const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
+  if (need > c->dn_batch_elems) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->dn_RB) { HIPCHK(hipFree(c->dn_RB)); HIPCHK(hipFree(c->dn_VB)); }
+    c->dn_RB = c->dn_VB = nullptr;
+    c->dn_batch_elems = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_RB), need * sizeof(T)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_VB), need * sizeof(T)));
+    c->dn_batch_elems = need;
+  }
+  return AHMC_OK;
+}
+
+// refresh(rng, ref, h, z) of ONE transition into `out` (c->r itself, or a batch slot): the fresh draw
+// rand_momentum (src/metric.jl:290-320), mixed with the current momentum for PartialMomentumRefreshment(α)
+// (src/hamiltonian.jl:243-254).  α = 0: out = ξ.
+template <class T>
+int dn_fresh_momentum(Ctx<T>* c, double alpha, T* out, uint32_t purpose = RNG_MOMENTUM) {
+  if (alpha == 0) return dn_momenta(c, 1, out, (T*)nullptr, purpose);
+  int rc = dn_ensure_batch(c, 1);
+  if (rc) return rc;
+  T* xi = out == c->dn_VB ? c->dn_RB : c->dn_VB;  // a batch buffer that is not the destination
+  rc = dn_momenta(c, 1, xi, (T*)nullptr, purpose);
+  if (rc) return rc;
+  const int64_t total = c->D * c->N;
+  const T a = (T)alpha, s = std::sqrt(1 - a * a);
+  hipLaunchKernelGGL((k_d_partial<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, out, c->r, xi, a, s, total);
+  HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
 
@@ -256,7 +290,7 @@ int dn_refresh(Ctx<T>* c, double alpha) {
   if (rc) return rc;
   rc = dn_ensure(c, 2);
   if (rc) return rc;
-  rc = dn_momenta(c, 1, c->r, (T*)nullptr);
+  rc = dn_fresh_momentum(c, alpha, c->r);
   if (rc) return rc;
   KP<T> p = make_kp(c);
   hipLaunchKernelGGL((k_d_jitter<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, p);
@@ -294,7 +328,7 @@ int dn_hmc_transition(Ctx<T>* c, int64_t L, int sampler, double refresh_alpha, b
   if (rc) return rc;
   rc = dn_ensure(c, 2);
   if (rc) return rc;
-  rc = dn_momenta(c, 1, c->r, (T*)nullptr);  // refresh (src/sampler.jl:54-57)
+  rc = dn_fresh_momentum(c, refresh_alpha, c->r);  // refresh (src/sampler.jl:54-57)
   if (rc) return rc;
   rc = dn_fill_caches(c);
   if (rc) return rc;
@@ -323,6 +357,22 @@ int dn_hmc_transition(Ctx<T>* c, int64_t L, int sampler, double refresh_alpha, b
   return AHMC_OK;
 }
 
+// RB / VB of a NUTS batch: the fresh momenta of its n_trans transitions and v = M⁻¹r of each (partial refreshment:
+// n_trans = 1, mixed with the chains' current momenta)
+template <class T>
+int dn_nuts_batch_momenta(Ctx<T>* c, int n_trans, double refresh_alpha) {
+  int rc = dn_ensure_batch(c, n_trans);
+  if (rc) return rc;
+  if (refresh_alpha == 0) return dn_momenta(c, n_trans, c->dn_RB, c->dn_VB);
+  rc = dn_fresh_momentum(c, refresh_alpha, c->dn_RB);
+  if (rc) return rc;
+  if (c->metric_kind == AHMC_METRIC_DENSE) return dn_gemm(c, c->dn_minv, c->dn_RB, c->dn_VB, c->N);
+  hipLaunchKernelGGL((k_d_vdiag<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->dn_RB, c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr,
+                     c->minv_per_chain ? 1 : 0, c->dn_VB, (int)c->D, c->N, (const int*)nullptr);
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
 // n_trans NUTS transitions of every chain (asynchronous chains, see ahmc_dense.hpp)
 template <class T>
 int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha, bool accum,
@@ -332,18 +382,18 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   if (criterion != AHMC_TC_GENERALISED)
     return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine implements GeneralisedNoUTurn only");
   if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");
+  if (refresh_alpha != 0 && n_trans > 1) {
+    // a partially refreshed momentum depends on the momentum the previous transition ended with, so the batch's
+    // momenta cannot be drawn up front: one transition per batch
+    for (int k = 0; k < n_trans; ++k) {
+      rc = dn_nuts_transition(c, max_depth, delta_max, criterion, sampler, refresh_alpha, accum, 1, samples_dev ? samples_dev + (size_t)k * c->D * c->N : nullptr);
+      if (rc) return rc;
+    }
+    return AHMC_OK;
+  }
   rc = dn_ensure(c, max_depth);
   if (rc) return rc;
-  const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
-  if (need > c->dn_batch_elems) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->dn_RB) { HIPCHK(hipFree(c->dn_RB)); HIPCHK(hipFree(c->dn_VB)); }
-    c->dn_RB = c->dn_VB = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_RB), need * sizeof(T)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_VB), need * sizeof(T)));
-    c->dn_batch_elems = need;
-  }
-  rc = dn_momenta(c, n_trans, c->dn_RB, c->dn_VB);
+  rc = dn_nuts_batch_momenta(c, n_trans, refresh_alpha);
   if (rc) return rc;
   KP<T> p = make_kp(c);
   p.max_depth = max_depth;

@@ -148,4 +148,12 @@ __global__ __launch_bounds__(256) void k_d_mn_end(KP<T> p, DP<T> q) {
   }
 }
 
+// PartialMomentumRefreshment(α) (src/hamiltonian.jl:243-254): out = α·r + sqrt(1 − α²)·ξ, ξ = the fresh momentum
+// draw (rand_momentum) — element-wise over `total` elements; out may alias r or ξ
+template <class T>
+__global__ __launch_bounds__(256) void k_d_partial(T* out, const T* r, const T* xi, T alpha, T s, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) out[idx] = alpha * r[idx] + s * xi[idx];
+}
+
 }  // namespace ahmc

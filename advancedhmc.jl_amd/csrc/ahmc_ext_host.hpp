@@ -74,7 +74,7 @@ DP<T> ext_dp(Ctx<T>* c) {
 // taken as they are: the previous transition — or set_phasepoint — left ℓπ and -∇ℓπ of θ in place)
 template <class T>
 int ext_hmc_start(Ctx<T>* c) {
-  int rc = dn_momenta(c, 1, c->r, (T*)nullptr);  // refresh (src/sampler.jl:54-57)
+  int rc = dn_fresh_momentum(c, c->ext.cfg.refresh_alpha, c->r);  // refresh (src/sampler.jl:54-57)
   if (rc) return rc;
   rc = dn_velocity(c);  // v = M⁻¹r, ℓκ
   if (rc) return rc;
@@ -95,8 +95,10 @@ int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
   if (n_trans < 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: n_trans must be >= 1");
   int rc = ext_common_checks(c, "ext_begin");
   if (rc) return rc;
-  if (cfg->refresh_alpha != 0)
-    return fail(c, AHMC_ERR_UNSUPPORTED, "ext_begin: partial momentum refreshment is not implemented in the step-synchronous engine");
+  if (cfg->refresh_alpha < 0 || cfg->refresh_alpha >= 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: PartialMomentumRefreshment needs 0 <= α < 1");
+  if (cfg->refresh_alpha != 0 && cfg->nuts && n_trans > 1)
+    return fail(c, AHMC_ERR_UNSUPPORTED, "ext_begin: with partial momentum refreshment a NUTS run is one transition (n_trans = 1): the next momentum "
+                                         "depends on the one this transition ends with");
   ExtRun& x = c->ext;
   if (cfg->nuts) {
     if (cfg->sampler != AHMC_TS_MULTINOMIAL && cfg->sampler != AHMC_TS_SLICE) return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
@@ -107,17 +109,7 @@ int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
     if (cfg->max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "ext_begin: the step-synchronous engine supports max_depth <= 17");
     rc = dn_ensure(c, cfg->max_depth);
     if (rc) return rc;
-    const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
-    if (need > c->dn_batch_elems) {
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (c->dn_RB) { HIPCHK(hipFree(c->dn_RB)); HIPCHK(hipFree(c->dn_VB)); }
-      c->dn_RB = c->dn_VB = nullptr;
-      c->dn_batch_elems = 0;
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_RB), need * sizeof(T)));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_VB), need * sizeof(T)));
-      c->dn_batch_elems = need;
-    }
-    rc = dn_momenta(c, n_trans, c->dn_RB, c->dn_VB);
+    rc = dn_nuts_batch_momenta(c, n_trans, cfg->refresh_alpha);
     if (rc) return rc;
     x.mode = EXT_NUTS;
     x.cfg = *cfg;

@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJ = os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "build")
+OBJ = os.environ.get("AHMC_OBJ_DIR") or os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "build")  # AHMC_OBJ_DIR: another build's objects
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 

@@ -285,3 +285,21 @@ def test_context_is_locked_during_a_run(oracle, rng):
     e._ext_drive()
     e.set_integrator(lf)
     e.close()
+
+
+def test_oracle_partial_refreshment_with_callback(oracle, rng):
+    """PartialMomentumRefreshment through the ask / tell run == through ahmc_sample with the density built in"""
+    D, N = 5, 12
+    m = make_metric("diag_chain", D, N, rng)
+    lf = A.Leapfrog(np.full(N, 0.3))
+    e_ext, e_ref, _ = pair(oracle, "iso", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    for kernel in (A.HMCKernel(A.PartialMomentumRefreshment(0.6), A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(5))),
+                   A.HMCKernel(A.PartialMomentumRefreshment(0.6), A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=5)))):
+        for _ in range(3):
+            e_ext.transition(kernel)
+            e_ref.run(kernel, 1)
+            assert_same_state(e_ext, e_ref)
+    e_ext.close(); e_ref.close()

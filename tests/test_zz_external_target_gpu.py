@@ -189,3 +189,59 @@ def test_hip_unsupported_combinations_and_state_errors(hip, rng):
     e._call("ahmc_ext_cancel")
     e.set_integrator(lf)
     e.close()
+
+
+@pytest.mark.parametrize("nuts", [False, True])
+@pytest.mark.parametrize("metric,target", [("dense", "dense"), ("diag", "dense"), ("dense", "funnel")])
+def test_dense_engine_partial_refreshment(hip, oracle, rng, metric, target, nuts):
+    """PartialMomentumRefreshment(α) (src/hamiltonian.jl:243-254) on the step-synchronous engine: refresh, then a
+    run of transitions through ahmc_sample (the momentum of each transition mixes in the one the previous ended with)"""
+    D, N = 20, 140
+    B = rng.normal(size=(D, D))
+    tgt = A.DenseGaussian(B @ B.T / D + np.eye(D)) if target == "dense" else A.Funnel(D)
+    if metric == "dense":
+        C2 = rng.normal(size=(D, D))
+        m = A.DenseEuclideanMetric(C2 @ C2.T / D + np.eye(D))
+    else:
+        m = A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+    lf = A.Leapfrog(np.full(N, 0.1) * (0.5 + rng.random(N)))
+    h = A.Hamiltonian(m, tgt)
+    e_g, e_o = A.Engine(h, N, rng=9, lib=hip), A.Engine(h, N, rng=9, lib=oracle)
+    th0, r0 = rng.normal(size=(D, N)) * 0.5, rng.normal(size=(D, N))
+    for e in (e_g, e_o):
+        e.set_integrator(lf)
+        e.set_position(th0, r0)
+        e.refresh(A.PartialMomentumRefreshment(0.4))
+    np.testing.assert_allclose(e_g.phasepoint().r, e_o.phasepoint().r, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(e_g.phasepoint().lk.value, e_o.phasepoint().lk.value, rtol=1e-9, atol=1e-9)
+    tc = A.GeneralisedNoUTurn(max_depth=6) if nuts else A.FixedNSteps(6)
+    kernel = A.HMCKernel(A.PartialMomentumRefreshment(0.4), A.Trajectory(A.MultinomialTS if nuts else A.EndPointTS, lf, tc))
+    for _ in range(3):
+        e_g.run(kernel, 1)
+        e_o.run(kernel, 1)
+        sa, sb = e_g.stats(), e_o.stats()
+        same = (sa["n_steps"] == sb["n_steps"]) & (sa["is_accept"] == sb["is_accept"])
+        assert same.mean() >= 0.99, same.mean()
+        za, zb = e_g.phasepoint(), e_o.phasepoint()
+        np.testing.assert_allclose(za.theta[:, same], zb.theta[:, same], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(za.r[:, same], zb.r[:, same], rtol=1e-8, atol=1e-8)
+        if not same.all():
+            e_g.set_position(zb.theta, zb.r)
+    e_g.close(); e_o.close()
+
+
+def test_hip_user_density_partial_refreshment(hip, oracle, rng):
+    D, N = 10, 100
+    m = make_metric("diag_chain", D, N, rng)
+    lf = A.Leapfrog(np.full(N, 0.2))
+    e_ext, e_ref = engines(hip, oracle, "iso", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    for kernel in (A.HMCKernel(A.PartialMomentumRefreshment(0.6), A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(5))),
+                   A.HMCKernel(A.PartialMomentumRefreshment(0.6), A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=5)))):
+        for _ in range(2):
+            e_ext.transition(kernel)
+            e_ref.run(kernel, 1)
+            assert_close_state(e_ext, e_ref, min_match=0.99)
+    e_ext.close(); e_ref.close()
