@@ -198,12 +198,25 @@ int dn_momenta(Ctx<T>* c, int n_trans, T* R, T* V, uint32_t purpose = RNG_MOMENT
   return AHMC_OK;
 }
 
+// TemperedLeapfrog on the step-synchronous engine: the two temper calls of a leapfrog (src/integrator.jl:231,241) as
+// element-wise launches around the step — for the chains moving forwards / backwards through n_pos / n_neg steps
 template <class T>
-int dn_check(Ctx<T>* c, const char* what, double refresh_alpha) {
+int dn_temper(Ctx<T>* c, int64_t i, bool second_half, int64_t n_pos, int64_t n_neg) {
+  if (c->integ_kind != AHMC_INTEGRATOR_TEMPERED) return AHMC_OK;
+  T* V = c->dn_W + (size_t)DS_CUR_V * c->D * c->N;
+  const T sa = (T)std::sqrt((T)c->integ_param);
+  hipLaunchKernelGGL((k_d_temper<T>), dim3(dn_grid_elems(c)), dim3(256), 0, c->stream, c->r, V, c->lk, c->dn_es, sa, i, second_half ? 1 : 0, n_pos, n_neg,
+                     (int)c->D, c->N);
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+template <class T>
+int dn_check(Ctx<T>* c, const char* what, double refresh_alpha, bool tree = false) {
   if (c->target_kind == AHMC_TARGET_EXTERNAL)
     return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": DenseEuclideanMetric with AHMC_TARGET_EXTERNAL is not implemented");
-  if (c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
-    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the dense engine");
+  if (tree && c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
+    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the step-synchronous tree kernel");
   if (refresh_alpha < 0 || refresh_alpha >= 1)
     return fail(c, AHMC_ERR_ARGUMENT, std::string(what) + ": PartialMomentumRefreshment needs 0 <= α < 1");
   return AHMC_OK;
@@ -311,7 +324,11 @@ int dn_leapfrog(Ctx<T>* c, int64_t n_steps) {
   hipLaunchKernelGGL((k_d_set<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_es, c->eps_nom, T(n_steps > 0 ? 1 : -1), c->N);
   hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
   for (int64_t i = 0; i < n; ++i) {
+    rc = dn_temper(c, i + 1, false, n, n);
+    if (rc) return rc;
     rc = dn_step(c);
+    if (rc) return rc;
+    rc = dn_temper(c, i + 1, true, n, n);
     if (rc) return rc;
     hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
   }
@@ -347,7 +364,11 @@ int dn_hmc_transition(Ctx<T>* c, int64_t L, int sampler, double refresh_alpha, b
     return AHMC_OK;
   }
   for (int64_t i = 0; i < L; ++i) {
+    rc = dn_temper(c, i + 1, false, L, L);
+    if (rc) return rc;
     rc = dn_step(c);
+    if (rc) return rc;
+    rc = dn_temper(c, i + 1, true, L, L);
     if (rc) return rc;
     hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
   }
@@ -377,7 +398,7 @@ int dn_nuts_batch_momenta(Ctx<T>* c, int n_trans, double refresh_alpha) {
 template <class T>
 int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha, bool accum,
                        int n_trans, T* samples_dev) {
-  int rc = dn_check(c, "nuts_transition", refresh_alpha);
+  int rc = dn_check(c, "nuts_transition", refresh_alpha, true);
   if (rc) return rc;
   if (criterion != AHMC_TC_GENERALISED)
     return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine implements GeneralisedNoUTurn only");

@@ -156,4 +156,26 @@ __global__ __launch_bounds__(256) void k_d_partial(T* out, const T* r, const T* 
   if (idx < total) out[idx] = alpha * r[idx] + s * xi[idx];
 }
 
+// temper(lf, r, (i, is_half), n_steps) (src/integrator.jl:198-209) for the chains that are moving: r ← r·√α while
+// 2(i−1)+1+[second half] <= n_steps, r ← r/√α afterwards; v = M⁻¹r scales with it, and after the second half so does
+// the kinetic energy the step has just stored (ℓκ ∝ r·v).  n_steps may differ with the direction (pass 2 of the
+// multinomial sampler re-integrates backward chains through n_bwd and forward chains through n_fwd steps).
+template <class T>
+__global__ __launch_bounds__(256) void k_d_temper(T* __restrict__ r, T* __restrict__ v, T* __restrict__ lk, const T* __restrict__ es, T sqrt_alpha,
+                                                  int64_t i, int second_half, int64_t n_pos, int64_t n_neg, int D, int64_t N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)D * N) return;
+  const int64_t c = idx / D;
+  const T e = es[c];
+  if (e == T(0)) return;
+  const int64_t i_temper = 2 * (i - 1) + 1 + (second_half ? 1 : 0);
+  const bool up = i_temper <= (e > T(0) ? n_pos : n_neg);
+  r[idx] = up ? r[idx] * sqrt_alpha : r[idx] / sqrt_alpha;
+  v[idx] = up ? v[idx] * sqrt_alpha : v[idx] / sqrt_alpha;
+  if (second_half && idx == c * D) {
+    const T f = up ? sqrt_alpha : T(1) / sqrt_alpha;
+    lk[c] = sanitize(lk[c] * f * f);
+  }
+}
+
 }  // namespace ahmc

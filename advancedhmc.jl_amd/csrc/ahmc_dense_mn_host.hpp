@@ -36,6 +36,23 @@ int dn_post_all(Ctx<T>* c, bool dense_target) {
 
 enum { MN_NONE = 0, MN_BWD = 1, MN_FWD = 2, MN_REINT = 3, MN_DONE = 4 };
 
+// TemperedLeapfrog: the temper call of the leapfrog the state machine is about to start (first half) or has just
+// finished (second half).  Pass 1 integrates all chains n_bwd steps backwards, then n_fwd forwards; pass 2 takes a
+// chain through the steps of its own direction again (step(lf, h, z, n; fwd), src/trajectory.jl:374-376).
+template <class T>
+int mn_temper(Ctx<T>* c, bool second_half) {
+  const MnRun& m = c->mn;
+  const int64_t i = second_half ? m.i : m.i + 1;  // m.i counts completed leapfrogs of the current pass
+  return dn_temper(c, i, second_half, m.n_fwd, m.n_bwd);
+}
+// first half-step of the next leapfrog of the current pass
+template <class T>
+int mn_pre(Ctx<T>* c) {
+  int rc = mn_temper(c, false);
+  if (rc) return rc;
+  return dn_pre_all(c);
+}
+
 template <class T>
 KP<T> mn_kp(Ctx<T>* c) {
   KP<T> p = make_kp(c);
@@ -84,7 +101,8 @@ int mn_select(Ctx<T>* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   m.phase = MN_REINT;
   m.left = left;
-  if (left > 0) return dn_pre_all(c);
+  m.i = 0;
+  if (left > 0) return mn_pre(c);
   return mn_end(c);
 }
 
@@ -118,11 +136,11 @@ int mn_begin(Ctx<T>* c, int64_t L, bool accum) {
     m.phase = MN_BWD;
     hipLaunchKernelGGL((k_d_set<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_es, c->eps_cur, T(-1), c->N);
     HIPCHK(hipGetLastError());
-    return dn_pre_all(c);
+    return mn_pre(c);
   }
   if (m.n_fwd > 0) {
     m.phase = MN_FWD;  // (es = +ϵ from k_d_hmc_begin)
-    return dn_pre_all(c);
+    return mn_pre(c);
   }
   return mn_select(c);
 }
@@ -137,23 +155,32 @@ int mn_after_step(Ctx<T>* c) {
   if (m.phase == MN_BWD || m.phase == MN_FWD) {
     const bool bwd = m.phase == MN_BWD;
     m.i += 1;
+    {
+      int rc = mn_temper(c, true);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL((k_d_mn_rec<T>), gridN, dim3(256), 0, c->stream, p, q, m.i, bwd ? -1 : 1, m.n_bwd);
     HIPCHK(hipGetLastError());
-    if (m.i < (bwd ? m.n_bwd : m.n_fwd)) return dn_pre_all(c);
+    if (m.i < (bwd ? m.n_bwd : m.n_fwd)) return mn_pre(c);
     if (bwd && m.n_fwd > 0) {
       int rc = mn_restore(c, T(1));
       if (rc) return rc;
       m.phase = MN_FWD;
       m.i = 0;
-      return dn_pre_all(c);
+      return mn_pre(c);
     }
     return mn_select(c);
   }
   if (m.phase == MN_REINT) {
+    m.i += 1;
+    {
+      int rc = mn_temper(c, true);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL((k_d_mn_count<T>), gridN, dim3(256), 0, c->stream, p, q);
     HIPCHK(hipGetLastError());
     m.left -= 1;
-    if (m.left > 0) return dn_pre_all(c);
+    if (m.left > 0) return mn_pre(c);
     return mn_end(c);
   }
   return fail(c, AHMC_ERR_STATE, "multinomial HMC: no leapfrog in flight");

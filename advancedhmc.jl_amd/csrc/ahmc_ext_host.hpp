@@ -29,13 +29,13 @@ __global__ __launch_bounds__(256) void k_x_ingest(const T* __restrict__ lp_in, c
 }
 
 template <class T>
-int ext_common_checks(Ctx<T>* c, const char* what) {
+int ext_common_checks(Ctx<T>* c, const char* what, bool tree = false) {
   if (c->target_kind != AHMC_TARGET_EXTERNAL)
     return fail(c, AHMC_ERR_STATE, std::string(what) + ": the target is not AHMC_TARGET_EXTERNAL (built-in targets run through ahmc_*_transition / ahmc_sample)");
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, std::string(what) + " before set_phasepoint");
   if (c->ext.mode != EXT_IDLE) return fail(c, AHMC_ERR_STATE, std::string(what) + ": a run is already in progress");
-  if (c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
-    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the step-synchronous engine");
+  if (tree && c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
+    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the step-synchronous tree kernel");
   return AHMC_OK;
 }
 
@@ -86,6 +86,8 @@ int ext_hmc_start(Ctx<T>* c) {
   HIPCHK(hipGetLastError());
   c->ext.l = 0;
   if (c->ext.cfg.sampler == AHMC_TS_MULTINOMIAL) return mn_begin(c, c->ext.L, false);  // (does the first half-step itself)
+  rc = dn_temper(c, 1, false, c->ext.L, c->ext.L);
+  if (rc) return rc;
   return dn_pre_all(c);
 }
 
@@ -93,7 +95,7 @@ template <class T>
 int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
   if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: cfg is NULL");
   if (n_trans < 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: n_trans must be >= 1");
-  int rc = ext_common_checks(c, "ext_begin");
+  int rc = ext_common_checks(c, "ext_begin", cfg->nuts != 0);
   if (rc) return rc;
   if (cfg->refresh_alpha < 0 || cfg->refresh_alpha >= 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: PartialMomentumRefreshment needs 0 <= α < 1");
   if (cfg->refresh_alpha != 0 && cfg->nuts && n_trans > 1)
@@ -280,10 +282,13 @@ int ext_advance(Ctx<T>* c, const void* lp_in, const void* g_in) {
       if (rc) { finish(); return rc; }
       if (c->mn.phase != MN_DONE) return AHMC_OK;
     } else {
-      hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
       x.l += 1;
+      rc = dn_temper(c, x.l, true, x.L, x.L);
+      if (rc) { finish(); return rc; }
+      hipLaunchKernelGGL((k_d_freeze<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->dn_es, c->N);
       if (x.l < x.L) {
-        rc = dn_pre_all(c);
+        rc = dn_temper(c, x.l + 1, false, x.L, x.L);
+        if (!rc) rc = dn_pre_all(c);
         if (rc) finish();
         return rc;
       }

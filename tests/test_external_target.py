@@ -303,3 +303,20 @@ def test_oracle_partial_refreshment_with_callback(oracle, rng):
             e_ref.run(kernel, 1)
             assert_same_state(e_ext, e_ref)
     e_ext.close(); e_ref.close()
+
+
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
+def test_oracle_tempered_static_hmc_with_callback(oracle, rng, TS):
+    D, N = 5, 12
+    m = make_metric("dense", D, N, rng)
+    lf = A.TemperedLeapfrog(np.full(N, 0.2), 1.05)
+    e_ext, e_ref, _ = pair(oracle, "funnel", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(6)))
+    for _ in range(3):
+        e_ext.transition(kernel)
+        e_ref.transition(kernel)
+        assert_same_state(e_ext, e_ref)
+    e_ext.close(); e_ref.close()

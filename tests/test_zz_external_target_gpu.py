@@ -245,3 +245,63 @@ def test_hip_user_density_partial_refreshment(hip, oracle, rng):
             e_ref.run(kernel, 1)
             assert_close_state(e_ext, e_ref, min_match=0.99)
     e_ext.close(); e_ref.close()
+
+
+@pytest.mark.parametrize("metric,target", [("dense", "dense"), ("diag", "dense"), ("dense", "funnel")])
+def test_dense_engine_tempered_leapfrog(hip, oracle, rng, metric, target):
+    """TemperedLeapfrog (src/integrator.jl:174-209) on the step-synchronous engine: step(lf, h, z, n) both ways,
+    static HMC with EndPointTS and MultinomialTS; NUTS stays unsupported there"""
+    D, N = 18, 120
+    B = rng.normal(size=(D, D))
+    tgt = A.DenseGaussian(B @ B.T / D + np.eye(D)) if target == "dense" else A.Funnel(D)
+    if metric == "dense":
+        C2 = rng.normal(size=(D, D))
+        m = A.DenseEuclideanMetric(C2 @ C2.T / D + np.eye(D))
+    else:
+        m = A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+    lf = A.TemperedLeapfrog(np.full(N, 0.08) * (0.5 + rng.random(N)), 1.05)
+    h = A.Hamiltonian(m, tgt)
+    e_g, e_o = A.Engine(h, N, rng=4, lib=hip), A.Engine(h, N, rng=4, lib=oracle)
+    th0, r0 = rng.normal(size=(D, N)) * 0.5, rng.normal(size=(D, N))
+    for e in (e_g, e_o):
+        e.set_integrator(lf)
+        e.set_position(th0, r0)
+    for n in (7, -4):
+        for e in (e_g, e_o):
+            e.step(n)
+        za, zb = e_g.phasepoint(), e_o.phasepoint()
+        np.testing.assert_allclose(za.theta, zb.theta, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(za.r, zb.r, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(za.lk.value, zb.lk.value, rtol=1e-9, atol=1e-8)
+    for TS in (A.EndPointTS, A.MultinomialTS):
+        kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(7)))
+        for _ in range(3):
+            e_g.transition(kernel)
+            e_o.transition(kernel)
+            sa, sb = e_g.stats(), e_o.stats()
+            za, zb = e_g.phasepoint(), e_o.phasepoint()
+            close = np.all(np.isclose(za.theta, zb.theta, rtol=1e-8, atol=1e-8), axis=0) & (sa["is_accept"] == sb["is_accept"])
+            assert close.mean() >= 0.99, close.mean()
+            np.testing.assert_allclose(sa["hamiltonian_energy"][close], sb["hamiltonian_energy"][close], rtol=1e-8, atol=1e-8)
+            if not close.all():
+                e_g.set_position(zb.theta, zb.r)
+    with pytest.raises(A.UnsupportedError):
+        e_g.transition(A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn())))
+    e_g.close(); e_o.close()
+
+
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
+def test_hip_user_density_tempered(hip, oracle, rng, TS):
+    D, N = 9, 80
+    m = make_metric("diag_chain", D, N, rng)
+    lf = A.TemperedLeapfrog(np.full(N, 0.15), 1.05)
+    e_ext, e_ref = engines(hip, oracle, "funnel", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(6)))
+    for _ in range(3):
+        e_ext.transition(kernel)
+        e_ref.transition(kernel)
+        assert_close_state(e_ext, e_ref, min_match=0.99)
+    e_ext.close(); e_ref.close()
