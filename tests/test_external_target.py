@@ -170,6 +170,26 @@ def test_batch_of_transitions_runs_chains_asynchronously(oracle, rng):
     e_ext.close(); e_ref.close()
 
 
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
+def test_batch_of_static_transitions(oracle, rng, TS):
+    D, N = 4, 10
+    m = make_metric("diag_shared", D, N, rng)
+    lf = A.Leapfrog(np.full(N, 0.3))
+    e_ext, e_ref, _ = pair(oracle, "iso", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(5)))
+    k = kernel.cfg()
+    e_ext._call("ahmc_ext_begin", C.byref(k), 3)
+    e_ext._ext_drive()
+    for _ in range(3):
+        e_ref.transition(kernel)
+    assert_same_state(e_ext, e_ref)
+    assert e_ext.info("iteration") == 3
+    e_ext.close(); e_ref.close()
+
+
 def test_pending_list_and_partial_evaluation(oracle, rng):
     """`fn(θ, chains)`: only the listed columns are evaluated; garbage elsewhere must be ignored"""
     D, N = 3, 9

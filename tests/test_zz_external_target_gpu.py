@@ -305,3 +305,23 @@ def test_hip_user_density_tempered(hip, oracle, rng, TS):
         e_ref.transition(kernel)
         assert_close_state(e_ext, e_ref, min_match=0.99)
     e_ext.close(); e_ref.close()
+
+
+@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
+def test_hip_batch_of_static_transitions(hip, oracle, rng, TS):
+    D, N = 6, 90
+    m = make_metric("diag_shared", D, N, rng)
+    lf = A.Leapfrog(np.full(N, 0.3))
+    e_ext, e_ref = engines(hip, oracle, "iso", m, N, lf)
+    th0 = rng.normal(size=(D, N))
+    e_ext.set_position(th0)
+    e_ref.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(5)))
+    k = kernel.cfg()
+    e_ext._call("ahmc_ext_begin", C.byref(k), 3)
+    e_ext._ext_drive()
+    for _ in range(3):
+        e_ref.transition(kernel)
+    assert e_ext.info("iteration") == 3
+    assert_close_state(e_ext, e_ref, min_match=0.98)
+    e_ext.close(); e_ref.close()
