@@ -419,8 +419,17 @@ __device__ __forceinline__ void block_allsum2(T& a, T& b) {
 
 // Returns the signed step of the chain's next leapfrog (0 = motionless step or idle).  lp_in / lk_in: ℓπ, ℓκ of the
 // point the leapfrog that has just completed arrived at (registers, uniform across the wave).
-template <class T>
+// CRIT: the termination criterion (AHMC_TC_*).  1 = GeneralisedNoUTurn (:566-570), the default and the only one the
+// kernel k_d_tree is built for; 0 = ClassicNoUTurn (:551-557): the "ρ" slots hold θ of the first-built leaf instead
+// of a momentum sum; 2 = StrictGeneralisedNoUTurn (:579-617): three more vectors per pending level (r of the
+// first-built leaf, r and v of the last-built one) and r, v of the edge the current subtree grows from.
+template <int CRIT>
+struct DLevel {
+  static constexpr int STRIDE = CRIT == 2 ? DS_PER_LEVEL + 3 : DS_PER_LEVEL;  // vector slots per pending level
+};
+template <class T, int CRIT = 1>
 __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int64_t c, int lane /* thread of the chain's workgroup, 0 .. DT_THREADS-1 */, T lp_in, T lk_in) {
+  constexpr int LS = DLevel<CRIT>::STRIDE;
   DChain<T>& S = q.S[c];
   const int D = p.D;
   const bool slice = p.sampler == 2;
@@ -479,16 +488,17 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
     // v_first / the candidate may point into a pending level.  Data is copied only when it must
     // outlive the call (park, tree-level candidate).
     T* s_rho = dslot(q, p, DS_SUB_RHO, c);
-    const T* rho_v = r;
+    const T* rho_v = CRIT == 0 ? th : r;  // Classic: θ of the subtree's first-built leaf
     const T* vf_v = V;
+    const T* rf_v = r;  // Strict: r of the subtree's first-built leaf
     const T *cth_v = th, *cr_v = r, *cg_v = g;
     T sub_lp = lp, sub_lk = lk;
     // ---- merges: one per trailing zero bit of `leaf` (:649-673) ----
     const int nm = __builtin_ctz((uint32_t)leaf);
     int merged = 0;
     for (int lvl = 0; lvl < nm && !sub_term; ++lvl) {
-      T* p_rho = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 0, c);
-      T* p_vf = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 1, c);
+      T* p_rho = dslot(q, p, DS_FIXED + LS * lvl + 0, c);
+      T* p_vf = dslot(q, p, DS_FIXED + LS * lvl + 1, c);
       const T w_p = S.pw[lvl];
       bool keep_first;
       T w_new;
@@ -500,9 +510,9 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         keep_first = w_new < w_p + (T)ds.randexp();
       }
       if (keep_first) {
-        cth_v = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 2, c);
-        cr_v = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 3, c);
-        cg_v = dslot(q, p, DS_FIXED + DS_PER_LEVEL * lvl + 4, c);
+        cth_v = dslot(q, p, DS_FIXED + LS * lvl + 2, c);
+        cr_v = dslot(q, p, DS_FIXED + LS * lvl + 3, c);
+        cg_v = dslot(q, p, DS_FIXED + LS * lvl + 4, c);
         sub_lp = S.plp[lvl];
         sub_lk = S.plk[lvl];
       }
@@ -511,18 +521,61 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       na_c = S.pna[lvl] + na_c;
       const T dh_p = S.pdh[lvl];
       dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
-      // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
-      T dots[2] = {0, 0};
-      for (int d = lane; d < D; d += DT_THREADS) {
-        const T rho = p_rho[d] + rho_v[d];
-        dots[0] += rho * p_vf[d];
-        dots[1] += rho * V[d];
-        s_rho[d] = rho;
+      if constexpr (CRIT == 1) {
+        // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
+        T dots[2] = {0, 0};
+        for (int d = lane; d < D; d += DT_THREADS) {
+          const T rho = p_rho[d] + rho_v[d];
+          dots[0] += rho * p_vf[d];
+          dots[1] += rho * V[d];
+          s_rho[d] = rho;
+        }
+        rho_v = s_rho;
+        vf_v = p_vf;
+        block_allsum2(dots[0], dots[1]);
+        sub_term = (dots[0] <= 0) || (dots[1] <= 0);
+      } else if constexpr (CRIT == 0) {
+        // ClassicNoUTurn (:551-557): ends = the pending half's first-built leaf (θ in the ρ slot, v_first) and the
+        // current leaf; Δθ = θ_right − θ_left; terminated if Δθ·M⁻¹(−r_left) >= 0 or −Δθ·M⁻¹r_right >= 0
+        T dots[2] = {0, 0};
+        for (int d = lane; d < D; d += DT_THREADS) {
+          const T thl = v > 0 ? p_rho[d] : th[d], thr = v > 0 ? th[d] : p_rho[d];
+          const T vl = v > 0 ? p_vf[d] : V[d], vr = v > 0 ? V[d] : p_vf[d];
+          const T dth = thr - thl;
+          dots[0] += dth * (-vl);
+          dots[1] += (-dth) * vr;
+        }
+        rho_v = p_rho;  // the merged subtree's first-built leaf is the pending half's
+        vf_v = p_vf;
+        block_allsum2(dots[0], dots[1]);
+        sub_term = (dots[0] >= 0) || (dots[1] >= 0);
+      } else {
+        // StrictGeneralisedNoUTurn (:579-617).  F = the pending (first-built) half, S = the half just completed:
+        //   (ρ_F + ρ_S ; ends F.first, S.last)   (ρ_F + r_S.first ; ends F.first, S.first)   (r_F.last + ρ_S ; ends F.last, S.last)
+        const T* p_rf = dslot(q, p, DS_FIXED + LS * lvl + 5, c);
+        const T* p_rl = dslot(q, p, DS_FIXED + LS * lvl + 6, c);
+        const T* p_vl = dslot(q, p, DS_FIXED + LS * lvl + 7, c);
+        T dots[6] = {0, 0, 0, 0, 0, 0};
+        for (int d = lane; d < D; d += DT_THREADS) {
+          const T rho = p_rho[d] + rho_v[d];
+          const T rho2 = p_rho[d] + rf_v[d];
+          const T rho3 = p_rl[d] + rho_v[d];
+          dots[0] += rho * p_vf[d];
+          dots[1] += rho * V[d];
+          dots[2] += rho2 * p_vf[d];
+          dots[3] += rho2 * vf_v[d];
+          dots[4] += rho3 * p_vl[d];
+          dots[5] += rho3 * V[d];
+          s_rho[d] = rho;
+        }
+        rho_v = s_rho;
+        vf_v = p_vf;
+        rf_v = p_rf;
+        block_allsum2(dots[0], dots[1]);
+        block_allsum2(dots[2], dots[3]);
+        block_allsum2(dots[4], dots[5]);
+        sub_term = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
       }
-      rho_v = s_rho;
-      vf_v = p_vf;
-      block_allsum2(dots[0], dots[1]);
-      sub_term = (dots[0] <= 0) || (dots[1] <= 0);
       merged = lvl + 1;
     }
     bool subtree_over = true;
@@ -539,17 +592,27 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       }
     } else if ((uint32_t)leaf < nleaf) {
       // park the finished level-nm subtree until its sibling is built
-      T* p_rho = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 0, c);
-      T* p_vf = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 1, c);
-      T* p_cth = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 2, c);
-      T* p_cr = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 3, c);
-      T* p_cg = dslot(q, p, DS_FIXED + DS_PER_LEVEL * nm + 4, c);
+      T* p_rho = dslot(q, p, DS_FIXED + LS * nm + 0, c);
+      T* p_vf = dslot(q, p, DS_FIXED + LS * nm + 1, c);
+      T* p_cth = dslot(q, p, DS_FIXED + LS * nm + 2, c);
+      T* p_cr = dslot(q, p, DS_FIXED + LS * nm + 3, c);
+      T* p_cg = dslot(q, p, DS_FIXED + LS * nm + 4, c);
       for (int d = lane; d < D; d += DT_THREADS) {
         p_rho[d] = rho_v[d];
         p_vf[d] = vf_v[d];
         p_cth[d] = cth_v[d];
         p_cr[d] = cr_v[d];
         p_cg[d] = cg_v[d];
+      }
+      if constexpr (CRIT == 2) {  // r of the first-built leaf, r and v of the last-built one (the current leaf)
+        T* p_rf = dslot(q, p, DS_FIXED + LS * nm + 5, c);
+        T* p_rl = dslot(q, p, DS_FIXED + LS * nm + 6, c);
+        T* p_vl = dslot(q, p, DS_FIXED + LS * nm + 7, c);
+        for (int d = lane; d < D; d += DT_THREADS) {
+          p_rf[d] = rf_v[d];
+          p_rl[d] = r[d];
+          p_vl[d] = V[d];
+        }
       }
       if (lane == 0) {
         S.pw[nm] = w_c;
@@ -594,7 +657,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
     w_tree = slice ? w_tree + w_c : logaddexp(w_tree, w_c);
     // isterminated on the whole tree; its edges are `cur` and the dormant one
     bool turn;
-    {
+    if constexpr (CRIT == 1) {
       T* t_rho = dslot(q, p, DS_TREE_RHO, c);
       const T* o_v = dslot(q, p, DS_OTH_V, c);
       T dots[2] = {0, 0};
@@ -606,6 +669,44 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       }
       block_allsum2(dots[0], dots[1]);
       turn = (dots[0] <= 0) || (dots[1] <= 0);
+    } else if constexpr (CRIT == 0) {
+      const T* o_th = dslot(q, p, DS_OTH_TH, c);
+      const T* o_v = dslot(q, p, DS_OTH_V, c);
+      const bool cl = cur_is_left_in != 0;
+      T dots[2] = {0, 0};
+      for (int d = lane; d < D; d += DT_THREADS) {
+        const T thl = cl ? th[d] : o_th[d], thr = cl ? o_th[d] : th[d];
+        const T vl = cl ? V[d] : o_v[d], vr = cl ? o_v[d] : V[d];
+        const T dth = thr - thl;
+        dots[0] += dth * (-vl);
+        dots[1] += (-dth) * vr;
+      }
+      block_allsum2(dots[0], dots[1]);
+      turn = (dots[0] >= 0) || (dots[1] >= 0);
+    } else {
+      // strict at the top: (ρ_tree + ρ_sub ; ends current edge, other edge), (ρ_tree + r_sub.first ; ends other edge,
+      // sub.first) and (r_start + ρ_sub ; ends start edge, current edge); start edge = the one the subtree grew from
+      T* t_rho = dslot(q, p, DS_TREE_RHO, c);
+      const T* o_v = dslot(q, p, DS_OTH_V, c);
+      const T* rs = dslot(q, p, DS_START_R, c);
+      const T* vs = dslot(q, p, DS_START_G, c);
+      T dots[6] = {0, 0, 0, 0, 0, 0};
+      for (int d = lane; d < D; d += DT_THREADS) {
+        const T rho = t_rho[d] + rho_v[d];
+        const T rho2 = t_rho[d] + rf_v[d];
+        const T rho3 = rs[d] + rho_v[d];
+        dots[0] += rho * V[d];
+        dots[1] += rho * o_v[d];
+        dots[2] += rho2 * o_v[d];
+        dots[3] += rho2 * vf_v[d];
+        dots[4] += rho3 * vs[d];
+        dots[5] += rho3 * V[d];
+        t_rho[d] = rho;
+      }
+      block_allsum2(dots[0], dots[1]);
+      block_allsum2(dots[2], dots[3]);
+      block_allsum2(dots[4], dots[5]);
+      turn = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
     }
     const bool done = sub_term || turn || (jw + 1 >= p.max_depth);
     if (!done) {
@@ -626,6 +727,14 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
           t = o_g[d]; o_g[d] = g[d]; g[d] = t;
           t = o_v[d]; o_v[d] = V[d]; V[d] = t;
           if (q.dense_metric) { t = o_w[d]; o_w[d] = Wc[d]; Wc[d] = t; }
+        }
+      }
+      if constexpr (CRIT == 2) {  // r, v of the edge the next subtree grows from (each thread re-reads its own elements)
+        T* rs = dslot(q, p, DS_START_R, c);
+        T* vs = dslot(q, p, DS_START_G, c);
+        for (int d = lane; d < D; d += DT_THREADS) {
+          rs[d] = r[d];
+          vs[d] = V[d];
         }
       }
       if (lane == 0) {
@@ -712,6 +821,10 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
       o_th[d] = td; o_r[d] = rd; o_g[d] = gd; o_v[d] = vd;
       t_rho[d] = rd;
       c_th[d] = td; c_r[d] = rd; c_g[d] = gd;
+      if constexpr (CRIT == 2) {
+        dslot(q, p, DS_START_R, c)[d] = rd;
+        dslot(q, p, DS_START_G, c)[d] = vd;
+      }
     }
     block_allsum2(dots[0], dots[1]);
     const T lp = lp_start;
@@ -781,6 +894,56 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree(KP<T> p, DP<T> q, const T
     }
   }
   const T e = d_tree_advance(p, q, c, lane, lp, lk);
+  if (lane == 0) q.es[c] = e;
+  if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237)
+    for (int d = lane; d < D; d += DT_THREADS) {
+      const T rh = r[d] - e / 2 * g[d];
+      const T vh = W ? V[d] - e / 2 * W[d] : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
+      r[d] = rh;
+      V[d] = vh;
+      th[d] = th[d] + e * vh;
+    }
+  }
+}
+
+// the same global step with ClassicNoUTurn (CRIT = 0) / StrictGeneralisedNoUTurn (CRIT = 2): k_d_tree's body around
+// d_tree_advance<T, CRIT> (kept as a second kernel so that the code of the default one does not move)
+template <class T, int CRIT>
+__global__ __launch_bounds__(DT_THREADS) void k_d_tree_crit(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
+  const int lane = threadIdx.x;  // one chain per workgroup of DT_THREADS threads
+  const int64_t j = blockIdx.x;
+  if (j >= q.n_list) return;
+  const int64_t c = q.list ? q.list[j] : j;
+  if (q.S[c].phase == DPH_IDLE) return;
+  const int D = p.D;
+  T* th = p.th() + c * D;
+  T* r = p.r() + c * D;
+  T* g = p.g() + c * D;
+  T* V = dslot(q, p, DS_CUR_V, c);
+  T* W = q.dense_metric ? dslot(q, p, DS_CUR_W, c) : nullptr;
+  T lp = p.lp()[c], lk = p.lk()[c];
+  if (do_post) {
+    const T e = q.es[c];
+    T s[2] = {0, 0};
+    for (int d = lane; d < D; d += DT_THREADS) {
+      const T gd = g[d];
+      T rn = r[d], vn;
+      if (e != T(0)) rn = rn - e / 2 * gd;
+      if (W) vn = e != T(0) ? V[d] - e / 2 * W[d] : V[d];
+      else vn = minv ? minv[per_chain ? c * D + d : d] * rn : rn;
+      if (e != T(0) || !W) { r[d] = rn; V[d] = vn; }
+      s[0] += rn * vn;
+      s[1] += th[d] * gd;
+    }
+    block_allsum2(s[0], s[1]);
+    lk = sanitize(-s[0] / 2);
+    if (dense_target) lp = sanitize(-s[1] / 2);
+    if (lane == 0) {
+      p.lk()[c] = lk;
+      if (dense_target) p.lp()[c] = lp;
+    }
+  }
+  const T e = d_tree_advance<T, CRIT>(p, q, c, lane, lp, lk);
   if (lane == 0) q.es[c] = e;
   if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237)
     for (int d = lane; d < D; d += DT_THREADS) {

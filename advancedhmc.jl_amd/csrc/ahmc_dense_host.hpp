@@ -59,9 +59,10 @@ int dn_refresh_fused(Ctx<T>* c) {
 
 // workspace for trees of up to max_depth doublings
 template <class T>
-int dn_ensure(Ctx<T>* c, int max_depth) {
+int dn_ensure(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
   const int nlev = max_depth > 1 ? max_depth - 1 : 1;
-  const size_t slots = (size_t)DS_FIXED + (size_t)DS_PER_LEVEL * nlev;
+  const size_t per_level = criterion == AHMC_TC_STRICT ? DLevel<2>::STRIDE : DLevel<1>::STRIDE;
+  const size_t slots = (size_t)DS_FIXED + per_level * nlev;
   if (slots > c->dn_slots) {
     if (c->dn_W) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->dn_W)); c->dn_W = nullptr; }
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_W), slots * (size_t)c->D * (size_t)c->N * sizeof(T)));
@@ -394,14 +395,24 @@ int dn_nuts_batch_momenta(Ctx<T>* c, int n_trans, double refresh_alpha) {
   return AHMC_OK;
 }
 
+// one global step of the tree state machine with the kernel built for the criterion
+template <class T>
+void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, const DP<T>& q, const T* minv_d, int per_chain, int dense_target, int do_post) {
+  if (criterion == AHMC_TC_CLASSIC)
+    hipLaunchKernelGGL((k_d_tree_crit<T, 0>), dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post);
+  else if (criterion == AHMC_TC_STRICT)
+    hipLaunchKernelGGL((k_d_tree_crit<T, 2>), dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post);
+  else
+    hipLaunchKernelGGL((k_d_tree<T>), dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post);
+}
+
 // n_trans NUTS transitions of every chain (asynchronous chains, see ahmc_dense.hpp)
 template <class T>
 int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha, bool accum,
                        int n_trans, T* samples_dev) {
   int rc = dn_check(c, "nuts_transition", refresh_alpha, true);
   if (rc) return rc;
-  if (criterion != AHMC_TC_GENERALISED)
-    return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine implements GeneralisedNoUTurn only");
+  if (criterion < AHMC_TC_CLASSIC || criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
   if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");
   if (refresh_alpha != 0 && n_trans > 1) {
     // a partially refreshed momentum depends on the momentum the previous transition ended with, so the batch's
@@ -412,7 +423,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     }
     return AHMC_OK;
   }
-  rc = dn_ensure(c, max_depth);
+  rc = dn_ensure(c, max_depth, criterion);
   if (rc) return rc;
   rc = dn_nuts_batch_momenta(c, n_trans, refresh_alpha);
   if (rc) return rc;
@@ -431,7 +442,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   const int pc = c->minv_per_chain ? 1 : 0;
   T* Wcur = dm ? c->dn_W + (size_t)DS_CUR_W * c->D * c->N : nullptr;
   // start of transition 0 (and, for Unit/Diag metrics, the first half of its first leapfrog)
-  hipLaunchKernelGGL((k_d_tree<T>), dim3((unsigned)c->N), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 0);
+  launch_d_tree(c, criterion, (unsigned)c->N, p, q, minv_d, pc, dt ? 1 : 0, 0);
   HIPCHK(hipGetLastError());
   // global steps until every chain has finished the batch.  Every CHUNK steps the list of chains
   // still running is compacted and its length read back, so the tail of the batch (few chains with
@@ -458,7 +469,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
           if (rc) return rc;
         }
       }
-      hipLaunchKernelGGL((k_d_tree<T>), dim3((unsigned)n_list), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, pc, dt ? 1 : 0, 1);
+      launch_d_tree(c, criterion, (unsigned)n_list, p, q, minv_d, pc, dt ? 1 : 0, 1);
     }
     done_steps += CHUNK;
     c->dn_global_steps += CHUNK;

@@ -105,11 +105,9 @@ int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
   if (cfg->nuts) {
     if (cfg->sampler != AHMC_TS_MULTINOMIAL && cfg->sampler != AHMC_TS_SLICE) return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
     if (cfg->criterion < AHMC_TC_CLASSIC || cfg->criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
-    if (cfg->criterion != AHMC_TC_GENERALISED)
-      return fail(c, AHMC_ERR_UNSUPPORTED, "ext_begin: the step-synchronous engine implements GeneralisedNoUTurn only");
     if (cfg->max_depth < 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: max_depth must be >= 1");
     if (cfg->max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "ext_begin: the step-synchronous engine supports max_depth <= 17");
-    rc = dn_ensure(c, cfg->max_depth);
+    rc = dn_ensure(c, cfg->max_depth, cfg->criterion);
     if (rc) return rc;
     rc = dn_nuts_batch_momenta(c, n_trans, cfg->refresh_alpha);
     if (rc) return rc;
@@ -127,7 +125,7 @@ int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
     hipLaunchKernelGGL((k_d_tree_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, c->dn_es, c->dn_active, c->N);
     const T* minv_d = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
     // start of transition 0 of every chain (Unit / Diag metric: and the first half of its first leapfrog)
-    hipLaunchKernelGGL((k_d_tree<T>), dim3((unsigned)c->N), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, c->minv_per_chain ? 1 : 0, 0, 0);
+    launch_d_tree(c, cfg->criterion, (unsigned)c->N, p, q, minv_d, c->minv_per_chain ? 1 : 0, 0, 0);
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   }
@@ -249,7 +247,7 @@ int ext_advance(Ctx<T>* c, const void* lp_in, const void* g_in) {
     }
     KP<T> p = ext_kp(c);
     DP<T> q = ext_dp(c);
-    hipLaunchKernelGGL((k_d_tree<T>), dim3((unsigned)x.n_list), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, c->minv_per_chain ? 1 : 0, 0, 1);
+    launch_d_tree(c, x.cfg.criterion, (unsigned)x.n_list, p, q, minv_d, c->minv_per_chain ? 1 : 0, 0, 1);
     // the chains still running: the next request
     int* out = c->dn_list + (size_t)x.pp * c->N;
     int* cnt = c->dn_active + 1;

@@ -44,10 +44,44 @@ def assert_close_state(e_ext, e_ref, min_match=0.999):
     return same
 
 
+@pytest.mark.parametrize("TC", [A.ClassicNoUTurn, A.StrictGeneralisedNoUTurn])
+@pytest.mark.parametrize("TS", [A.MultinomialTS, A.SliceTS])
+@pytest.mark.parametrize("metric,target", [("dense", "dense"), ("dense", "funnel"), ("diag", "dense"), ("unit", "dense")])
+def test_dense_engine_classic_and_strict_uturn(hip, oracle, rng, metric, target, TS, TC):
+    """ClassicNoUTurn (src/trajectory.jl:551-557) and StrictGeneralisedNoUTurn (:579-617) in the step-synchronous tree
+    kernel (k_d_tree_crit) against the oracle's recursion"""
+    D, N = 16, 160
+    B = rng.normal(size=(D, D))
+    tgt = A.DenseGaussian(B @ B.T / D + np.eye(D)) if target == "dense" else A.Funnel(D)
+    if metric == "dense":
+        C2 = rng.normal(size=(D, D))
+        m = A.DenseEuclideanMetric(C2 @ C2.T / D + np.eye(D))
+    elif metric == "diag":
+        m = A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+    else:
+        m = A.UnitEuclideanMetric(D)
+    lf = A.Leapfrog(np.full(N, 0.2) * (0.5 + rng.random(N)))
+    h = A.Hamiltonian(m, tgt)
+    e_g, e_o = A.Engine(h, N, rng=6, lib=hip), A.Engine(h, N, rng=6, lib=oracle)
+    th0 = rng.normal(size=(D, N)) * 0.5
+    for e in (e_g, e_o):
+        e.set_integrator(lf)
+        e.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, TC(max_depth=7)))
+    for _ in range(4):
+        e_g.transition(kernel)
+        e_o.transition(kernel)
+        same = assert_close_state(e_g, e_o, min_match=0.99)
+        if not same.all():
+            e_g.set_position(e_o.phasepoint().theta)
+    e_g.close(); e_o.close()
+
+
+@pytest.mark.parametrize("TC", [A.GeneralisedNoUTurn, A.ClassicNoUTurn, A.StrictGeneralisedNoUTurn])
 @pytest.mark.parametrize("target", ["iso", "funnel"])
 @pytest.mark.parametrize("metric", ["unit", "diag_chain", "diag_shared", "dense"])
 @pytest.mark.parametrize("TS", [A.MultinomialTS, A.SliceTS])
-def test_hip_nuts_with_user_density(hip, oracle, rng, target, metric, TS):
+def test_hip_nuts_with_user_density(hip, oracle, rng, target, metric, TS, TC):
     D, N = 10, 200
     m = make_metric(metric, D, N, rng)
     lf = A.Leapfrog(np.full(N, 0.25) * (0.5 + rng.random(N)))
@@ -55,7 +89,7 @@ def test_hip_nuts_with_user_density(hip, oracle, rng, target, metric, TS):
     th0 = rng.normal(size=(D, N))
     e_ext.set_position(th0)
     e_ref.set_position(th0)
-    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.GeneralisedNoUTurn(max_depth=7)))
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, TC(max_depth=7)))
     for _ in range(3):
         e_ext.transition(kernel)
         e_ref.transition(kernel)
@@ -180,8 +214,11 @@ def test_hip_unsupported_combinations_and_state_errors(hip, rng):
     e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.ExternalTarget(D, iso_fn)), N, lib=hip)
     e.set_integrator(lf)
     e.set_position(rng.normal(size=(D, N)))
-    with pytest.raises(A.UnsupportedError):
-        e.transition(A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.ClassicNoUTurn())))
+    tl = A.TemperedLeapfrog(0.1, 1.05)
+    e.set_integrator(tl)
+    with pytest.raises(A.UnsupportedError):  # the tree kernel has no tempering
+        e.transition(A.HMCKernel(A.Trajectory(A.MultinomialTS, tl, A.GeneralisedNoUTurn())))
+    e.set_integrator(lf)
     k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn())).cfg()
     e._call("ahmc_ext_begin", C.byref(k), 1)
     with pytest.raises(A.AHMCError, match="run is in progress"):
