@@ -906,9 +906,11 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree(KP<T> p, DP<T> q, const T
   }
 }
 
-// the same global step with ClassicNoUTurn (CRIT = 0) / StrictGeneralisedNoUTurn (CRIT = 2): k_d_tree's body around
-// d_tree_advance<T, CRIT> (kept as a second kernel so that the code of the default one does not move)
-template <class T, int CRIT>
+// the same global step with ClassicNoUTurn (CRIT = 0) / StrictGeneralisedNoUTurn (CRIT = 2) and / or TemperedLeapfrog
+// (TEMPER): k_d_tree's body around d_tree_advance<T, CRIT> (kept as a second kernel so that the code of the default
+// one does not move).  A NUTS leaf is step(lf, h, z, 1): temper multiplies r by √α before the first half-step and
+// divides it by √α after the second (src/integrator.jl:198-209 with n_steps = 1); v = M⁻¹r goes with it.
+template <class T, int CRIT, bool TEMPER>
 __global__ __launch_bounds__(DT_THREADS) void k_d_tree_crit(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
   const int lane = threadIdx.x;  // one chain per workgroup of DT_THREADS threads
   const int64_t j = blockIdx.x;
@@ -929,8 +931,17 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree_crit(KP<T> p, DP<T> q, co
       const T gd = g[d];
       T rn = r[d], vn;
       if (e != T(0)) rn = rn - e / 2 * gd;
-      if (W) vn = e != T(0) ? V[d] - e / 2 * W[d] : V[d];
-      else vn = minv ? minv[per_chain ? c * D + d : d] * rn : rn;
+      if constexpr (TEMPER) {
+        if (e != T(0)) rn = rn / p.lf.sqrt_alpha;
+      }
+      if (W) {
+        vn = e != T(0) ? V[d] - e / 2 * W[d] : V[d];
+        if constexpr (TEMPER) {
+          if (e != T(0)) vn = vn / p.lf.sqrt_alpha;
+        }
+      } else {
+        vn = minv ? minv[per_chain ? c * D + d : d] * rn : rn;
+      }
       if (e != T(0) || !W) { r[d] = rn; V[d] = vn; }
       s[0] += rn * vn;
       s[1] += th[d] * gd;
@@ -947,8 +958,13 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree_crit(KP<T> p, DP<T> q, co
   if (lane == 0) q.es[c] = e;
   if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237)
     for (int d = lane; d < D; d += DT_THREADS) {
-      const T rh = r[d] - e / 2 * g[d];
-      const T vh = W ? V[d] - e / 2 * W[d] : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
+      T r0 = r[d], v0 = W ? V[d] : T(0);
+      if constexpr (TEMPER) {
+        r0 = r0 * p.lf.sqrt_alpha;
+        v0 = v0 * p.lf.sqrt_alpha;
+      }
+      const T rh = r0 - e / 2 * g[d];
+      const T vh = W ? v0 - e / 2 * W[d] : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
       r[d] = rh;
       V[d] = vh;
       th[d] = th[d] + e * vh;

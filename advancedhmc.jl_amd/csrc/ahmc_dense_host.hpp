@@ -213,11 +213,10 @@ int dn_temper(Ctx<T>* c, int64_t i, bool second_half, int64_t n_pos, int64_t n_n
 }
 
 template <class T>
-int dn_check(Ctx<T>* c, const char* what, double refresh_alpha, bool tree = false) {
+int dn_check(Ctx<T>* c, const char* what, double refresh_alpha) {
   if (c->target_kind == AHMC_TARGET_EXTERNAL)
-    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": DenseEuclideanMetric with AHMC_TARGET_EXTERNAL is not implemented");
-  if (tree && c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
-    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the step-synchronous tree kernel");
+    return fail(c, AHMC_ERR_STATE, std::string(what) + ": with AHMC_TARGET_EXTERNAL the caller evaluates the log-density: use ahmc_set_phasepoint and the "
+                                                       "ask / tell calls ahmc_ext_* (or ahmc_lf_pre / ahmc_lf_post for single leapfrogs)");
   if (refresh_alpha < 0 || refresh_alpha >= 1)
     return fail(c, AHMC_ERR_ARGUMENT, std::string(what) + ": PartialMomentumRefreshment needs 0 <= α < 1");
   return AHMC_OK;
@@ -395,22 +394,27 @@ int dn_nuts_batch_momenta(Ctx<T>* c, int n_trans, double refresh_alpha) {
   return AHMC_OK;
 }
 
-// one global step of the tree state machine with the kernel built for the criterion
+// one global step of the tree state machine with the kernel built for the criterion and the integrator (the default
+// — GeneralisedNoUTurn, no tempering — is k_d_tree, the measured kernel)
 template <class T>
 void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, const DP<T>& q, const T* minv_d, int per_chain, int dense_target, int do_post) {
-  if (criterion == AHMC_TC_CLASSIC)
-    hipLaunchKernelGGL((k_d_tree_crit<T, 0>), dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post);
-  else if (criterion == AHMC_TC_STRICT)
-    hipLaunchKernelGGL((k_d_tree_crit<T, 2>), dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post);
-  else
-    hipLaunchKernelGGL((k_d_tree<T>), dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post);
+  const bool temper = c->integ_kind == AHMC_INTEGRATOR_TEMPERED;
+#define AHMC_LAUNCH_TREE(K) hipLaunchKernelGGL(K, dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post)
+  if (criterion == AHMC_TC_CLASSIC) {
+    if (temper) AHMC_LAUNCH_TREE((k_d_tree_crit<T, 0, true>)); else AHMC_LAUNCH_TREE((k_d_tree_crit<T, 0, false>));
+  } else if (criterion == AHMC_TC_STRICT) {
+    if (temper) AHMC_LAUNCH_TREE((k_d_tree_crit<T, 2, true>)); else AHMC_LAUNCH_TREE((k_d_tree_crit<T, 2, false>));
+  } else {
+    if (temper) AHMC_LAUNCH_TREE((k_d_tree_crit<T, 1, true>)); else AHMC_LAUNCH_TREE((k_d_tree<T>));
+  }
+#undef AHMC_LAUNCH_TREE
 }
 
 // n_trans NUTS transitions of every chain (asynchronous chains, see ahmc_dense.hpp)
 template <class T>
 int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha, bool accum,
                        int n_trans, T* samples_dev) {
-  int rc = dn_check(c, "nuts_transition", refresh_alpha, true);
+  int rc = dn_check(c, "nuts_transition", refresh_alpha);
   if (rc) return rc;
   if (criterion < AHMC_TC_CLASSIC || criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
   if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");

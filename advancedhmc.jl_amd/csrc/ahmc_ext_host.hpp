@@ -29,13 +29,11 @@ __global__ __launch_bounds__(256) void k_x_ingest(const T* __restrict__ lp_in, c
 }
 
 template <class T>
-int ext_common_checks(Ctx<T>* c, const char* what, bool tree = false) {
+int ext_common_checks(Ctx<T>* c, const char* what) {
   if (c->target_kind != AHMC_TARGET_EXTERNAL)
     return fail(c, AHMC_ERR_STATE, std::string(what) + ": the target is not AHMC_TARGET_EXTERNAL (built-in targets run through ahmc_*_transition / ahmc_sample)");
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, std::string(what) + " before set_phasepoint");
   if (c->ext.mode != EXT_IDLE) return fail(c, AHMC_ERR_STATE, std::string(what) + ": a run is already in progress");
-  if (tree && c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
-    return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + ": TemperedLeapfrog is not implemented in the step-synchronous tree kernel");
   return AHMC_OK;
 }
 
@@ -95,7 +93,7 @@ template <class T>
 int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
   if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: cfg is NULL");
   if (n_trans < 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: n_trans must be >= 1");
-  int rc = ext_common_checks(c, "ext_begin", cfg->nuts != 0);
+  int rc = ext_common_checks(c, "ext_begin");
   if (rc) return rc;
   if (cfg->refresh_alpha < 0 || cfg->refresh_alpha >= 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: PartialMomentumRefreshment needs 0 <= α < 1");
   if (cfg->refresh_alpha != 0 && cfg->nuts && n_trans > 1)

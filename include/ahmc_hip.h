@@ -295,7 +295,7 @@ int32_t ahmc_reset_accum(ahmc_ctx* ctx);
  * where the reference's `refresh` re-evaluates it (src/hamiltonian.jl:213-220 → phasepoint :115-119):
  * identical for a deterministic log-density (the CPU oracle asks for that evaluation, as the
  * reference does).  HIP engine: runs on the step-synchronous engine of the dense metric — Unit /
- * Diag / Dense metric; Leapfrog / JitteredLeapfrog (TemperedLeapfrog: static HMC only); full or partial
+ * Diag / Dense metric; Leapfrog / JitteredLeapfrog / TemperedLeapfrog; full or partial
  * refreshment (partial + NUTS: n_trans = 1); static EndPointTS / MultinomialTS; NUTS with MultinomialTS /
  * SliceTS and any of the three U-turn criteria; anything else is AHMC_ERR_UNSUPPORTED.
  * Any other call that changes the context between begin and the end of the loop is

@@ -325,8 +325,8 @@ def test_oracle_partial_refreshment_with_callback(oracle, rng):
     e_ext.close(); e_ref.close()
 
 
-@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
-def test_oracle_tempered_static_hmc_with_callback(oracle, rng, TS):
+@pytest.mark.parametrize("TS,TC", [(A.EndPointTS, None), (A.MultinomialTS, None), (A.MultinomialTS, A.GeneralisedNoUTurn)])
+def test_oracle_tempered_with_callback(oracle, rng, TS, TC):
     D, N = 5, 12
     m = make_metric("dense", D, N, rng)
     lf = A.TemperedLeapfrog(np.full(N, 0.2), 1.05)
@@ -334,7 +334,7 @@ def test_oracle_tempered_static_hmc_with_callback(oracle, rng, TS):
     th0 = rng.normal(size=(D, N))
     e_ext.set_position(th0)
     e_ref.set_position(th0)
-    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(6)))
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(6) if TC is None else TC(max_depth=5)))
     for _ in range(3):
         e_ext.transition(kernel)
         e_ref.transition(kernel)

@@ -214,11 +214,9 @@ def test_hip_unsupported_combinations_and_state_errors(hip, rng):
     e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.ExternalTarget(D, iso_fn)), N, lib=hip)
     e.set_integrator(lf)
     e.set_position(rng.normal(size=(D, N)))
-    tl = A.TemperedLeapfrog(0.1, 1.05)
-    e.set_integrator(tl)
-    with pytest.raises(A.UnsupportedError):  # the tree kernel has no tempering
-        e.transition(A.HMCKernel(A.Trajectory(A.MultinomialTS, tl, A.GeneralisedNoUTurn())))
-    e.set_integrator(lf)
+    kp = A.HMCKernel(A.PartialMomentumRefreshment(0.5), A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn())).cfg()
+    with pytest.raises(A.UnsupportedError):  # the next momentum depends on the one a transition ends with: one per run
+        e._call("ahmc_ext_begin", C.byref(kp), 2)
     k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn())).cfg()
     e._call("ahmc_ext_begin", C.byref(k), 1)
     with pytest.raises(A.AHMCError, match="run is in progress"):
@@ -322,13 +320,20 @@ def test_dense_engine_tempered_leapfrog(hip, oracle, rng, metric, target):
             np.testing.assert_allclose(sa["hamiltonian_energy"][close], sb["hamiltonian_energy"][close], rtol=1e-8, atol=1e-8)
             if not close.all():
                 e_g.set_position(zb.theta, zb.r)
-    with pytest.raises(A.UnsupportedError):
-        e_g.transition(A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn())))
+    # NUTS: every leaf is step(lf, h, z, 1), tempered up before its first half-step and down after its second
+    for TC in (A.GeneralisedNoUTurn, A.StrictGeneralisedNoUTurn):
+        kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, TC(max_depth=6)))
+        for _ in range(3):
+            e_g.transition(kernel)
+            e_o.transition(kernel)
+            same = assert_close_state(e_g, e_o, min_match=0.98)
+            if not same.all():
+                e_g.set_position(e_o.phasepoint().theta, e_o.phasepoint().r)
     e_g.close(); e_o.close()
 
 
-@pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
-def test_hip_user_density_tempered(hip, oracle, rng, TS):
+@pytest.mark.parametrize("TS,TC", [(A.EndPointTS, None), (A.MultinomialTS, None), (A.MultinomialTS, A.GeneralisedNoUTurn), (A.SliceTS, A.ClassicNoUTurn)])
+def test_hip_user_density_tempered(hip, oracle, rng, TS, TC):
     D, N = 9, 80
     m = make_metric("diag_chain", D, N, rng)
     lf = A.TemperedLeapfrog(np.full(N, 0.15), 1.05)
@@ -336,7 +341,7 @@ def test_hip_user_density_tempered(hip, oracle, rng, TS):
     th0 = rng.normal(size=(D, N))
     e_ext.set_position(th0)
     e_ref.set_position(th0)
-    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(6)))
+    kernel = A.HMCKernel(A.Trajectory(TS, lf, A.FixedNSteps(6) if TC is None else TC(max_depth=6)))
     for _ in range(3):
         e_ext.transition(kernel)
         e_ref.transition(kernel)
