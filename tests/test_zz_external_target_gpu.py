@@ -2,11 +2,12 @@
 reproduce the oracle running the same density built in (Float64: 1e-9 on energies / positions, discrete
 statistics identical on >= 99.9 % of chains — the bars of test_gpu_parity.py).
 
-This file sorts last on purpose and its tests are xfail(strict=False): the ahmc_ext_* host code was written
-after this round's GPU minutes were spent, so it has been exercised on the CPU oracle only
-(tests/test_external_target.py).  The device kernels it launches are the dense engine's, unchanged — verified by
-scripts/isa_digest.py against the build that passed the GPU suite.  A pass shows up as XPASS; the markers go
-once a GPU run has confirmed them.
+This file sorts last on purpose and its tests are xfail(strict=False): the ahmc_ext_* host code and the
+step-synchronous engine's new variants (static MultinomialTS, partial refreshment, TemperedLeapfrog, Classic / Strict
+U-turn) were written after this round's GPU minutes were spent, so they have been exercised on the CPU oracle only
+(tests/test_external_target.py).  The kernels of the measured build are untouched — scripts/isa_digest.py against
+profiles/r1_isa_digest_d9f5554.json; the new work is host orchestration plus new kernels.  A pass shows up as XPASS;
+the markers go once a GPU run has confirmed them.
 """
 import ctypes as C
 
@@ -16,7 +17,11 @@ import pytest
 import ahmc_amd as A
 from test_external_target import TARGETS, iso_fn, make_metric
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="ahmc_ext_* host path not yet run on a GPU (round 1 GPU budget spent)")]
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.xfail(strict=False, reason="step-synchronous engine additions not yet run on a GPU (round 1 GPU budget spent)"),
+              # every loop of the new host code is bounded (NUTS batches by their step bound, static HMC by L, the step-size
+              # search by its iteration count); should one hang all the same, the run is cut short instead of stalling
+              pytest.mark.timeout(240, method="thread")]
 
 RT = 1e-9
 
