@@ -17,7 +17,9 @@
 // oscillator bound (:108-153), seed self-consistency (test/sampler-vec.jl:69-80) and the
 // statistical checks (test/sampler-vec.jl:43,66).  An independent numpy restatement of the RNG-free
 // formulas (tests/golden/make_independent_golden.py -> independent_golden.json) is replayed against
-// this file by the same test module.
+// this file by the same test module, and a second, independent transcription of the Julia source of the
+// dynamic and static transitions (oracle/ahmc_ref.py, plain Python) must agree with this file bit for bit on
+// the same Philox streams (tests/test_oracle_cross.py).
 //
 // Each function cites the reference lines it follows (paths relative to the AdvancedHMC.jl
 // checkout).  Batch semantics: every chain is run through the reference's *scalar* (vector θ)

@@ -1,0 +1,420 @@
+"""ahmc_ref.py — a SECOND, independent restatement of the reference's dynamic and static transitions.
+
+TEST INFRASTRUCTURE ONLY (like everything under oracle/).  Transcribed from the Julia source of
+AdvancedHMC.jl v0.8.6 — struct for struct, function for function, recursion and all, in plain Python with
+float64 scalars and lists — not from oracle/ahmc_oracle.cpp.  Its job is to
+pin the C++ oracle's CONTROL logic (tree building, sampler combination, termination, statistics): the two
+restatements must agree bit for bit on the same Philox streams (tests/test_oracle_cross.py).  What the two
+share by construction is only the specification that is ours, not the reference's: the Philox4x32-10 stream
+layout of include/ahmc_hip.h (`ahmc_seed`) and the order in which a D-vector is summed (index order).
+
+Citations are path:line in the AdvancedHMC.jl checkout.
+"""
+import math
+
+INF = float("inf")
+RNG_MOMENTUM, RNG_TRANSITION, RNG_JITTER = 0, 1, 2
+M32 = 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al. 2011) and the stream layout: counter = (chain, iteration, purpose, slot),
+# key = (seed_lo, seed_hi)
+# ------------------------------------------------------------------------------------------------
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    for _ in range(10):
+        p0 = 0xD2511F53 * c0
+        p1 = 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32
+        k0 = (k0 + 0x9E3779B9) & M32
+        k1 = (k1 + 0xBB67AE85) & M32
+    return c0, c1, c2, c3
+
+
+class Rng:
+    def __init__(self, seed, chain, iteration):
+        self.k0, self.k1, self.chain, self.iter = seed & M32, (seed >> 32) & M32, chain & M32, iteration & M32
+        self.draw = 0  # sequential scalar draws of one transition
+
+    def raw(self, purpose, slot):
+        return philox4x32_10(self.chain, self.iter, purpose, slot & M32, self.k0, self.k1)
+
+    @staticmethod
+    def u53(hi, lo):
+        return (float(((hi >> 5) << 26) | (lo >> 6)) + 0.5) * (1.0 / 9007199254740992.0)
+
+    def uniform(self, purpose, slot):
+        p = self.raw(purpose, slot)
+        return self.u53(p[0], p[1])
+
+    def normal(self, purpose, d):  # Box–Muller on pair d // 2
+        p = self.raw(purpose, d >> 1)
+        u1, u2 = self.u53(p[0], p[1]), self.u53(p[2], p[3])
+        rad = math.sqrt(-2.0 * math.log(u1))
+        ang = 6.283185307179586476925286766559 * u2
+        return rad * math.sin(ang) if (d & 1) else rad * math.cos(ang)
+
+    # the `rng` argument of the dynamic transition: one 32-bit word per draw, in call order
+    def _word(self):
+        k = self.draw
+        self.draw += 1
+        return self.raw(RNG_TRANSITION, k >> 2)[k & 3]
+
+    def rand(self):
+        return (float(self._word()) + 0.5) * 2.3283064365386962890625e-10
+
+    def rand_bool(self):
+        return (self._word() >> 31) != 0
+
+    def randexp(self):
+        return -math.log(self.rand())
+
+
+# ------------------------------------------------------------------------------------------------
+# LogExpFunctions.logaddexp
+# ------------------------------------------------------------------------------------------------
+def logaddexp(x, y):
+    if x == y:
+        delta = 0.0
+    else:
+        delta = abs(x - y)
+    mx = x if x > y else y
+    if math.isnan(x) or math.isnan(y):
+        mx = float("nan")
+    return mx + math.log1p(math.exp(-delta))
+
+
+def jl_min(a, b):  # Base.min propagates NaN
+    if math.isnan(a) or math.isnan(b):
+        return float("nan")
+    return a if a < b else b
+
+
+def dot(a, b):
+    s = 0.0
+    for x, y in zip(a, b):
+        s += x * y
+    return s
+
+
+# ------------------------------------------------------------------------------------------------
+# Hamiltonian: metric (src/metric.jl, src/hamiltonian.jl:50-59,155-177) + target
+# ------------------------------------------------------------------------------------------------
+class Hamiltonian:
+    def __init__(self, minv, logdensity_and_gradient, D=None):
+        self.minv = minv  # None = UnitEuclideanMetric, list = DiagEuclideanMetric's M⁻¹
+        self.fn = logdensity_and_gradient
+        self.D = len(minv) if minv is not None else D
+
+    def dHdr(self, r):  # ∂H∂r (:50-59)
+        if self.minv is None:
+            return list(r)
+        return [m * x for m, x in zip(self.minv, r)]
+
+    def neg_energy_r(self, r):  # neg_energy(h, r, θ) (:155-177)
+        s = 0.0
+        if self.minv is None:
+            for x in r:
+                s += x * x
+        else:
+            for m, x in zip(self.minv, r):
+                s += (x * x) * m
+        return -s / 2
+
+    def dHdtheta(self, theta):  # ∂H∂θ (:45-48): DualValue(ℓπ, -∇ℓπ)
+        v, g = self.fn(theta)
+        return v, [-x for x in g]
+
+    def rand_momentum(self, rng):  # src/metric.jl:290-309
+        z = [rng.normal(RNG_MOMENTUM, d) for d in range(self.D)]
+        if self.minv is None:
+            return z
+        return [x / math.sqrt(m) for x, m in zip(z, self.minv)]
+
+
+def iso_gaussian(theta):  # test/common.jl:40-44, 52-56 with m = 0, s = 1
+    log2pi = 1.8378770664093454835606594728112
+    v = 0.0
+    for x in theta:
+        v += -(log2pi + x * x) / 2
+    return v, [-x for x in theta]
+
+
+def funnel(theta):  # research/notebooks/geweke_test.ipynb cell 4 (the arithmetic of include/ahmc_hip.h's family)
+    log2pi = 1.8378770664093454835606594728112
+    D = len(theta)
+    y = theta[0]
+    ss = 0.0
+    for x in theta[1:]:
+        ss += x * x
+    try:
+        ey = math.exp(-y)
+    except OverflowError:
+        ey = INF
+    nm1 = float(D - 1)
+    v = -(log2pi + 2 * math.log(3.0) + y * y / 9) / 2 - nm1 * (log2pi + y) / 2 - ss * ey / 2
+    g = [-y / 9 - nm1 / 2 + ss * ey / 2] + [-x * ey for x in theta[1:]]
+    return v, g
+
+
+class PhasePoint:  # src/hamiltonian.jl:88-107
+    def __init__(self, theta, r, lp, g, lk):
+        self.theta, self.r, self.g = theta, r, g
+        self.lp = lp if math.isfinite(lp) else -INF  # non-finite values → -Inf (:95-104)
+        self.lk = lk if math.isfinite(lk) else -INF
+
+    def isfinite(self, h):  # :141-142: values and gradients of ℓπ and ℓκ
+        return (math.isfinite(self.lp) and math.isfinite(self.lk) and all(math.isfinite(x) for x in self.g)
+                and all(math.isfinite(x) for x in h.dHdr(self.r)))
+
+
+def phasepoint(h, theta, r, lp=None, g=None):  # :115-119
+    if lp is None:
+        lp, g = h.dHdtheta(theta)
+    return PhasePoint(theta, r, lp, g, h.neg_energy_r(r))
+
+
+def energy(z):  # :149,194
+    return -(z.lp + z.lk)
+
+
+def neg_energy(z):
+    return z.lp + z.lk
+
+
+# ------------------------------------------------------------------------------------------------
+# step (src/integrator.jl:216-265), Leapfrog only
+# ------------------------------------------------------------------------------------------------
+def step(eps, h, z, n_steps=1, full_trajectory=False):
+    fwd = n_steps > 0
+    n_steps = abs(n_steps)
+    e = eps if fwd else -eps
+    res = []
+    theta, r, value, gradient = z.theta, z.r, z.lp, z.g
+    for _ in range(n_steps):
+        r = [a - e / 2 * b for a, b in zip(r, gradient)]
+        dr = h.dHdr(r)
+        theta = [a + e * b for a, b in zip(theta, dr)]
+        value, gradient = h.dHdtheta(theta)
+        r = [a - e / 2 * b for a, b in zip(r, gradient)]
+        z = phasepoint(h, theta, r, value, gradient)
+        res.append(z)
+        if not z.isfinite(h):
+            break
+    return res if full_trajectory else z
+
+
+# ------------------------------------------------------------------------------------------------
+# trajectory samplers (src/trajectory.jl:90-206)
+# ------------------------------------------------------------------------------------------------
+class SliceTS:
+    def __init__(self, zcand, lu, n):
+        self.zcand, self.lu, self.n = zcand, lu, n
+
+    @classmethod
+    def initial(cls, rng, z0):  # :143-144
+        return cls(z0, neg_energy(z0) - rng.randexp(), 1)
+
+    @classmethod
+    def leaf(cls, s, H0, zcand):  # :163-165
+        return cls(zcand, s.lu, int(s.lu <= neg_energy(zcand)))
+
+    @staticmethod
+    def combine_rng(rng, s1, s2):  # :178-183
+        n = s1.n + s2.n
+        zcand = s1.zcand if n * rng.rand() < s1.n else s2.zcand
+        return SliceTS(zcand, s1.lu, n)
+
+    @staticmethod
+    def combine_z(zcand, s1, s2):  # :185-189
+        return SliceTS(zcand, s1.lu, s1.n + s2.n)
+
+    @staticmethod
+    def mh_accept(rng, s, sp):  # :202
+        return s.n * rng.rand() < sp.n
+
+    def termination(self, delta_max, H0, Hp):  # :500-502
+        return Termination(False, not (self.lu < delta_max + -Hp))
+
+
+class MultinomialTS:
+    def __init__(self, zcand, lw):
+        self.zcand, self.lw = zcand, lw
+
+    @classmethod
+    def initial(cls, rng, z0):  # :155
+        return cls(z0, 0.0)
+
+    @classmethod
+    def leaf(cls, s, H0, zcand):  # :174-176
+        return cls(zcand, H0 + neg_energy(zcand))
+
+    @staticmethod
+    def combine_rng(rng, s1, s2):  # :191-195
+        lw = logaddexp(s1.lw, s2.lw)
+        zcand = s1.zcand if lw < s1.lw + rng.randexp() else s2.zcand
+        return MultinomialTS(zcand, lw)
+
+    @staticmethod
+    def combine_z(zcand, s1, s2):  # :197-200
+        return MultinomialTS(zcand, logaddexp(s1.lw, s2.lw))
+
+    @staticmethod
+    def mh_accept(rng, s, sp):  # :204-206
+        return s.lw < sp.lw + rng.randexp()
+
+    def termination(self, delta_max, H0, Hp):  # :503-507
+        return Termination(False, not (-H0 < delta_max + -Hp))
+
+
+# ------------------------------------------------------------------------------------------------
+# Termination, BinaryTree, U-turn criteria (src/trajectory.jl:454-623)
+# ------------------------------------------------------------------------------------------------
+class Termination:
+    def __init__(self, dynamic, numerical):
+        self.dynamic, self.numerical = dynamic, numerical
+
+    def __mul__(self, o):  # :493-495
+        return Termination(self.dynamic or o.dynamic, self.numerical or o.numerical)
+
+    def isterminated(self):
+        return self.dynamic or self.numerical
+
+
+class BinaryTree:  # :512-520
+    def __init__(self, zleft, zright, rho, sum_alpha, n_alpha, dH_max):
+        self.zleft, self.zright, self.rho, self.sum_alpha, self.n_alpha, self.dH_max = zleft, zright, rho, sum_alpha, n_alpha, dH_max
+
+
+def maxabs(a, b):  # :526
+    return a if abs(a) > abs(b) else b
+
+
+def combine_trees(tl, tr):  # :533-542, TurnStatistic combine :466-467
+    rho = None if tl.rho is None else [a + b for a, b in zip(tl.rho, tr.rho)]
+    return BinaryTree(tl.zleft, tr.zright, rho, tl.sum_alpha + tr.sum_alpha, tl.n_alpha + tr.n_alpha, maxabs(tl.dH_max, tr.dH_max))
+
+
+def generalised_uturn_criterion(rho, p_sharp_minus, p_sharp_plus):  # :619-621
+    return (dot(rho, p_sharp_minus) <= 0) or (dot(rho, p_sharp_plus) <= 0)
+
+
+CLASSIC, GENERALISED, STRICT = 0, 1, 2
+
+
+def isterminated_tree(tc, h, t, tleft, tright):
+    if tc == CLASSIC:  # :551-557
+        z0, z1 = t.zleft, t.zright
+        dth = [b - a for a, b in zip(z0.theta, z1.theta)]
+        s = (dot(dth, h.dHdr([-x for x in z0.r])) >= 0) or (dot([-x for x in dth], h.dHdr(z1.r)) >= 0)
+        return Termination(s, False)
+    s1 = Termination(generalised_uturn_criterion(t.rho, h.dHdr(t.zleft.r), h.dHdr(t.zright.r)), False)  # :566-570
+    if tc == GENERALISED:
+        return s1
+    # StrictGeneralisedNoUTurn (:579-617)
+    rho2 = [a + b for a, b in zip(tleft.rho, tright.zleft.r)]
+    s2 = Termination(generalised_uturn_criterion(rho2, h.dHdr(t.zleft.r), h.dHdr(tright.zleft.r)), False)
+    rho3 = [a + b for a, b in zip(tleft.zright.r, tright.rho)]
+    s3 = Termination(generalised_uturn_criterion(rho3, h.dHdr(tleft.zright.r), h.dHdr(t.zright.r)), False)
+    return s1 * s2 * s3
+
+
+# ------------------------------------------------------------------------------------------------
+# build_tree (:626-675) and the dynamic transition (:677-742)
+# ------------------------------------------------------------------------------------------------
+class NUTS:
+    def __init__(self, TS, tc, eps, max_depth=10, delta_max=1000.0):
+        self.TS, self.tc, self.eps, self.max_depth, self.delta_max = TS, tc, eps, max_depth, delta_max
+
+
+def build_tree(rng, nt, h, z, sampler, v, j, H0):
+    if j == 0:
+        zp = step(nt.eps, h, z, v)
+        Hp = energy(zp)
+        dH = Hp - H0
+        alpha = math.exp(jl_min(0.0, -dH))
+        sp = nt.TS.leaf(sampler, H0, zp)
+        rho = None if nt.tc == CLASSIC else zp.r
+        return BinaryTree(zp, zp, rho, alpha, 1, dH), sp, sp.termination(nt.delta_max, H0, Hp)
+    tree1, sampler1, term1 = build_tree(rng, nt, h, z, sampler, v, j - 1, H0)
+    if not term1.isterminated():
+        if v == -1:
+            tree2, sampler2, term2 = build_tree(rng, nt, h, tree1.zleft, sampler, v, j - 1, H0)
+            tl, tr = tree2, tree1
+        else:
+            tree2, sampler2, term2 = build_tree(rng, nt, h, tree1.zright, sampler, v, j - 1, H0)
+            tl, tr = tree1, tree2
+        tree1 = combine_trees(tl, tr)
+        sampler1 = nt.TS.combine_rng(rng, sampler1, sampler2)
+        term1 = term1 * term2 * isterminated_tree(nt.tc, h, tree1, tl, tr)
+    return tree1, sampler1, term1
+
+
+def nuts_transition(rng, h, nt, z0):
+    H0 = energy(z0)
+    tree = BinaryTree(z0, z0, None if nt.tc == CLASSIC else z0.r, 0.0, 0, 0.0)
+    sampler = nt.TS.initial(rng, z0)
+    termination = Termination(False, False)
+    zcand = z0
+    j = 0
+    while not termination.isterminated() and j < nt.max_depth:
+        vleft = rng.rand_bool()
+        if vleft:
+            treep, samplerp, termp = build_tree(rng, nt, h, tree.zleft, sampler, -1, j, H0)
+            tl, tr = treep, tree
+        else:
+            treep, samplerp, termp = build_tree(rng, nt, h, tree.zright, sampler, 1, j, H0)
+            tl, tr = tree, treep
+        if not termp.isterminated():
+            j = j + 1
+            if nt.TS.mh_accept(rng, sampler, samplerp):
+                zcand = samplerp.zcand
+        tree = combine_trees(tl, tr)
+        sampler = nt.TS.combine_z(zcand, sampler, samplerp)
+        termination = termination * termp * isterminated_tree(nt.tc, h, tree, tl, tr)
+    H = energy(zcand)
+    stat = dict(n_steps=tree.n_alpha, is_accept=True, acceptance_rate=tree.sum_alpha / tree.n_alpha, log_density=zcand.lp,
+                hamiltonian_energy=H, hamiltonian_energy_error=H - H0, max_hamiltonian_energy_error=tree.dH_max, tree_depth=j,
+                numerical_error=termination.numerical)
+    return zcand, stat
+
+
+# ------------------------------------------------------------------------------------------------
+# static transition, EndPointTS (src/trajectory.jl:271-340, mh_accept_ratio :855-880)
+# ------------------------------------------------------------------------------------------------
+def hmc_transition(rng, h, eps, L, z):
+    H0 = energy(z)
+    zp = step(eps, h, z, L)
+    Hp = energy(zp)
+    is_accept = Hp < H0 + (-math.log(rng.uniform(RNG_TRANSITION, 0)))  # :858: one 53-bit draw (static transitions keep 53 bits)
+    alpha = jl_min(1.0, math.exp(H0 - Hp))
+    zn = zp if is_accept else z
+    zn = PhasePoint(zn.theta, [-x for x in zn.r], zn.lp, zn.g, zn.lk)  # :283
+    H = energy(zn)
+    stat = dict(n_steps=L, is_accept=is_accept, acceptance_rate=alpha, log_density=zn.lp, hamiltonian_energy=H,
+                hamiltonian_energy_error=H - H0, numerical_error=not math.isfinite(Hp))
+    return zn, stat
+
+
+# ------------------------------------------------------------------------------------------------
+# transition(rng, h, κ, z) (src/sampler.jl:48-58): refresh, then the trajectory's transition
+# ------------------------------------------------------------------------------------------------
+def refresh(rng, h, z):  # FullMomentumRefreshment (src/hamiltonian.jl:213-220)
+    return phasepoint(h, z.theta, h.rand_momentum(rng))
+
+
+def sample_chain(seed, chain, h, kernel, theta0, n_transitions, iteration0=0):
+    """n_transitions of one chain from θ0; kernel = NUTS(...) or ("hmc", eps, L).  Returns (draws, stats)."""
+    z = phasepoint(h, list(theta0), [0.0] * len(theta0))
+    draws, stats = [], []
+    for it in range(n_transitions):
+        rng = Rng(seed, chain, iteration0 + it)
+        z = refresh(rng, h, z)
+        if isinstance(kernel, NUTS):
+            z, st = nuts_transition(rng, h, kernel, z)
+        else:
+            _, eps, L = kernel
+            z, st = hmc_transition(rng, h, eps, L, z)
+        draws.append((list(z.theta), list(z.r)))
+        stats.append(st)
+    return draws, stats

@@ -1,0 +1,132 @@
+"""The C++ oracle against a second, independent restatement of the reference (oracle/ahmc_ref.py: the Julia
+source transcribed struct for struct into plain Python).  Both run the same Philox streams; every discrete
+statistic and every float must agree bit for bit, transition after transition — which pins the oracle's control
+logic (recursion order of build_tree, which draws are consumed when, sampler combination, the three U-turn
+criteria, divergence, the statistics) to a second reading of src/trajectory.jl, not only to its known-answer tests.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import ahmc_amd as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ahmc_ref as R  # noqa: E402
+
+TARGETS = {"iso": (R.iso_gaussian, A.IsoGaussian), "funnel": (R.funnel, A.Funnel)}
+TS = {"multinomial": (R.MultinomialTS, A.MultinomialTS), "slice": (R.SliceTS, A.SliceTS)}
+TC = {"classic": (R.CLASSIC, A.ClassicNoUTurn), "generalised": (R.GENERALISED, A.GeneralisedNoUTurn), "strict": (R.STRICT, A.StrictGeneralisedNoUTurn)}
+
+FLOAT_STATS = ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error", "max_hamiltonian_energy_error")
+INT_STATS = ("n_steps", "tree_depth", "numerical_error", "is_accept")
+
+
+@pytest.mark.parametrize("target", ["iso", "funnel"])
+@pytest.mark.parametrize("metric", ["unit", "diag"])
+@pytest.mark.parametrize("ts", ["multinomial", "slice"])
+@pytest.mark.parametrize("tc", ["classic", "generalised", "strict"])
+def test_nuts_transitions_bit_for_bit(oracle, rng, target, metric, ts, tc):
+    D, N, n_trans, seed = 5, 12, 4, 0xA5A5
+    fn, builtin = TARGETS[target]
+    minv = None if metric == "unit" else (0.5 + rng.random((D, N)))
+    eps = 0.35 * (0.5 + rng.random(N))
+    th0 = rng.normal(size=(D, N))
+    m = A.UnitEuclideanMetric(D) if minv is None else A.DiagEuclideanMetric(np.asfortranarray(minv))
+    lf = A.Leapfrog(eps)
+    eng = A.Engine(A.Hamiltonian(m, builtin(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(lf)
+    eng.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS[ts][1], lf, TC[tc][1](max_depth=6, delta_max=50.0)))
+    ref = []
+    for c in range(N):
+        h = R.Hamiltonian(None if minv is None else [float(x) for x in minv[:, c]], fn, D)
+        nt = R.NUTS(TS[ts][0], TC[tc][0], float(eps[c]), max_depth=6, delta_max=50.0)
+        ref.append(R.sample_chain(seed, c, h, nt, [float(x) for x in th0[:, c]], n_trans))
+    depths = set()
+    for it in range(n_trans):
+        eng.transition(kernel)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            (th_ref, r_ref), st_ref = ref[c][0][it], ref[c][1][it]
+            assert [float(x) for x in z.theta[:, c]] == th_ref, (it, c)
+            assert [float(x) for x in z.r[:, c]] == r_ref, (it, c)
+            for k in FLOAT_STATS:
+                assert float(st[k][c]) == st_ref[k], (k, it, c)
+            for k in INT_STATS:
+                assert int(st[k][c]) == int(st_ref[k]), (k, it, c)
+            depths.add(st_ref["tree_depth"])
+    assert len(depths) > 1  # (trees of several sizes were built)
+    eng.close()
+
+
+@pytest.mark.parametrize("metric", ["unit", "diag"])
+def test_static_endpoint_transitions_bit_for_bit(oracle, rng, metric):
+    D, N, n_trans, seed, L = 4, 10, 5, 77, 6
+    minv = None if metric == "unit" else (0.5 + rng.random((D, N)))
+    eps = 0.4 * (0.5 + rng.random(N))
+    th0 = rng.normal(size=(D, N))
+    m = A.UnitEuclideanMetric(D) if minv is None else A.DiagEuclideanMetric(np.asfortranarray(minv))
+    lf = A.Leapfrog(eps)
+    eng = A.Engine(A.Hamiltonian(m, A.Funnel(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(lf)
+    eng.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(L)))
+    ref = []
+    for c in range(N):
+        h = R.Hamiltonian(None if minv is None else [float(x) for x in minv[:, c]], R.funnel, D)
+        ref.append(R.sample_chain(seed, c, h, ("hmc", float(eps[c]), L), [float(x) for x in th0[:, c]], n_trans))
+    accepts = set()
+    for it in range(n_trans):
+        eng.transition(kernel)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            (th_ref, r_ref), st_ref = ref[c][0][it], ref[c][1][it]
+            assert [float(x) for x in z.theta[:, c]] == th_ref, (it, c)
+            assert [float(x) for x in z.r[:, c]] == r_ref, (it, c)
+            for k in ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error"):
+                assert float(st[k][c]) == st_ref[k], (k, it, c)
+            assert bool(st["is_accept"][c]) == st_ref["is_accept"] and int(st["n_steps"][c]) == L
+            accepts.add(st_ref["is_accept"])
+    eng.close()
+
+
+def test_philox_restatement_against_random123_vectors():
+    """the Python Philox used above against the Random123 known-answer vectors (kat_vectors: philox4x32 10)"""
+    assert R.philox4x32_10(0, 0, 0, 0, 0, 0) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert R.philox4x32_10(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert R.philox4x32_10(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0) == (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+
+
+@pytest.mark.parametrize("ts", ["multinomial", "slice"])
+def test_divergent_and_max_depth_trees_bit_for_bit(oracle, rng, ts):
+    """large steps on the funnel (divergences: Δ_max exceeded, non-finite points) and tiny steps with max_depth 3
+    (trees that end by depth, not by a U-turn)"""
+    D, N, seed = 4, 16, 99
+    th0 = rng.normal(size=(D, N)) * 2
+    seen_div, seen_full = False, False
+    for eps_v, max_depth, delta_max in ((2.5, 6, 10.0), (1e-3, 3, 1000.0)):
+        lf = A.Leapfrog(np.full(N, eps_v))
+        eng = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.Funnel(D)), N, rng=seed, lib=oracle)
+        eng.set_integrator(lf)
+        eng.set_position(th0)
+        kernel = A.HMCKernel(A.Trajectory(TS[ts][1], lf, A.GeneralisedNoUTurn(max_depth=max_depth, delta_max=delta_max)))
+        for it in range(3):
+            eng.transition(kernel)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            h = R.Hamiltonian(None, R.funnel, D)
+            nt = R.NUTS(TS[ts][0], R.GENERALISED, eps_v, max_depth=max_depth, delta_max=delta_max)
+            draws, stats = R.sample_chain(seed, c, h, nt, [float(x) for x in th0[:, c]], 3)
+            assert [float(x) for x in z.theta[:, c]] == draws[-1][0], c
+            for k in FLOAT_STATS:
+                a, b = float(st[k][c]), stats[-1][k]
+                assert a == b or (np.isnan(a) and np.isnan(b)), (k, c, a, b)
+            for k in INT_STATS:
+                assert int(st[k][c]) == int(stats[-1][k]), (k, c)
+            seen_div |= any(s["numerical_error"] for s in stats)
+            seen_full |= any(s["tree_depth"] == max_depth and s["n_steps"] == 2 ** max_depth - 1 for s in stats)
+        eng.close()
+    assert seen_div and seen_full
