@@ -418,3 +418,164 @@ def sample_chain(seed, chain, h, kernel, theta0, n_transitions, iteration0=0):
         draws.append((list(z.theta), list(z.r)))
         stats.append(st)
     return draws, stats
+
+
+# ------------------------------------------------------------------------------------------------
+# static transition, MultinomialTS (src/trajectory.jl:369-390; randcat src/utilities.jl:51-59)
+# ------------------------------------------------------------------------------------------------
+COUPLED_CHAIN = 0xFFFFFFFF
+
+
+def hmc_multinomial_transition(rng, h, eps, L, z):
+    H0 = energy(z)
+    # n_steps_fwd = rand_coupled(rng, 0:n_steps) (:373): ONE draw shared by all chains — the stream of chain 0xFFFFFFFF
+    shared = Rng((rng.k1 << 32) | rng.k0, COUPLED_CHAIN, rng.iter)
+    n_fwd = int(math.floor(shared.uniform(RNG_TRANSITION, 0) * float(L + 1)))
+    n_fwd = min(n_fwd, L)
+    zs_fwd = step(eps, h, z, n_fwd, full_trajectory=True)
+    zs_bwd = step(eps, h, z, -(L - n_fwd), full_trajectory=True) if L - n_fwd > 0 else []
+    zs = list(reversed(zs_bwd)) + [z] + zs_fwd  # vcat(reverse(zs_bwd)..., z, zs_fwd...) (:377)
+    lw = [-energy(zz) for zz in zs]  # unnormalised log weights (:379)
+    mx = -INF
+    for v in lw:
+        mx = v if v > mx else mx
+    se = 0.0
+    for v in lw:
+        se += math.exp(v - mx)
+    lse = mx + math.log(se)
+    u = rng.uniform(RNG_TRANSITION, 0)
+    cum, idx = 0.0, 0
+    while cum < u and idx < len(zs):  # randcat: the first index whose cumulated probability reaches u
+        cum += math.exp(lw[idx] - lse)
+        idx += 1
+    zp = zs[max(idx, 1) - 1]
+    sa = 0.0
+    for v in lw:
+        sa += math.exp(jl_min(0.0, -((-v) - H0)))
+    alpha = sa / float(len(lw))  # mean MH acceptance over the trajectory (:385-388)
+    zn = PhasePoint(zp.theta, [-x for x in zp.r], zp.lp, zp.g, zp.lk)
+    H = energy(zn)
+    stat = dict(n_steps=L, is_accept=True, acceptance_rate=alpha, log_density=zn.lp, hamiltonian_energy=H,
+                hamiltonian_energy_error=H - H0, numerical_error=not math.isfinite(energy(zp)))
+    return zn, stat
+
+
+# ------------------------------------------------------------------------------------------------
+# adaptation (src/adaptation/stepsize.jl, massmatrix.jl, stan_adaptor.jl; glue src/sampler.jl:3-22,72-90), one chain
+# ------------------------------------------------------------------------------------------------
+class DualAveraging:  # NesterovDualAveraging(δ, ϵ) (stepsize.jl:168-172) with DAState (:25-31)
+    def __init__(self, delta, eps, gamma=0.05, t0=10.0, kappa=0.75):
+        self.delta, self.gamma, self.t0, self.kappa = delta, gamma, t0, kappa
+        self.m, self.eps, self.mu, self.x_bar, self.H_bar = 0, eps, math.log(10 * eps), 0.0, 0.0
+
+    def adapt(self, alpha):  # adapt_stepsize! (:178-210)
+        m = self.m + 1
+        eta_H = 1.0 / (m + self.t0)
+        H_bar = (1.0 - eta_H) * self.H_bar + eta_H * (self.delta - jl_min(1.0, alpha))
+        x = self.mu - H_bar * (math.sqrt(m) / self.gamma)
+        eta_x = m ** (-self.kappa)
+        x_bar = (1.0 - eta_x) * self.x_bar + eta_x * x
+        eps = math.exp(x)
+        if not math.isfinite(eps):  # (:198-202)
+            m, eps, x_bar, H_bar = self.m, self.eps, self.x_bar, self.H_bar
+        self.m, self.eps, self.x_bar, self.H_bar = m, eps, x_bar, H_bar
+
+    def reset(self):  # (:40-46)
+        self.m, self.mu, self.x_bar, self.H_bar = 0, math.log(10 * self.eps), 0.0, 0.0
+
+    def finalize(self):  # (:55-58)
+        self.eps = math.exp(self.x_bar)
+
+
+class WelfordVar:  # massmatrix.jl:86-157
+    def __init__(self, D, n_min=10):
+        self.n, self.n_min, self.mu, self.M, self.var = 0, n_min, [0.0] * D, [0.0] * D, [1.0] * D
+
+    def push(self, s):  # (:141-149)
+        self.n += 1
+        n = float(self.n)
+        delta = [a - b for a, b in zip(s, self.mu)]
+        self.mu = [a + d / n for a, d in zip(self.mu, delta)]
+        self.M = [a + d * d * ((n - 1) / n) for a, d in zip(self.M, delta)]
+
+    def get_estimation(self):  # (:152-157)
+        n = float(self.n)
+        return [n / ((n + 5) * (n - 1)) * m + 1e-3 * (5 / (n + 5)) for m in self.M]
+
+    def update(self):  # update!(ve) (:60-62)
+        if self.n >= self.n_min:
+            self.var = self.get_estimation()
+
+    def reset(self):  # (:134-139)
+        self.n = 0
+        self.mu = [0.0] * len(self.mu)
+        self.M = [0.0] * len(self.M)
+
+
+def stan_windows(init_buffer, term_buffer, window_size, n_adapts):  # initialize! (stan_adaptor.jl:13-50)
+    window_start, window_end = init_buffer + 1, n_adapts - term_buffer
+    splits = []
+    next_window = init_buffer + window_size
+    while next_window <= window_end:
+        if next_window + 2 * window_size > window_end:
+            next_window = window_end
+        splits.append(next_window)
+        window_size *= 2
+        next_window += window_size
+    if splits and splits[-1] == n_adapts:
+        splits.pop()
+    return window_start, window_end, splits
+
+
+class StanHMCAdaptor:  # stan_adaptor.jl:94-159
+    def __init__(self, pc, ssa, init_buffer=75, term_buffer=50, window_size=25):
+        self.pc, self.ssa, self.ib, self.tb, self.ws = pc, ssa, init_buffer, term_buffer, window_size
+        self.i, self.window_start, self.window_end, self.splits = 0, 0, 0, []
+
+    def initialize(self, n_adapts):
+        self.window_start, self.window_end, self.splits = stan_windows(self.ib, self.tb, self.ws, n_adapts)
+
+    def adapt(self, theta, alpha):  # (:137-159)
+        self.i += 1
+        self.ssa.adapt(alpha)
+        if self.window_start <= self.i <= self.window_end:
+            self.pc.push(theta)
+            if self.i in self.splits:
+                self.pc.update()
+        if self.i in self.splits:
+            self.ssa.reset()
+            self.pc.reset()
+
+
+def sample_chain_adapted(seed, chain, fn, minv0, eps0, kernel_of, theta0, n_samples, n_adapts, delta=0.8, windows=(75, 50, 25)):
+    """sample(rng, h, κ, θ, n_samples, StanHMCAdaptor(WelfordVar, NesterovDualAveraging(δ, ϵ)), n_adapts)
+    (src/sampler.jl:159-248) for one chain with a DiagEuclideanMetric; kernel_of(eps) -> NUTS(...) or ("hmc", eps, L) /
+    ("hmc_mn", eps, L).  Returns (draws, stats, final eps, final M⁻¹)."""
+    D = len(theta0)
+    h = Hamiltonian(list(minv0), fn, D)
+    eps = eps0
+    adaptor = StanHMCAdaptor(WelfordVar(D), DualAveraging(delta, eps0), *windows)
+    z = phasepoint(h, list(theta0), [0.0] * D)
+    draws, stats = [], []
+    for i in range(1, n_samples + 1):
+        rng = Rng(seed, chain, i - 1)
+        z = refresh(rng, h, z)
+        kernel = kernel_of(eps)
+        if isinstance(kernel, NUTS):
+            z, st = nuts_transition(rng, h, kernel, z)
+        elif kernel[0] == "hmc":
+            z, st = hmc_transition(rng, h, kernel[1], kernel[2], z)
+        else:
+            z, st = hmc_multinomial_transition(rng, h, kernel[1], kernel[2], z)
+        st["step_size"] = eps
+        if i <= n_adapts:  # adapt!(h, κ, adaptor, i, n_adapts, z, α) (src/sampler.jl:72-90)
+            if i == 1:
+                adaptor.initialize(n_adapts)
+            adaptor.adapt(z.theta, st["acceptance_rate"])
+            if i == n_adapts:
+                adaptor.ssa.finalize()
+            h = Hamiltonian(list(adaptor.pc.var), fn, D)  # update(h, adaptor): renew(metric, getM⁻¹)
+            eps = adaptor.ssa.eps                          # update(κ, adaptor): nominal step size ← getϵ
+        draws.append((list(z.theta), list(z.r)))
+        stats.append(st)
+    return draws, stats, eps, list(h.minv)

@@ -130,3 +130,61 @@ def test_divergent_and_max_depth_trees_bit_for_bit(oracle, rng, ts):
             seen_full |= any(s["tree_depth"] == max_depth and s["n_steps"] == 2 ** max_depth - 1 for s in stats)
         eng.close()
     assert seen_div and seen_full
+
+
+def test_static_multinomial_transitions_bit_for_bit(oracle, rng):
+    D, N, n_trans, seed, L = 4, 10, 6, 31, 7
+    minv = 0.5 + rng.random((D, N))
+    eps = 0.35 * (0.5 + rng.random(N))
+    th0 = rng.normal(size=(D, N))
+    lf = A.Leapfrog(eps)
+    eng = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(np.asfortranarray(minv)), A.Funnel(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(lf)
+    eng.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.FixedNSteps(L)))
+    zs = []
+    for c in range(N):
+        h = R.Hamiltonian([float(x) for x in minv[:, c]], R.funnel, D)
+        zs.append(R.phasepoint(h, [float(x) for x in th0[:, c]], [0.0] * D))
+    for it in range(n_trans):
+        eng.transition(kernel)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            h = R.Hamiltonian([float(x) for x in minv[:, c]], R.funnel, D)
+            r = R.Rng(seed, c, it)
+            zs[c], sr = R.hmc_multinomial_transition(r, h, float(eps[c]), L, R.refresh(r, h, zs[c]))
+            assert [float(x) for x in z.theta[:, c]] == zs[c].theta, (it, c)
+            assert [float(x) for x in z.r[:, c]] == zs[c].r, (it, c)
+            for k in ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error"):
+                assert float(st[k][c]) == sr[k], (k, it, c)
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["nuts", "hmc"])
+def test_sample_with_stan_adaptor_bit_for_bit(oracle, rng, kind):
+    """the whole `sample` loop with StanHMCAdaptor(WelfordVar, NesterovDualAveraging): window schedule, dual averaging
+    (incl. its resets and finalize!), Welford pushes / updates / resets, renew of the metric and of the step size —
+    step sizes, mass matrices and draws after 60 adaptation + 10 sampling transitions, bit for bit"""
+    D, N, seed, n_samples, n_adapts = 3, 6, 5, 70, 60
+    windows = (8, 6, 5)
+    th0 = rng.normal(size=(D, N))
+    metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
+    lf = A.Leapfrog(np.full(N, 0.3))
+    if kind == "nuts":
+        kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=5)))
+        kernel_of = lambda e: R.NUTS(R.MultinomialTS, R.GENERALISED, e, max_depth=5)  # noqa: E731
+    else:
+        kernel = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(5)))
+        kernel_of = lambda e: ("hmc", e, 5)  # noqa: E731
+    adaptor = A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf), init_buffer=windows[0], term_buffer=windows[1],
+                               window_size=windows[2])
+    thetas, stats = A.sample(seed, A.Hamiltonian(metric, A.IsoGaussian(D)), kernel, th0, n_samples, adaptor, n_adapts, lib=oracle)
+    for c in range(N):
+        draws, st_ref, eps_ref, minv_ref = R.sample_chain_adapted(seed, c, R.iso_gaussian, [1.0] * D, 0.3, kernel_of, [float(x) for x in th0[:, c]],
+                                                                  n_samples, n_adapts, windows=windows)
+        for i in range(n_samples):
+            assert [float(x) for x in thetas[i][:, c]] == draws[i][0], (i, c)
+            assert float(stats[i]["step_size"][c]) == st_ref[i]["step_size"], (i, c)
+            assert float(stats[i]["acceptance_rate"][c]) == st_ref[i]["acceptance_rate"], (i, c)
+        assert float(stats[-1]["nom_step_size"][c]) == eps_ref and eps_ref != 0.3
+        assert minv_ref != [1.0] * D
