@@ -579,3 +579,48 @@ def sample_chain_adapted(seed, chain, fn, minv0, eps0, kernel_of, theta0, n_samp
         draws.append((list(z.theta), list(z.r)))
         stats.append(st)
     return draws, stats, eps, list(h.minv)
+
+
+# ------------------------------------------------------------------------------------------------
+# find_good_stepsize (src/trajectory.jl:753-837)
+# ------------------------------------------------------------------------------------------------
+RNG_FINDEPS = 3
+
+
+def find_good_stepsize(seed, chain, iteration, h, theta, initial_step_size=0.1, max_n_iters=100):
+    eps = epsp = float(initial_step_size)
+    loghalf = math.log(0.5)
+    log_a_min, log_a_cross, log_a_max = 2 * loghalf, loghalf, math.log(0.75)
+    d, invd = 2.0, 0.5
+    rng = Rng(seed, chain, iteration)
+    z0 = [rng.normal(RNG_FINDEPS, k) for k in range(h.D)]  # rand_momentum on the search's own stream
+    r = z0 if h.minv is None else [x / math.sqrt(m) for x, m in zip(z0, h.minv)]
+    z = phasepoint(h, list(theta), r)
+    H = energy(z)
+
+    def A(e):  # (:753-757)
+        return energy(step(e, h, z))
+
+    Hp = A(eps)
+    dH = H - Hp
+    ratio_too_high = dH > log_a_cross
+    for _ in range(max_n_iters):
+        epsp = d * eps if ratio_too_high else invd * eps
+        Hp = A(eps)  # (evaluated at ϵ, not ϵ′: :799-800)
+        dH = H - Hp
+        if ratio_too_high != (dH > log_a_cross):
+            break
+        eps = epsp
+    eps, epsp = (eps, epsp) if eps <= epsp else (epsp, eps)  # minmax
+    for _ in range(max_n_iters):
+        mid = eps / 2 + epsp / 2  # Statistics.middle
+        Hp = A(mid)
+        dH = H - Hp
+        if dH > log_a_max:
+            eps = mid
+        elif dH < log_a_min:
+            epsp = mid
+        else:
+            eps = mid
+            break
+    return eps

@@ -188,3 +188,22 @@ def test_sample_with_stan_adaptor_bit_for_bit(oracle, rng, kind):
             assert float(stats[i]["acceptance_rate"][c]) == st_ref[i]["acceptance_rate"], (i, c)
         assert float(stats[-1]["nom_step_size"][c]) == eps_ref and eps_ref != 0.3
         assert minv_ref != [1.0] * D
+
+
+@pytest.mark.parametrize("metric", ["unit", "diag"])
+@pytest.mark.parametrize("target", ["iso", "funnel"])
+def test_find_good_stepsize_bit_for_bit(oracle, rng, metric, target):
+    D, N, seed = 6, 20, 123
+    fn, builtin = TARGETS[target]
+    minv = None if metric == "unit" else (0.05 + 5 * rng.random((D, N)))
+    th0 = rng.normal(size=(D, N)) * 2
+    m = A.UnitEuclideanMetric(D) if minv is None else A.DiagEuclideanMetric(np.asfortranarray(minv))
+    eng = A.Engine(A.Hamiltonian(m, builtin(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(A.Leapfrog(0.1))
+    eng.set_position(th0)
+    eps = eng.find_good_stepsize()
+    for c in range(N):
+        h = R.Hamiltonian(None if minv is None else [float(x) for x in minv[:, c]], fn, D)
+        assert float(eps[c]) == R.find_good_stepsize(seed, c, 0, h, [float(x) for x in th0[:, c]]), c
+    assert len(set(float(e) for e in eps)) > 1
+    eng.close()
