@@ -185,18 +185,28 @@ def neg_energy(z):
 # ------------------------------------------------------------------------------------------------
 # step (src/integrator.jl:216-265), Leapfrog only
 # ------------------------------------------------------------------------------------------------
-def step(eps, h, z, n_steps=1, full_trajectory=False):
+def temper(alpha, r, i, is_half, n_steps):  # TemperedLeapfrog (src/integrator.jl:198-209); alpha None = the other integrators
+    if alpha is None:
+        return r
+    i_temper = 2 * (i - 1) + 1 + (0 if is_half else 1)
+    s = math.sqrt(alpha)
+    return [x * s for x in r] if i_temper <= n_steps else [x / s for x in r]
+
+
+def step(eps, h, z, n_steps=1, full_trajectory=False, alpha=None):
     fwd = n_steps > 0
     n_steps = abs(n_steps)
     e = eps if fwd else -eps
     res = []
     theta, r, value, gradient = z.theta, z.r, z.lp, z.g
-    for _ in range(n_steps):
+    for i in range(1, n_steps + 1):
+        r = temper(alpha, r, i, True, n_steps)
         r = [a - e / 2 * b for a, b in zip(r, gradient)]
         dr = h.dHdr(r)
         theta = [a + e * b for a, b in zip(theta, dr)]
         value, gradient = h.dHdtheta(theta)
         r = [a - e / 2 * b for a, b in zip(r, gradient)]
+        r = temper(alpha, r, i, False, n_steps)
         z = phasepoint(h, theta, r, value, gradient)
         res.append(z)
         if not z.isfinite(h):
@@ -323,13 +333,13 @@ def isterminated_tree(tc, h, t, tleft, tright):
 # build_tree (:626-675) and the dynamic transition (:677-742)
 # ------------------------------------------------------------------------------------------------
 class NUTS:
-    def __init__(self, TS, tc, eps, max_depth=10, delta_max=1000.0):
-        self.TS, self.tc, self.eps, self.max_depth, self.delta_max = TS, tc, eps, max_depth, delta_max
+    def __init__(self, TS, tc, eps, max_depth=10, delta_max=1000.0, temper_alpha=None):
+        self.TS, self.tc, self.eps, self.max_depth, self.delta_max, self.temper_alpha = TS, tc, eps, max_depth, delta_max, temper_alpha
 
 
 def build_tree(rng, nt, h, z, sampler, v, j, H0):
     if j == 0:
-        zp = step(nt.eps, h, z, v)
+        zp = step(nt.eps, h, z, v, alpha=nt.temper_alpha)
         Hp = energy(zp)
         dH = Hp - H0
         alpha = math.exp(jl_min(0.0, -dH))
@@ -382,9 +392,9 @@ def nuts_transition(rng, h, nt, z0):
 # ------------------------------------------------------------------------------------------------
 # static transition, EndPointTS (src/trajectory.jl:271-340, mh_accept_ratio :855-880)
 # ------------------------------------------------------------------------------------------------
-def hmc_transition(rng, h, eps, L, z):
+def hmc_transition(rng, h, eps, L, z, temper_alpha=None):
     H0 = energy(z)
-    zp = step(eps, h, z, L)
+    zp = step(eps, h, z, L, alpha=temper_alpha)
     Hp = energy(zp)
     is_accept = Hp < H0 + (-math.log(rng.uniform(RNG_TRANSITION, 0)))  # :858: one 53-bit draw (static transitions keep 53 bits)
     alpha = jl_min(1.0, math.exp(H0 - Hp))
@@ -399,8 +409,17 @@ def hmc_transition(rng, h, eps, L, z):
 # ------------------------------------------------------------------------------------------------
 # transition(rng, h, κ, z) (src/sampler.jl:48-58): refresh, then the trajectory's transition
 # ------------------------------------------------------------------------------------------------
-def refresh(rng, h, z):  # FullMomentumRefreshment (src/hamiltonian.jl:213-220)
-    return phasepoint(h, z.theta, h.rand_momentum(rng))
+def refresh(rng, h, z, alpha=0.0):
+    """FullMomentumRefreshment (src/hamiltonian.jl:213-220); alpha != 0: PartialMomentumRefreshment(α) (:243-254)"""
+    xi = h.rand_momentum(rng)
+    if alpha == 0.0:
+        return phasepoint(h, z.theta, xi)
+    s = math.sqrt(1 - alpha * alpha)
+    return phasepoint(h, z.theta, [alpha * a + s * b for a, b in zip(z.r, xi)])
+
+
+def jitter(rng, eps0, jit):  # JitteredLeapfrog (src/integrator.jl:140-143): one uniform per transition, on its own stream
+    return eps0 * (1 + jit * (2 * rng.uniform(RNG_JITTER, 0) - 1))
 
 
 def sample_chain(seed, chain, h, kernel, theta0, n_transitions, iteration0=0):

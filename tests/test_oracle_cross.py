@@ -207,3 +207,61 @@ def test_find_good_stepsize_bit_for_bit(oracle, rng, metric, target):
         assert float(eps[c]) == R.find_good_stepsize(seed, c, 0, h, [float(x) for x in th0[:, c]]), c
     assert len(set(float(e) for e in eps)) > 1
     eng.close()
+
+
+def test_jitter_partial_refreshment_and_tempering_bit_for_bit(oracle, rng):
+    """transition(rng, h, κ, z) (src/sampler.jl:48-58) with a JitteredLeapfrog + PartialMomentumRefreshment (NUTS), and a
+    TemperedLeapfrog (static EndPointTS and NUTS)"""
+    D, N, seed, n_trans = 4, 8, 17, 4
+    th0 = rng.normal(size=(D, N))
+    minv = 0.5 + rng.random((D, N))
+    m = A.DiagEuclideanMetric(np.asfortranarray(minv))
+    # (1) jitter + partial refreshment, NUTS
+    lf = A.JitteredLeapfrog(0.3, 0.4)
+    eng = A.Engine(A.Hamiltonian(m, A.Funnel(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(lf)
+    eng.set_position(th0)
+    kernel = A.HMCKernel(A.PartialMomentumRefreshment(0.7), A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=5)))
+    zs = []
+    for c in range(N):
+        h = R.Hamiltonian([float(x) for x in minv[:, c]], R.funnel, D)
+        zs.append(R.phasepoint(h, [float(x) for x in th0[:, c]], [0.0] * D))
+    for it in range(n_trans):
+        eng.run(kernel, 1)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            h = R.Hamiltonian([float(x) for x in minv[:, c]], R.funnel, D)
+            r = R.Rng(seed, c, it)
+            e = R.jitter(r, 0.3, 0.4)
+            zs[c], sr = R.nuts_transition(r, h, R.NUTS(R.MultinomialTS, R.GENERALISED, e, max_depth=5), R.refresh(r, h, zs[c], 0.7))
+            assert float(st["step_size"][c]) == e and e != 0.3
+            assert [float(x) for x in z.theta[:, c]] == zs[c].theta and [float(x) for x in z.r[:, c]] == zs[c].r, (it, c)
+            assert int(st["n_steps"][c]) == sr["n_steps"] and float(st["acceptance_rate"][c]) == sr["acceptance_rate"]
+    eng.close()
+    # (2) tempering: static EndPointTS, then NUTS
+    eps = 0.25 * (0.5 + rng.random(N))
+    lf = A.TemperedLeapfrog(eps, 1.1)
+    eng = A.Engine(A.Hamiltonian(m, A.IsoGaussian(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(lf)
+    eng.set_position(th0)
+    k_hmc = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(5)))
+    k_nuts = A.HMCKernel(A.Trajectory(A.SliceTS, lf, A.StrictGeneralisedNoUTurn(max_depth=5)))
+    zs = []
+    for c in range(N):
+        h = R.Hamiltonian([float(x) for x in minv[:, c]], R.iso_gaussian, D)
+        zs.append(R.phasepoint(h, [float(x) for x in th0[:, c]], [0.0] * D))
+    for it in range(n_trans):
+        nuts = it % 2 == 1
+        eng.transition(k_nuts if nuts else k_hmc)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            h = R.Hamiltonian([float(x) for x in minv[:, c]], R.iso_gaussian, D)
+            r = R.Rng(seed, c, it)
+            z0 = R.refresh(r, h, zs[c])
+            if nuts:
+                zs[c], sr = R.nuts_transition(r, h, R.NUTS(R.SliceTS, R.STRICT, float(eps[c]), max_depth=5, temper_alpha=1.1), z0)
+            else:
+                zs[c], sr = R.hmc_transition(r, h, float(eps[c]), 5, z0, temper_alpha=1.1)
+            assert [float(x) for x in z.theta[:, c]] == zs[c].theta and [float(x) for x in z.r[:, c]] == zs[c].r, (it, c)
+            assert float(st["hamiltonian_energy"][c]) == sr["hamiltonian_energy"]
+    eng.close()
