@@ -100,22 +100,48 @@ def dot(a, b):
 # ------------------------------------------------------------------------------------------------
 # Hamiltonian: metric (src/metric.jl, src/hamiltonian.jl:50-59,155-177) + target
 # ------------------------------------------------------------------------------------------------
+def cholesky_upper(M):
+    """U upper triangular with UᵀU = M (cholesky(Symmetric(M⁻¹)).U, src/metric.jl:104-109), column by column"""
+    D = len(M)
+    U = [[0.0] * D for _ in range(D)]
+    for j in range(D):
+        for i in range(j + 1):
+            s = M[i][j]
+            for k in range(i):
+                s -= U[k][i] * U[k][j]
+            U[i][j] = math.sqrt(s) if i == j else s / U[i][i]
+    return U
+
+
 class Hamiltonian:
     def __init__(self, minv, logdensity_and_gradient, D=None):
-        self.minv = minv  # None = UnitEuclideanMetric, list = DiagEuclideanMetric's M⁻¹
+        # None = UnitEuclideanMetric; list of floats = DiagEuclideanMetric's M⁻¹; list of rows = DenseEuclideanMetric's M⁻¹
+        self.minv = minv
         self.fn = logdensity_and_gradient
         self.D = len(minv) if minv is not None else D
+        self.dense = minv is not None and isinstance(minv[0], list)
+        self.chol = cholesky_upper(minv) if self.dense else None
 
-    def dHdr(self, r):  # ∂H∂r (:50-59)
+    def dHdr(self, r):  # ∂H∂r (:50-68)
         if self.minv is None:
             return list(r)
+        if self.dense:  # M⁻¹ * r
+            out = []
+            for row in self.minv:
+                s = 0.0
+                for m, x in zip(row, r):
+                    s += m * x
+                out.append(s)
+            return out
         return [m * x for m, x in zip(self.minv, r)]
 
-    def neg_energy_r(self, r):  # neg_energy(h, r, θ) (:155-177)
+    def neg_energy_r(self, r):  # neg_energy(h, r, θ) (:155-184)
         s = 0.0
         if self.minv is None:
             for x in r:
                 s += x * x
+        elif self.dense:  # mul!(_temp, M⁻¹, r); -dot(r, _temp) / 2
+            s = dot(r, self.dHdr(r))
         else:
             for m, x in zip(self.minv, r):
                 s += (x * x) * m
@@ -128,6 +154,13 @@ class Hamiltonian:
     def rand_momentum(self, rng):  # src/metric.jl:290-309
         z = [rng.normal(RNG_MOMENTUM, d) for d in range(self.D)]
         if self.minv is None:
+            return z
+        if self.dense:  # ldiv!(cholM⁻¹, r) (:311-320): back substitution with the upper factor
+            for i in range(self.D - 1, -1, -1):
+                s = z[i]
+                for j in range(i + 1, self.D):
+                    s -= self.chol[i][j] * z[j]
+                z[i] = s / self.chol[i][i]
             return z
         return [x / math.sqrt(m) for x, m in zip(z, self.minv)]
 
@@ -613,6 +646,8 @@ def find_good_stepsize(seed, chain, iteration, h, theta, initial_step_size=0.1, 
     d, invd = 2.0, 0.5
     rng = Rng(seed, chain, iteration)
     z0 = [rng.normal(RNG_FINDEPS, k) for k in range(h.D)]  # rand_momentum on the search's own stream
+    if h.dense:
+        raise NotImplementedError
     r = z0 if h.minv is None else [x / math.sqrt(m) for x, m in zip(z0, h.minv)]
     z = phasepoint(h, list(theta), r)
     H = energy(z)

@@ -265,3 +265,36 @@ def test_jitter_partial_refreshment_and_tempering_bit_for_bit(oracle, rng):
             assert [float(x) for x in z.theta[:, c]] == zs[c].theta and [float(x) for x in z.r[:, c]] == zs[c].r, (it, c)
             assert float(st["hamiltonian_energy"][c]) == sr["hamiltonian_energy"]
     eng.close()
+
+
+@pytest.mark.parametrize("ts,tc", [("multinomial", "generalised"), ("slice", "strict"), ("multinomial", "classic")])
+def test_dense_metric_nuts_bit_for_bit(oracle, rng, ts, tc):
+    """DenseEuclideanMetric (src/metric.jl:89-120,311-320; src/hamiltonian.jl:60-68,179-184): Cholesky factor,
+    rand_momentum = U \\ z, ∂H∂r = M⁻¹r, neg_energy — the side of the oracle the MFMA engine is checked against"""
+    D, N, n_trans, seed = 5, 8, 3, 2024
+    B = rng.normal(size=(D, D))
+    Minv = B @ B.T / D + np.eye(D)
+    Minv = (Minv + Minv.T) / 2
+    eps = 0.3 * (0.5 + rng.random(N))
+    th0 = rng.normal(size=(D, N))
+    lf = A.Leapfrog(eps)
+    eng = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), A.Funnel(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(lf)
+    eng.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(TS[ts][1], lf, TC[tc][1](max_depth=5)))
+    rows = [[float(x) for x in Minv[i]] for i in range(D)]
+    ref = []
+    for c in range(N):
+        h = R.Hamiltonian(rows, R.funnel, D)
+        ref.append(R.sample_chain(seed, c, h, R.NUTS(TS[ts][0], TC[tc][0], float(eps[c]), max_depth=5), [float(x) for x in th0[:, c]], n_trans))
+    for it in range(n_trans):
+        eng.transition(kernel)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            (th_ref, r_ref), st_ref = ref[c][0][it], ref[c][1][it]
+            assert [float(x) for x in z.theta[:, c]] == th_ref and [float(x) for x in z.r[:, c]] == r_ref, (it, c)
+            for k in FLOAT_STATS:
+                assert float(st[k][c]) == st_ref[k], (k, it, c)
+            for k in INT_STATS:
+                assert int(st[k][c]) == int(st_ref[k]), (k, it, c)
+    eng.close()
