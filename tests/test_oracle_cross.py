@@ -298,3 +298,31 @@ def test_dense_metric_nuts_bit_for_bit(oracle, rng, ts, tc):
             for k in INT_STATS:
                 assert int(st[k][c]) == int(st_ref[k]), (k, it, c)
     eng.close()
+
+
+def test_baseline_cfg1_plumbing_case(oracle):
+    """BASELINE.json configs[0]: D = 10 isotropic Gaussian, UnitEuclideanMetric, static
+    HMC(Leapfrog(0.1), FixedNSteps(16)), EndPointTS, 1 024 chains, θ0 ~ U(0,1), seed 0x5EED0001 — the reference's own
+    CPU-runnable case.  The oracle's run: the first chains bit for bit against the second restatement, the whole batch
+    against the moments the reference's test asserts (test/sampler-vec.jl:36-43: mean ≈ 0 within RNDATOL per chain)."""
+    D, N, L, seed, n = 10, 1024, 16, 0x5EED0001, 300
+    th0 = np.random.default_rng(seed).random((D, N))
+    lf = A.Leapfrog(0.1)
+    eng = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.IsoGaussian(D)), N, rng=seed, lib=oracle)
+    eng.set_integrator(lf)
+    eng.set_position(th0)
+    kernel = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(L)))
+    eng.run(kernel, 5)
+    z = eng.phasepoint()
+    for c in range(6):
+        h = R.Hamiltonian(None, R.iso_gaussian, D)
+        draws, _ = R.sample_chain(seed, c, h, ("hmc", 0.1, L), [float(x) for x in th0[:, c]], 5)
+        assert [float(x) for x in z.theta[:, c]] == draws[-1][0], c
+    eng.run(kernel, n)  # accumulators are reset at the first kept transition of the call
+    acc = eng.accum()
+    assert acc["total_n_steps"] == n * N * L and acc["n_divergent"] == 0
+    mean = acc["sum_theta"] / n
+    var = acc["sumsq_theta"] / n - mean ** 2
+    assert abs(mean.mean()) < 0.02 and abs(var.mean() + (mean ** 2).mean() - 1) < 0.05  # pooled over 3e5 draws per dimension
+    assert eng.stats()["acceptance_rate"].mean() > 0.9  # ϵ = 0.1 on a unit Gaussian
+    eng.close()

@@ -372,3 +372,28 @@ def test_hip_batch_of_static_transitions(hip, oracle, rng, TS):
     assert e_ext.info("iteration") == 3
     assert_close_state(e_ext, e_ref, min_match=0.98)
     e_ext.close(); e_ref.close()
+
+
+def test_baseline_cfg1_on_the_gpu(hip, oracle):
+    """BASELINE.json configs[0] (D = 10, Unit metric, static HMC with 16 leapfrogs, 1 024 chains) run by the fused
+    k_hmc kernel against the oracle on the same streams (the kernel is the measured build's; only this test is new)"""
+    D, N, L, seed = 10, 1024, 16, 0x5EED0001
+    th0 = np.random.default_rng(seed).random((D, N))
+    lf = A.Leapfrog(0.1)
+    h = A.Hamiltonian(A.UnitEuclideanMetric(D), A.IsoGaussian(D))
+    kernel = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(L)))
+    e_g, e_o = A.Engine(h, N, rng=seed, lib=hip), A.Engine(h, N, rng=seed, lib=oracle)
+    for e in (e_g, e_o):
+        e.set_integrator(lf)
+        e.set_position(th0)
+    for _ in range(5):
+        e_g.transition(kernel)
+        e_o.transition(kernel)
+        sa, sb = e_g.stats(), e_o.stats()
+        same = sa["is_accept"] == sb["is_accept"]
+        assert same.mean() >= 0.999
+        np.testing.assert_allclose(e_g.phasepoint().theta[:, same], e_o.phasepoint().theta[:, same], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(sa["hamiltonian_energy"][same], sb["hamiltonian_energy"][same], rtol=1e-9, atol=1e-9)
+        if not same.all():
+            e_g.set_position(e_o.phasepoint().theta, e_o.phasepoint().r)
+    e_g.close(); e_o.close()
