@@ -274,7 +274,8 @@ unsigned group_grid(Ctx<T>* c) {  // blocks of 256 threads covering N groups of 
 template <class T>
 int check_builtin(Ctx<T>* c, const char* what) {
   if (c->target_kind == AHMC_TARGET_EXTERNAL)
-    return fail(c, AHMC_ERR_STATE, std::string(what) + " needs a built-in target; with AHMC_TARGET_EXTERNAL use ahmc_lf_pre/ahmc_lf_post");
+    return fail(c, AHMC_ERR_STATE, std::string(what) + " needs a built-in target; with AHMC_TARGET_EXTERNAL the caller evaluates the log-density: "
+                                   "ahmc_ext_* (whole transitions, find_good_stepsize) or ahmc_lf_pre / ahmc_lf_post (single leapfrogs)");
   if (dense_engine(c))
     return fail(c, AHMC_ERR_UNSUPPORTED, std::string(what) + " is not implemented for DenseEuclideanMetric / AHMC_TARGET_DENSE_GAUSS");
   return AHMC_OK;
