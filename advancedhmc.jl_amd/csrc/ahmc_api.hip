@@ -569,6 +569,23 @@ int64_t nuts_batch(Ctx<T>* c) {
   return std::max<int64_t>(1, std::min<int64_t>(32, cap));
 }
 
+// nsteps(τ) for FixedIntegrationTime(λ) (src/trajectory.jl:241-243): max(1, floor(λ / nominal step size)).  Needs ONE
+// step size: a scalar one, or the single chain's own (which adaptation keeps on the device)
+template <class T>
+int resolve_integration_time(Ctx<T>* c, double lambda, int64_t& L) {
+  double eps = (double)(T)c->eps_scalar_value;
+  if (!c->eps_scalar) {
+    if (c->N != 1) return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
+    T e1;
+    HIPCHK(hipMemcpyAsync(&e1, c->eps_nom, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    eps = (double)e1;
+  }
+  const int64_t n = (int64_t)std::floor(lambda / eps);
+  L = n < 1 ? 1 : n;
+  return AHMC_OK;
+}
+
 template <class T>
 int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refresh_alpha, bool accum) {
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
@@ -577,9 +594,8 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refr
   if (sampler != AHMC_TS_ENDPOINT && sampler != AHMC_TS_MULTINOMIAL)
     return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
   if (lambda > 0) {  // nsteps(τ) for FixedIntegrationTime (src/trajectory.jl:241-243)
-    if (!c->eps_scalar) return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
-    int64_t n = (int64_t)std::floor(lambda / (double)(T)c->eps_scalar_value);
-    L = n < 1 ? 1 : n;
+    int rc2 = resolve_integration_time(c, lambda, L);
+    if (rc2) return rc2;
   }
   if (L < 0) L = -L;
   if (dense_engine(c)) return dn_hmc_transition(c, L, sampler, refresh_alpha, accum);

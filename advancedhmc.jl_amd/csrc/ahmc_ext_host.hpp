@@ -132,9 +132,8 @@ int ext_begin(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int n_trans) {
     return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
   int64_t L = cfg->L;
   if (cfg->lambda > 0) {  // nsteps(τ) for FixedIntegrationTime (src/trajectory.jl:241-243)
-    if (!c->eps_scalar) return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
-    const int64_t n = (int64_t)std::floor(cfg->lambda / (double)(T)c->eps_scalar_value);
-    L = n < 1 ? 1 : n;
+    rc = resolve_integration_time(c, cfg->lambda, L);
+    if (rc) return rc;
   }
   if (L < 0) L = -L;
   if (L < 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: static HMC needs at least one leapfrog step");

@@ -1059,7 +1059,7 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, T refresh_a
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
   if (sampler != AHMC_TS_ENDPOINT && sampler != AHMC_TS_MULTINOMIAL)
     return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
-  if (lambda > 0 && !c->eps_scalar)
+  if (lambda > 0 && !c->eps_scalar && c->N != 1)  // (one chain: its step size IS the scalar)
     return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
   L = resolve_L(c, L, lambda);
   if (L < 0) L = -L;
@@ -1781,7 +1781,7 @@ int32_t ahmc_ext_begin(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int32_t n_tran
     } else {
       if (cfg->sampler != AHMC_TS_ENDPOINT && cfg->sampler != AHMC_TS_MULTINOMIAL)
         return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
-      if (cfg->lambda > 0 && !c->eps_scalar)
+      if (cfg->lambda > 0 && !c->eps_scalar && c->N != 1)
         return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
     }
     c->ext.cfg = *cfg;

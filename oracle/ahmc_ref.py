@@ -564,6 +564,45 @@ class WelfordVar:  # massmatrix.jl:86-157
         self.M = [0.0] * len(self.M)
 
 
+class NutpieVar:  # massmatrix.jl:172-250: Welford estimators of the positions and of the gradients
+    def __init__(self, D, n_min=10):
+        self.pos, self.grad, self.n, self.n_min, self.var = WelfordVar(D, n_min), WelfordVar(D, n_min), 0, n_min, [1.0] * D
+
+    def push_point(self, theta, gradient):  # push!(nv, z::PhasePoint) (:238-243); gradient = z.ℓπ.gradient
+        self.n += 1
+        self.pos.push(theta)
+        self.grad.push(gradient)
+
+    def update(self):
+        if self.n >= self.n_min:  # get_estimation (:246-250)
+            self.var = [math.sqrt(a / b) for a, b in zip(self.pos.get_estimation(), self.grad.get_estimation())]
+
+    def reset(self):  # (:228-232)
+        self.n = 0
+        self.pos.reset()
+        self.grad.reset()
+
+
+class NaiveHMCAdaptor:  # Adaptation.jl:41-64: both adaptors at every iteration, no windows
+    def __init__(self, pc, ssa):
+        self.pc, self.ssa = pc, ssa
+
+    def initialize(self, n_adapts):
+        pass
+
+    def adapt(self, z, alpha):
+        self.ssa.adapt(alpha)
+        push_position_or_point(self.pc, z)
+        self.pc.update()
+
+
+def push_position_or_point(pc, z):
+    if isinstance(pc, NutpieVar):
+        pc.push_point(z.theta, z.g)
+    else:
+        pc.push(z.theta)
+
+
 def stan_windows(init_buffer, term_buffer, window_size, n_adapts):  # initialize! (stan_adaptor.jl:13-50)
     window_start, window_end = init_buffer + 1, n_adapts - term_buffer
     splits = []
@@ -587,11 +626,11 @@ class StanHMCAdaptor:  # stan_adaptor.jl:94-159
     def initialize(self, n_adapts):
         self.window_start, self.window_end, self.splits = stan_windows(self.ib, self.tb, self.ws, n_adapts)
 
-    def adapt(self, theta, alpha):  # (:137-159)
+    def adapt(self, z, alpha):  # (:137-159)
         self.i += 1
         self.ssa.adapt(alpha)
         if self.window_start <= self.i <= self.window_end:
-            self.pc.push(theta)
+            push_position_or_point(self.pc, z)
             if self.i in self.splits:
                 self.pc.update()
         if self.i in self.splits:
@@ -599,20 +638,24 @@ class StanHMCAdaptor:  # stan_adaptor.jl:94-159
             self.pc.reset()
 
 
-def sample_chain_adapted(seed, chain, fn, minv0, eps0, kernel_of, theta0, n_samples, n_adapts, delta=0.8, windows=(75, 50, 25)):
+def sample_chain_adapted(seed, chain, fn, minv0, eps0, kernel_of, theta0, n_samples, n_adapts, delta=0.8, windows=(75, 50, 25),
+                         estimator=WelfordVar, naive=False):
     """sample(rng, h, κ, θ, n_samples, StanHMCAdaptor(WelfordVar, NesterovDualAveraging(δ, ϵ)), n_adapts)
     (src/sampler.jl:159-248) for one chain with a DiagEuclideanMetric; kernel_of(eps) -> NUTS(...) or ("hmc", eps, L) /
     ("hmc_mn", eps, L).  Returns (draws, stats, final eps, final M⁻¹)."""
     D = len(theta0)
     h = Hamiltonian(list(minv0), fn, D)
     eps = eps0
-    adaptor = StanHMCAdaptor(WelfordVar(D), DualAveraging(delta, eps0), *windows)
+    adaptor = (NaiveHMCAdaptor(estimator(D), DualAveraging(delta, eps0)) if naive
+               else StanHMCAdaptor(estimator(D), DualAveraging(delta, eps0), *windows))
     z = phasepoint(h, list(theta0), [0.0] * D)
     draws, stats = [], []
     for i in range(1, n_samples + 1):
         rng = Rng(seed, chain, i - 1)
         z = refresh(rng, h, z)
         kernel = kernel_of(eps)
+        if not isinstance(kernel, NUTS) and kernel[0] == "hmcda":  # FixedIntegrationTime(λ): nsteps (src/trajectory.jl:241-243)
+            kernel = ("hmc", eps, max(1, int(math.floor(kernel[2] / eps))))
         if isinstance(kernel, NUTS):
             z, st = nuts_transition(rng, h, kernel, z)
         elif kernel[0] == "hmc":
@@ -623,7 +666,7 @@ def sample_chain_adapted(seed, chain, fn, minv0, eps0, kernel_of, theta0, n_samp
         if i <= n_adapts:  # adapt!(h, κ, adaptor, i, n_adapts, z, α) (src/sampler.jl:72-90)
             if i == 1:
                 adaptor.initialize(n_adapts)
-            adaptor.adapt(z.theta, st["acceptance_rate"])
+            adaptor.adapt(z, st["acceptance_rate"])
             if i == n_adapts:
                 adaptor.ssa.finalize()
             h = Hamiltonian(list(adaptor.pc.var), fn, D)  # update(h, adaptor): renew(metric, getM⁻¹)

@@ -326,3 +326,40 @@ def test_baseline_cfg1_plumbing_case(oracle):
     assert abs(mean.mean()) < 0.02 and abs(var.mean() + (mean ** 2).mean() - 1) < 0.05  # pooled over 3e5 draws per dimension
     assert eng.stats()["acceptance_rate"].mean() > 0.9  # ϵ = 0.1 on a unit Gaussian
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["stan_nutpie", "naive_welford", "naive_nutpie_hmcda"])
+def test_other_adaptors_bit_for_bit(oracle, rng, case):
+    """NutpieVar behind the Stan adaptor, NaiveHMCAdaptor (both estimators), and HMCDA's FixedIntegrationTime (the
+    number of leapfrogs follows the adapted NOMINAL step size, src/trajectory.jl:241-243)"""
+    D, N, seed, n_samples, n_adapts = 3, 5, 8, 45, 40
+    windows = (6, 5, 4)
+    th0 = rng.normal(size=(D, N))
+    metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
+    nutpie = "nutpie" in case
+    pc = A.NutpieVar(metric) if nutpie else A.MassMatrixAdaptor(metric)
+    if case == "naive_nutpie_hmcda":
+        lf = A.Leapfrog(0.25)  # FixedIntegrationTime needs ONE step size (src/trajectory.jl:241-243), so a single chain is run
+        N = 1
+        th0 = th0[:, :1]
+        metric = A.DiagEuclideanMetric(np.ones((D, 1), order="F"))
+        pc = A.NutpieVar(metric)
+        kernel = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedIntegrationTime(1.5)))
+        kernel_of = lambda e: ("hmcda", e, 1.5)  # noqa: E731
+        eps0 = 0.25
+    else:
+        lf = A.Leapfrog(np.full(N, 0.3))
+        kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=5)))
+        kernel_of = lambda e: R.NUTS(R.MultinomialTS, R.GENERALISED, e, max_depth=5)  # noqa: E731
+        eps0 = 0.3
+    ssa = A.StepSizeAdaptor(0.8, lf)
+    naive = case.startswith("naive")
+    adaptor = A.NaiveHMCAdaptor(pc, ssa) if naive else A.StanHMCAdaptor(pc, ssa, init_buffer=windows[0], term_buffer=windows[1], window_size=windows[2])
+    thetas, stats = A.sample(seed, A.Hamiltonian(metric, A.Funnel(D)), kernel, th0, n_samples, adaptor, n_adapts, lib=oracle)
+    for c in range(N):
+        draws, st_ref, eps_ref, minv_ref = R.sample_chain_adapted(seed, c, R.funnel, [1.0] * D, eps0, kernel_of, [float(x) for x in th0[:, c]], n_samples,
+                                                                  n_adapts, windows=windows, estimator=R.NutpieVar if nutpie else R.WelfordVar, naive=naive)
+        for i in range(n_samples):
+            assert [float(x) for x in np.atleast_2d(thetas[i].T).T[:, c]] == draws[i][0], (i, c)
+            assert int(np.atleast_1d(stats[i]["n_steps"])[c]) == st_ref[i]["n_steps"], (i, c)
+        assert float(np.atleast_1d(stats[-1]["nom_step_size"])[c]) == eps_ref and minv_ref != [1.0] * D
