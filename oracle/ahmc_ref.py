@@ -583,6 +583,33 @@ class NutpieVar:  # massmatrix.jl:172-250: Welford estimators of the positions a
         self.grad.reset()
 
 
+class WelfordCov:  # massmatrix.jl:283-340
+    def __init__(self, D, n_min=10):
+        self.n, self.n_min, self.mu = 0, n_min, [0.0] * D
+        self.M = [[0.0] * D for _ in range(D)]
+        self.var = [[1.0 if i == j else 0.0 for j in range(D)] for i in range(D)]  # (`cov`; named var like the Diag estimators)
+
+    def push(self, s):  # (:323-331)
+        self.n += 1
+        n = float(self.n)
+        delta = [a - b for a, b in zip(s, self.mu)]
+        self.mu = [a + d / n for a, d in zip(self.mu, delta)]
+        D = len(s)
+        for i in range(D):
+            for j in range(D):
+                self.M[i][j] = self.M[i][j] + (s[i] - self.mu[i]) * delta[j]
+
+    def update(self):  # update!(ce) + get_estimation (:272-281, :334-340)
+        if self.n >= self.n_min:
+            n = float(self.n)
+            D = len(self.mu)
+            self.var = [[n / ((n + 5) * (n - 1)) * self.M[i][j] + (1e-3 * (5 / (n + 5)) if i == j else 0.0) for j in range(D)] for i in range(D)]
+
+    def reset(self):
+        D = len(self.mu)
+        self.n, self.mu, self.M = 0, [0.0] * D, [[0.0] * D for _ in range(D)]
+
+
 class NaiveHMCAdaptor:  # Adaptation.jl:41-64: both adaptors at every iteration, no windows
     def __init__(self, pc, ssa):
         self.pc, self.ssa = pc, ssa
@@ -644,7 +671,7 @@ def sample_chain_adapted(seed, chain, fn, minv0, eps0, kernel_of, theta0, n_samp
     (src/sampler.jl:159-248) for one chain with a DiagEuclideanMetric; kernel_of(eps) -> NUTS(...) or ("hmc", eps, L) /
     ("hmc_mn", eps, L).  Returns (draws, stats, final eps, final M⁻¹)."""
     D = len(theta0)
-    h = Hamiltonian(list(minv0), fn, D)
+    h = Hamiltonian([list(row) for row in minv0] if isinstance(minv0[0], list) else list(minv0), fn, D)
     eps = eps0
     adaptor = (NaiveHMCAdaptor(estimator(D), DualAveraging(delta, eps0)) if naive
                else StanHMCAdaptor(estimator(D), DualAveraging(delta, eps0), *windows))
@@ -669,11 +696,12 @@ def sample_chain_adapted(seed, chain, fn, minv0, eps0, kernel_of, theta0, n_samp
             adaptor.adapt(z, st["acceptance_rate"])
             if i == n_adapts:
                 adaptor.ssa.finalize()
-            h = Hamiltonian(list(adaptor.pc.var), fn, D)  # update(h, adaptor): renew(metric, getM⁻¹)
+            v = adaptor.pc.var
+            h = Hamiltonian([list(row) for row in v] if isinstance(v[0], list) else list(v), fn, D)  # update(h, adaptor): renew(metric, getM⁻¹)
             eps = adaptor.ssa.eps                          # update(κ, adaptor): nominal step size ← getϵ
         draws.append((list(z.theta), list(z.r)))
         stats.append(st)
-    return draws, stats, eps, list(h.minv)
+    return draws, stats, eps, h.minv
 
 
 # ------------------------------------------------------------------------------------------------

@@ -363,3 +363,23 @@ def test_other_adaptors_bit_for_bit(oracle, rng, case):
             assert [float(x) for x in np.atleast_2d(thetas[i].T).T[:, c]] == draws[i][0], (i, c)
             assert int(np.atleast_1d(stats[i]["n_steps"])[c]) == st_ref[i]["n_steps"], (i, c)
         assert float(np.atleast_1d(stats[-1]["nom_step_size"])[c]) == eps_ref and minv_ref != [1.0] * D
+
+
+def test_dense_metric_with_welford_cov_adaptation_bit_for_bit(oracle, rng):
+    """one chain with a DenseEuclideanMetric and StanHMCAdaptor → WelfordCov (massmatrix.jl:283-340), the reference's
+    single-chain case: pushes, window-end estimate, the renewed metric's Cholesky factor, draws"""
+    D, seed, n_samples, n_adapts = 3, 21, 50, 44
+    windows = (6, 5, 4)
+    th0 = rng.normal(size=(D, 1))
+    metric = A.DenseEuclideanMetric(np.eye(D))
+    lf = A.Leapfrog(0.3)
+    kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=5)))
+    adaptor = A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf), init_buffer=windows[0], term_buffer=windows[1], window_size=windows[2])
+    thetas, stats = A.sample(seed, A.Hamiltonian(metric, A.Funnel(D)), kernel, th0, n_samples, adaptor, n_adapts, lib=oracle)
+    eye = [[1.0 if i == j else 0.0 for j in range(D)] for i in range(D)]
+    draws, st_ref, eps_ref, minv_ref = R.sample_chain_adapted(seed, 0, R.funnel, eye, 0.3, lambda e: R.NUTS(R.MultinomialTS, R.GENERALISED, e, max_depth=5),
+                                                              [float(x) for x in th0[:, 0]], n_samples, n_adapts, windows=windows, estimator=R.WelfordCov)
+    for i in range(n_samples):
+        assert [float(x) for x in np.asarray(thetas[i]).reshape(D)] == draws[i][0], i
+    assert float(np.atleast_1d(stats[-1]["nom_step_size"])[0]) == eps_ref
+    assert minv_ref != eye and minv_ref[0][1] != 0.0
