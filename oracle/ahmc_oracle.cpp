@@ -38,6 +38,7 @@
 #include <string>
 #include <vector>
 
+#include <sys/mman.h>   // lazily committed coroutine stacks
 #include <ucontext.h>  // coroutines of the external-target ask / tell protocol (ahmc_ext_*)
 
 #ifdef _OPENMP
@@ -809,9 +810,16 @@ struct Ctx : CtxBase {
   // supplied (ℓπ, -∇ℓπ) for the position it published.  One chain runs at a time (no OpenMP in this mode).
   struct ExtCo {
     ucontext_t uc;
-    std::vector<char> stack;
+    void* stack = nullptr;  // mmap'd, committed page by page as the coroutine touches it (N stacks would not fit otherwise)
+    size_t stack_bytes = 0;
     int state = 0;  // 0 runnable, 1 waiting for the caller's evaluation, 2 finished
     int k = 0;      // transition of the batch this chain is in
+    ExtCo() = default;
+    ExtCo(const ExtCo&) = delete;
+    ExtCo& operator=(const ExtCo&) = delete;
+    ~ExtCo() {
+      if (stack) munmap(stack, stack_bytes);
+    }
   };
   struct Ext {
     int mode = 0;  // 0 idle, 1 NUTS, 2 static HMC, 3 find_good_stepsize
@@ -821,7 +829,8 @@ struct Ctx : CtxBase {
     double fe_init = 0;
     int fe_iters = 0;
     ucontext_t main_uc;
-    std::vector<ExtCo> co;
+    std::unique_ptr<ExtCo[]> co;  // N coroutines; never moved once made (a ucontext_t points into itself)
+    int64_t n_co = 0;
     int64_t cur = -1;
     std::vector<T> theta;  // (D,N): the positions the waiting chains want evaluated
     const T* in_lp = nullptr;
@@ -1270,8 +1279,8 @@ void ext_resume(Ctx<T>* c, int64_t i) {
 template <class T>
 void ext_finish_if_done(Ctx<T>* c) {
   auto& x = c->ext;
-  for (auto& co : x.co)
-    if (co.state != 2) return;
+  for (int64_t i = 0; i < x.n_co; ++i)
+    if (x.co[i].state != 2) return;
   if (x.mode == 3) {
     c->iteration = x.iter0;
     c->eps_nom = x.fe_out;
@@ -1281,7 +1290,8 @@ void ext_finish_if_done(Ctx<T>* c) {
     c->iteration = x.iter0 + (uint64_t)x.n_trans;
   }
   x.mode = 0;
-  x.co.clear();
+  x.co.reset();
+  x.n_co = 0;
   c->target.ext_eval = nullptr;
   c->target.ext_self = nullptr;
 }
@@ -1297,15 +1307,24 @@ int ext_start(Ctx<T>* c, int mode) {
   x.in_g = nullptr;
   c->target.ext_eval = &ext_eval_thunk<T>;
   c->target.ext_self = c;
-  x.co.clear();
-  x.co.resize((size_t)c->N);
+  x.co.reset(new typename Ctx<T>::ExtCo[(size_t)c->N]);
+  x.n_co = c->N;
   const size_t stack_bytes = (size_t)1 << 19;  // build_tree recurses max_depth deep; its vectors live on the heap
   for (int64_t i = 0; i < c->N; ++i) {
     auto& co = x.co[(size_t)i];
-    co.stack.resize(stack_bytes);
+    void* st = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (st == MAP_FAILED) {
+      x.co.reset();
+      x.n_co = 0;
+      x.mode = 0;
+      c->target.ext_eval = nullptr;
+      return fail(c, AHMC_ERR_RUNTIME, "ext_begin: cannot map the coroutine stacks");
+    }
+    co.stack = st;
+    co.stack_bytes = stack_bytes;
     getcontext(&co.uc);
-    co.uc.uc_stack.ss_sp = co.stack.data();
-    co.uc.uc_stack.ss_size = co.stack.size();
+    co.uc.uc_stack.ss_sp = co.stack;
+    co.uc.uc_stack.ss_size = co.stack_bytes;
     co.uc.uc_link = &x.main_uc;
     makecontext(&co.uc, (void (*)())&ext_co_entry<T>, 0);
   }
@@ -1843,7 +1862,8 @@ int32_t ahmc_ext_cancel(ahmc_ctx* ctx) {
       // blocks leak (bounded by the tree state of N chains); a test-infrastructure shortcut
       c->iteration = c->ext.iter0;
       c->ext.mode = 0;
-      c->ext.co.clear();
+      c->ext.co.reset();
+      c->ext.n_co = 0;
       c->target.ext_eval = nullptr;
       c->target.ext_self = nullptr;
     }
