@@ -166,7 +166,7 @@ def test_dense_engine_static_multinomial(hip, oracle, rng, metric, target):
 
 @pytest.mark.parametrize("metric", ["unit", "diag_chain", "dense"])
 def test_hip_find_good_stepsize_with_user_density(hip, oracle, rng, metric):
-    D, N = 16, 96
+    D, N = 16, 128
     m = make_metric(metric, D, N, rng)
     e_ext, e_ref = engines(hip, oracle, "iso", m, N, A.Leapfrog(0.1))
     th0 = rng.normal(size=(D, N))
