@@ -383,3 +383,57 @@ def test_dense_metric_with_welford_cov_adaptation_bit_for_bit(oracle, rng):
         assert [float(x) for x in np.asarray(thetas[i]).reshape(D)] == draws[i][0], i
     assert float(np.atleast_1d(stats[-1]["nom_step_size"])[0]) == eps_ref
     assert minv_ref != eye and minv_ref[0][1] != 0.0
+
+
+def test_randomised_configurations_bit_for_bit(oracle):
+    """120 random configurations (D 1..7, max_depth 1..7, step sizes from tiny to divergent, every sampler /
+    criterion / metric / target, Δ_max from tight to loose): oracle == second restatement, bit for bit"""
+    master = np.random.default_rng(987654321)
+    n_div = n_deep = 0
+    for case in range(120):
+        D = int(master.integers(1, 8))
+        N = int(master.integers(1, 5))
+        max_depth = int(master.integers(1, 8))
+        ts = ["multinomial", "slice"][int(master.integers(0, 2))]
+        tc = ["classic", "generalised", "strict"][int(master.integers(0, 3))]
+        target = ["iso", "funnel"][int(master.integers(0, 2))] if D > 1 else "iso"
+        metric = ["unit", "diag", "dense"][int(master.integers(0, 3))]
+        delta_max = float([5.0, 50.0, 1000.0][int(master.integers(0, 3))])
+        eps = float(10 ** master.uniform(-2.5, 0.6)) * (0.5 + master.random(N))
+        seed = int(master.integers(0, 2 ** 62))
+        th0 = master.normal(size=(D, N)) * float(master.uniform(0.2, 3.0))
+        fn, builtin = TARGETS[target]
+        if metric == "unit":
+            m, minvs = A.UnitEuclideanMetric(D), [None] * N
+        elif metric == "diag":
+            mv = 0.1 + 3 * master.random((D, N))
+            m, minvs = A.DiagEuclideanMetric(np.asfortranarray(mv)), [[float(x) for x in mv[:, c]] for c in range(N)]
+        else:
+            B = master.normal(size=(D, D))
+            M = B @ B.T / D + 0.5 * np.eye(D)
+            M = (M + M.T) / 2
+            m, minvs = A.DenseEuclideanMetric(M), [[[float(x) for x in M[i]] for i in range(D)]] * N
+        lf = A.Leapfrog(eps)
+        eng = A.Engine(A.Hamiltonian(m, builtin(D)), N, rng=seed, lib=oracle)
+        eng.set_integrator(lf)
+        eng.set_position(th0)
+        kernel = A.HMCKernel(A.Trajectory(TS[ts][1], lf, TC[tc][1](max_depth=max_depth, delta_max=delta_max)))
+        for _ in range(2):
+            eng.transition(kernel)
+        st, z = eng.stats(), eng.phasepoint()
+        for c in range(N):
+            h = R.Hamiltonian(minvs[c], fn, D)
+            nt = R.NUTS(TS[ts][0], TC[tc][0], float(eps[c]), max_depth=max_depth, delta_max=delta_max)
+            draws, stats = R.sample_chain(seed, c, h, nt, [float(x) for x in th0[:, c]], 2)
+            tag = (case, c, D, max_depth, ts, tc, target, metric)
+            assert [float(x) for x in z.theta[:, c]] == draws[-1][0], tag
+            assert [float(x) for x in z.r[:, c]] == draws[-1][1], tag
+            for k in FLOAT_STATS:
+                a, b = float(st[k][c]), stats[-1][k]
+                assert a == b or (np.isnan(a) and np.isnan(b)), (k,) + tag
+            for k in INT_STATS:
+                assert int(st[k][c]) == int(stats[-1][k]), (k,) + tag
+            n_div += stats[-1]["numerical_error"]
+            n_deep += stats[-1]["tree_depth"] == max_depth
+        eng.close()
+    assert n_div > 5 and n_deep > 5
