@@ -201,3 +201,20 @@ def test_ess_and_bundle_samples(oracle):
     np.testing.assert_array_equal(b["value"][:, :3, :], np.stack(ths)[2:])
     j = b["names"].index("n_steps")
     assert np.all(b["value"][:, j, :] == 4)
+
+
+def test_header_is_plain_c_and_the_abi_is_usable_from_c(tmp_path, oracle):
+    """include/ahmc_hip.h compiles as C99 and as C++17, and a plain-C program (tests/c_abi/ask_tell_demo.c) samples a
+    user log-density through the ask / tell calls — linked here against the CPU checker's implementation of the ABI"""
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c"], ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++"]):
+        subprocess.run(cmd + [HEADER], check=True, capture_output=True)
+    exe = str(tmp_path / "ask_tell_demo")
+    odir = os.path.dirname(oracle.path)
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", inc, os.path.join(ROOT, "tests", "c_abi", "ask_tell_demo.c"), "-o", exe,
+                    "-L", odir, "-lahmc_oracle", "-lm", f"-Wl,-rpath,{odir}"], check=True, capture_output=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.startswith("ok ")
+    acc = float(res.stdout.split()[1])
+    assert 0.6 < acc < 0.95  # dual averaging towards δ = 0.8
