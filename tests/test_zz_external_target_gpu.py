@@ -397,3 +397,20 @@ def test_baseline_cfg1_on_the_gpu(hip, oracle):
         if not same.all():
             e_g.set_position(e_o.phasepoint().theta, e_o.phasepoint().r)
     e_g.close(); e_o.close()
+
+
+def test_plain_c_program_on_the_hip_engine(hip, tmp_path):
+    """tests/c_abi/ask_tell_demo.c (plain C99: user log-density through ask / tell, find_good_stepsize, step-size
+    adaptation) linked against libahmc_hip.so — no Python, no torch in that process"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sodir = os.path.dirname(A.hip_library_path())
+    exe = str(tmp_path / "ask_tell_demo")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "ask_tell_demo.c"), "-o", exe,
+                    "-L", sodir, "-lahmc_hip", "-lm", f"-Wl,-rpath,{sodir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"],
+                   check=True, capture_output=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=200)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.startswith("ok ")
