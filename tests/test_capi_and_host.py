@@ -218,3 +218,18 @@ def test_header_is_plain_c_and_the_abi_is_usable_from_c(tmp_path, oracle):
     assert res.stdout.startswith("ok ")
     acc = float(res.stdout.split()[1])
     assert 0.6 < acc < 0.95  # dual averaging towards δ = 0.8
+
+
+def test_hip_engine_fails_loudly_without_a_gpu():
+    """no device → ahmc_create returns a status and a message (nothing falls back to a CPU path, nothing aborts)"""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = A.CLib(A.hip_library_path())
+    ctx = C.c_void_p()
+    code = lib.dll.ahmc_create(0, A.capi.F64, 4, 8, None, C.byref(ctx))
+    assert code == A.capi.ERR_RUNTIME and not ctx.value
+    assert b"device" in lib.dll.ahmc_last_error(None)
+    with pytest.raises(A.AHMCError):
+        A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(4), A.IsoGaussian(4)), 8, lib=lib)
