@@ -13,4 +13,7 @@ echo "suite exit $?" >> $O/gpu_suite.log
 timeout 900 python -m pytest tests/test_zz_external_target_gpu.py -q -m gpu --runxfail --timeout 300 > $O/unrun.log 2>&1
 echo "unrun exit $?" >> $O/unrun.log
 timeout 600 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err
-tail -5 $O/gpu_suite.log; tail -40 $O/unrun.log; cat $O/bench.json
+# 4. what an ask / tell request costs (device closure, then host closure)
+timeout 300 python scripts/ext_bench.py --chains 16384 --transitions 4 > $O/ext_bench_device.json 2> $O/ext_bench_device.err
+timeout 300 python scripts/ext_bench.py --chains 16384 --transitions 4 --host > $O/ext_bench_host.json 2> $O/ext_bench_host.err
+tail -5 $O/gpu_suite.log; tail -40 $O/unrun.log; cat $O/bench.json $O/ext_bench_device.json $O/ext_bench_host.json
