@@ -340,3 +340,46 @@ def test_oracle_tempered_with_callback(oracle, rng, TS, TC):
         e_ref.transition(kernel)
         assert_same_state(e_ext, e_ref)
     e_ext.close(); e_ref.close()
+
+
+def test_randomised_configurations_callback_equals_builtin(oracle):
+    """80 random configurations (kernel kind, sampler, criterion, metric, integrator, refreshment, sizes, batch
+    length): the run through ahmc_ext_* with the density as a callback == the run with it built in, bit for bit"""
+    master = np.random.default_rng(20260926)
+    for case in range(80):
+        D = int(master.integers(1, 7))
+        N = int(master.integers(1, 9))
+        target = ["iso", "funnel"][int(master.integers(0, 2))] if D > 1 else "iso"
+        metric = ["unit", "diag_chain", "diag_shared", "dense"][int(master.integers(0, 4))]
+        m = make_metric(metric, D, N, master)
+        eps = float(10 ** master.uniform(-1.5, 0.3)) * (0.5 + master.random(N))
+        integ = int(master.integers(0, 3))
+        lf = (A.Leapfrog(eps), A.JitteredLeapfrog(float(eps[0]), 0.5), A.TemperedLeapfrog(eps, 1.0 + 0.2 * float(master.random())))[integ]
+        alpha = [0.0, 0.0, float(master.uniform(0.1, 0.9))][int(master.integers(0, 3))]
+        refresh = A.PartialMomentumRefreshment(alpha) if alpha else A.FullMomentumRefreshment()
+        if master.random() < 0.6:
+            TS_ = [A.MultinomialTS, A.SliceTS][int(master.integers(0, 2))]
+            TC_ = [A.ClassicNoUTurn, A.GeneralisedNoUTurn, A.StrictGeneralisedNoUTurn][int(master.integers(0, 3))]
+            traj = A.Trajectory(TS_, lf, TC_(max_depth=int(master.integers(1, 7)), delta_max=float([20.0, 1000.0][int(master.integers(0, 2))])))
+        else:
+            TS_ = [A.EndPointTS, A.MultinomialTS][int(master.integers(0, 2))]
+            traj = A.Trajectory(TS_, lf, A.FixedNSteps(int(master.integers(1, 9))))
+        kernel = A.HMCKernel(refresh, traj)
+        n_trans = int(master.integers(1, 4))
+        e_ext, e_ref, _ = pair(oracle, target, m, N, lf, seed=int(master.integers(0, 2 ** 40)))
+        th0 = master.normal(size=(D, N)) * 1.5
+        e_ext.set_position(th0)
+        e_ref.set_position(th0)
+        k = kernel.cfg()
+        e_ext._call("ahmc_ext_begin", C.byref(k), n_trans)
+        e_ext._ext_drive()
+        e_ref.run(kernel, n_trans)
+        za, zb = e_ext.phasepoint(), e_ref.phasepoint()
+        sa, sb = e_ext.stats(), e_ref.stats()
+        tag = (case, D, N, target, metric, integ, alpha, type(traj.termination_criterion).__name__, traj.TS.__name__, n_trans)
+        np.testing.assert_array_equal(za.theta, zb.theta, err_msg=str(tag))
+        np.testing.assert_array_equal(za.r, zb.r, err_msg=str(tag))
+        for key in ("n_steps", "is_accept", "tree_depth", "numerical_error", "step_size", "acceptance_rate", "hamiltonian_energy"):
+            np.testing.assert_array_equal(sa[key], sb[key], err_msg=str((key,) + tag))
+        assert e_ext.info("iteration") == e_ref.info("iteration") == n_trans
+        e_ext.close(); e_ref.close()
