@@ -414,3 +414,64 @@ def test_plain_c_program_on_the_hip_engine(hip, tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=200)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.startswith("ok ")
+
+
+def test_hip_randomised_configurations(hip, oracle):
+    """60 random configurations on the step-synchronous engine — half with a user density through ahmc_ext_*, half with
+    the dense metric / dense target — every kernel kind, sampler, criterion, integrator and refreshment, against the
+    oracle running the same density built in"""
+    master = np.random.default_rng(424242)
+    mismatched = total = 0
+    for case in range(60):
+        ext = case % 2 == 0
+        D = int(master.integers(2, 12))
+        N = int(master.integers(3, 40))
+        integ = int(master.integers(0, 3))
+        eps = float(10 ** master.uniform(-1.3, -0.3)) * (0.5 + master.random(N))
+        lf = (A.Leapfrog(eps), A.JitteredLeapfrog(float(eps[0]), 0.4), A.TemperedLeapfrog(eps, 1.0 + 0.1 * float(master.random())))[integ]
+        alpha = [0.0, 0.0, float(master.uniform(0.1, 0.9))][int(master.integers(0, 3))]
+        refresh = A.PartialMomentumRefreshment(alpha) if alpha else A.FullMomentumRefreshment()
+        if master.random() < 0.6:
+            TS_ = [A.MultinomialTS, A.SliceTS][int(master.integers(0, 2))]
+            TC_ = [A.ClassicNoUTurn, A.GeneralisedNoUTurn, A.StrictGeneralisedNoUTurn][int(master.integers(0, 3))]
+            traj = A.Trajectory(TS_, lf, TC_(max_depth=int(master.integers(1, 7))))
+        else:
+            TS_ = [A.EndPointTS, A.MultinomialTS][int(master.integers(0, 2))]
+            traj = A.Trajectory(TS_, lf, A.FixedNSteps(int(master.integers(1, 9))))
+        kernel = A.HMCKernel(refresh, traj)
+        seed = int(master.integers(0, 2 ** 40))
+        th0 = master.normal(size=(D, N))
+        if ext:
+            target = ["iso", "funnel"][int(master.integers(0, 2))]
+            m = make_metric(["unit", "diag_chain", "diag_shared", "dense"][int(master.integers(0, 4))], D, N, master)
+            e_g, e_o = engines(hip, oracle, target, m, N, lf, seed=seed)
+        else:
+            B = master.normal(size=(D, D))
+            dense_target = master.random() < 0.6
+            tgt = A.DenseGaussian(B @ B.T / D + np.eye(D)) if dense_target else A.Funnel(D)
+            m = make_metric("dense" if (not dense_target or master.random() < 0.6) else ["unit", "diag_chain"][int(master.integers(0, 2))], D, N, master)
+            h = A.Hamiltonian(m, tgt)
+            e_g, e_o = A.Engine(h, N, rng=seed, lib=hip), A.Engine(h, N, rng=seed, lib=oracle)
+            for e in (e_g, e_o):
+                e.set_integrator(lf)
+        e_g.set_position(th0)
+        e_o.set_position(th0)
+        tag = (case, ext, D, N, integ, alpha, type(traj.termination_criterion).__name__, traj.TS.__name__)
+        for _ in range(2):
+            if ext:
+                e_g.transition(kernel)
+            else:
+                e_g.run(kernel, 1)
+            e_o.run(kernel, 1)
+            sa, sb = e_g.stats(), e_o.stats()
+            za, zb = e_g.phasepoint(), e_o.phasepoint()
+            same = (sa["n_steps"] == sb["n_steps"]) & (sa["is_accept"] == sb["is_accept"]) & np.all(np.isclose(za.theta, zb.theta, rtol=1e-7, atol=1e-7), axis=0)
+            total += N
+            mismatched += int((~same).sum())
+            np.testing.assert_allclose(za.r[:, same], zb.r[:, same], rtol=1e-7, atol=1e-7, err_msg=str(tag))
+            np.testing.assert_allclose(sa["hamiltonian_energy"][same], sb["hamiltonian_energy"][same], rtol=1e-7, atol=1e-7, err_msg=str(tag))
+            np.testing.assert_allclose(sa["step_size"], sb["step_size"], rtol=1e-12, err_msg=str(tag))
+            if not same.all():
+                e_g.set_position(zb.theta, zb.r)
+        e_g.close(); e_o.close()
+    assert mismatched <= 0.01 * total, (mismatched, total)
