@@ -1150,23 +1150,26 @@ int32_t ahmc_lf_post(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps, con
   FOR_CTX_MUT(ctx, {
     if (!lp || !grad_neg) return fail(c, AHMC_ERR_ARGUMENT, "lf_post: NULL argument");
     const int64_t DN = c->D * c->N;
-    // stage the caller's arrays (host or device) through c->g / c->lp
+    // stage the caller's arrays (host or device) through c->g / c->lp; a host gradient goes through the context's
+    // persistent staging buffer (shared with ahmc_ext_advance) — no allocation per step
     hipPointerAttribute_t at;
     const T* gsrc = static_cast<const T*>(grad_neg);
-    T* staged = nullptr;
     bool on_device = hipPointerGetAttributes(&at, grad_neg) == hipSuccess && at.type == hipMemoryTypeDevice;
     (void)hipGetLastError();
     if (!on_device) {
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&staged), sizeof(T) * DN));
-      HIPCHK(hipMemcpyAsync(staged, grad_neg, sizeof(T) * DN, hipMemcpyDefault, c->stream));
-      gsrc = staged;
+      if (!c->ext_gstage) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->ext_gstage), sizeof(T) * DN));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->ext_lpstage), sizeof(T) * c->N));
+      }
+      HIPCHK(hipMemcpyAsync(c->ext_gstage, grad_neg, sizeof(T) * DN, hipMemcpyDefault, c->stream));
+      gsrc = c->ext_gstage;
     }
     HIPCHK(hipMemcpyAsync(c->lp, lp, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
     KP<T> p = make_kp(c);
     hipLaunchKernelGGL((k_lf_post<T>), dim3((unsigned)((DN + 255) / 256)), dim3(256), 0, c->stream, p, (int)fwd, i, n_steps, gsrc);
     HIPCHK(hipGetLastError());
     int rc = launch_kinetic(c);
-    if (staged) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(staged)); }
+    if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));  // the caller may reuse its host arrays when this returns
     return rc;
   });
 }
