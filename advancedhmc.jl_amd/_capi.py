@@ -201,14 +201,26 @@ def dtype_code(dtype) -> int:
     raise ArgumentError(ERR_ARGUMENT, f"element type must be float32 or float64, got {dt}")
 
 
+class _OwningPtr(C.c_void_p):
+    """void* that keeps the object it points into alive.  `as_ptr(np.ascontiguousarray(x))` hands the C call the
+    address of a TEMPORARY: with a bare c_void_p the temporary is freed as soon as as_ptr returns, i.e. before the
+    call runs (round-1 bug: the gradient of a user log-density was read from freed memory once D·N·8 B outgrew
+    numpy's small-block cache).  The pointer object lives in the caller's argument tuple until the call returns,
+    and so does what it refers to."""
+    _keep = None
+
+
 def as_ptr(a) -> C.c_void_p:
-    """host numpy array, torch tensor (host or device) or raw int address -> void*"""
+    """host numpy array, torch tensor (host or device) or raw int address -> void* (owning, see _OwningPtr)"""
     if a is None:
         return C.c_void_p(None)
     if isinstance(a, int):
         return C.c_void_p(a)
     if isinstance(a, np.ndarray):
-        return C.c_void_p(a.ctypes.data)
-    if hasattr(a, "data_ptr"):
-        return C.c_void_p(a.data_ptr())
-    raise TypeError(f"cannot take the address of {type(a)}")
+        p = _OwningPtr(a.ctypes.data)
+    elif hasattr(a, "data_ptr"):
+        p = _OwningPtr(a.data_ptr())
+    else:
+        raise TypeError(f"cannot take the address of {type(a)}")
+    p._keep = a
+    return p

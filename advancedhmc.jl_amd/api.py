@@ -538,9 +538,10 @@ class Engine:
         if self._external:
             lp, grad = self.h.target.fn(th)
             rr = self._mat(r, "r") if r is not None else np.zeros_like(th)
-            self._call("ahmc_set_phasepoint", capi.as_ptr(th), capi.as_ptr(rr),
-                       capi.as_ptr(np.ascontiguousarray(lp, dtype=self.dtype)),
-                       capi.as_ptr(np.asfortranarray(-np.asarray(grad), dtype=self.dtype)))
+            # the converted arrays are bound to names: the C call reads them (as_ptr also keeps them alive)
+            lp_a = np.ascontiguousarray(lp, dtype=self.dtype).reshape(self.N)
+            g_a = self._mat(-np.asarray(grad), "∇ℓπ")
+            self._call("ahmc_set_phasepoint", capi.as_ptr(th), capi.as_ptr(rr), capi.as_ptr(lp_a), capi.as_ptr(g_a))
             return
         rr = None if r is None else self._mat(r, "r")
         self._call("ahmc_set_position", capi.as_ptr(th), capi.as_ptr(rr))
@@ -572,8 +573,9 @@ class Engine:
                 self._call("ahmc_lf_pre", fwd, i, n)
                 self._call("ahmc_get_phasepoint", capi.as_ptr(theta_view), None, None, None, None)
                 lp, grad = self.h.target.fn(theta_view)
-                self._call("ahmc_lf_post", fwd, i, n, capi.as_ptr(np.ascontiguousarray(lp, dtype=self.dtype)),
-                           capi.as_ptr(np.asfortranarray(-np.asarray(grad), dtype=self.dtype)))
+                lp_a = np.ascontiguousarray(lp, dtype=self.dtype).reshape(self.N)
+                g_a = self._mat(-np.asarray(grad), "∇ℓπ")
+                self._call("ahmc_lf_post", fwd, i, n, capi.as_ptr(lp_a), capi.as_ptr(g_a))
             return
         self._call("ahmc_leapfrog", int(n_steps))
 

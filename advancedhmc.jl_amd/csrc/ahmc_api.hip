@@ -1150,26 +1150,36 @@ int32_t ahmc_lf_post(ahmc_ctx* ctx, int32_t fwd, int64_t i, int64_t n_steps, con
   FOR_CTX_MUT(ctx, {
     if (!lp || !grad_neg) return fail(c, AHMC_ERR_ARGUMENT, "lf_post: NULL argument");
     const int64_t DN = c->D * c->N;
-    // stage the caller's arrays (host or device) through c->g / c->lp; a host gradient goes through the context's
-    // persistent staging buffer (shared with ahmc_ext_advance) — no allocation per step
-    hipPointerAttribute_t at;
+    // the caller's arrays may live on the host or on the device: host arrays go through the context's persistent
+    // staging buffers (shared with ahmc_ext_advance; no allocation per step), and the call then returns only after
+    // the stream has consumed them — the caller may reuse (or free) its host arrays as soon as this returns
+    auto on_device = [&](const void* ptr) {
+      hipPointerAttribute_t at;
+      const bool dev = hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeDevice;
+      (void)hipGetLastError();
+      return dev;
+    };
+    const bool g_dev = on_device(grad_neg), lp_dev = on_device(lp);
+    if ((!g_dev || !lp_dev) && !c->ext_gstage) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->ext_gstage), sizeof(T) * DN));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->ext_lpstage), sizeof(T) * c->N));
+    }
     const T* gsrc = static_cast<const T*>(grad_neg);
-    bool on_device = hipPointerGetAttributes(&at, grad_neg) == hipSuccess && at.type == hipMemoryTypeDevice;
-    (void)hipGetLastError();
-    if (!on_device) {
-      if (!c->ext_gstage) {
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->ext_gstage), sizeof(T) * DN));
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->ext_lpstage), sizeof(T) * c->N));
-      }
+    const T* lsrc = static_cast<const T*>(lp);
+    if (!g_dev) {
       HIPCHK(hipMemcpyAsync(c->ext_gstage, grad_neg, sizeof(T) * DN, hipMemcpyDefault, c->stream));
       gsrc = c->ext_gstage;
     }
-    HIPCHK(hipMemcpyAsync(c->lp, lp, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+    if (!lp_dev) {
+      HIPCHK(hipMemcpyAsync(c->ext_lpstage, lp, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
+      lsrc = c->ext_lpstage;
+    }
+    HIPCHK(hipMemcpyAsync(c->lp, lsrc, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
     KP<T> p = make_kp(c);
     hipLaunchKernelGGL((k_lf_post<T>), dim3((unsigned)((DN + 255) / 256)), dim3(256), 0, c->stream, p, (int)fwd, i, n_steps, gsrc);
     HIPCHK(hipGetLastError());
     int rc = launch_kinetic(c);
-    if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));  // the caller may reuse its host arrays when this returns
+    if (!g_dev || !lp_dev) HIPCHK(hipStreamSynchronize(c->stream));
     return rc;
   });
 }

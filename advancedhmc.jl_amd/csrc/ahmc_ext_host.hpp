@@ -218,14 +218,19 @@ int ext_advance(Ctx<T>* c, const void* lp_in, const void* g_in) {
   };
   const T* gsrc = static_cast<const T*>(g_in);
   const T* lsrc = static_cast<const T*>(lp_in);
+  bool staged = false;
   if (!on_device(g_in)) {
     HIPCHK(hipMemcpyAsync(c->ext_gstage, g_in, sizeof(T) * c->D * c->N, hipMemcpyDefault, c->stream));
     gsrc = c->ext_gstage;
+    staged = true;
   }
   if (!on_device(lp_in)) {
     HIPCHK(hipMemcpyAsync(c->ext_lpstage, lp_in, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
     lsrc = c->ext_lpstage;
+    staged = true;
   }
+  // host arrays are the caller's again when this call returns: not every path below synchronises by itself
+  if (staged) HIPCHK(hipStreamSynchronize(c->stream));
   hipLaunchKernelGGL((k_x_ingest<T>), dim3(dn_grid_elems(c, x.n_list)), dim3(256), 0, c->stream, lsrc, gsrc, c->lp, c->g, (int)c->D, x.n_list, x.list);
   HIPCHK(hipGetLastError());
   auto finish = [&]() {

@@ -7,6 +7,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -233,3 +234,36 @@ def test_hip_engine_fails_loudly_without_a_gpu():
     assert b"device" in lib.dll.ahmc_last_error(None)
     with pytest.raises(A.AHMCError):
         A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(4), A.IsoGaussian(4)), 8, lib=lib)
+
+
+def test_user_gradient_survives_the_call_boundary(oracle):
+    """Round-1 regression (ADVICE high #1): `as_ptr(<temporary>)` handed the C call the address of an array that was
+    already freed, so an ExternalTarget engine started from a garbage gradient once D*N*8 B outgrew numpy's
+    small-block cache.  Run in a child with MALLOC_PERTURB_ so that freed memory is visibly poisoned."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import ahmc_amd as A
+lib = A.CLib(%r)
+D, N = 10, 200
+fn = lambda th: (np.sum(-th * th / 2, axis=0), [list(row) for row in -th])   # a list: the conversion makes a temporary
+e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.ExternalTarget(D, fn)), N, lib=lib)
+e.set_integrator(A.Leapfrog(0.1))
+th = np.random.default_rng(0).normal(size=(D, N))
+e.set_position(th)
+z = e.phasepoint()
+assert np.array_equal(z.lp.gradient, th), np.abs(z.lp.gradient - th).max()
+np.testing.assert_allclose(z.lp.value, np.sum(-th * th / 2, axis=0), rtol=1e-13)
+e.step(3)   # lf_post reads a converted temporary as well
+ref = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(D), A.IsoGaussian(D)), N, lib=lib)
+ref.set_integrator(A.Leapfrog(0.1)); ref.set_position(th); ref.step(3)
+np.testing.assert_allclose(e.phasepoint().theta, ref.phasepoint().theta, rtol=1e-13)
+p = A.capi.as_ptr(np.arange(4.0) + 1)      # the pointer owns the temporary
+import ctypes
+assert list((ctypes.c_double * 4).from_address(p.value)) == [1.0, 2.0, 3.0, 4.0]
+print("ok")
+''' % (ROOT, oracle.path)
+    env = dict(os.environ, MALLOC_PERTURB_="165")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr

@@ -1,13 +1,13 @@
 """GPU side of the ask / tell protocol (ahmc_ext_*): the HIP engine driven with a user log-density must
 reproduce the oracle running the same density built in (Float64: 1e-9 on energies / positions, discrete
-statistics identical on >= 99.9 % of chains — the bars of test_gpu_parity.py).
+statistics identical on >= 99.9 % of chains — the bars of test_gpu_parity.py), plus the step-synchronous engine's
+variants (static MultinomialTS, partial refreshment, TemperedLeapfrog, Classic / Strict U-turn) and the split-step
+pair ahmc_lf_pre / ahmc_lf_post.
 
-This file sorts last on purpose and its tests are xfail(strict=False): the ahmc_ext_* host code and the
-step-synchronous engine's new variants (static MultinomialTS, partial refreshment, TemperedLeapfrog, Classic / Strict
-U-turn) were written after this round's GPU minutes were spent, so they have been exercised on the CPU oracle only
-(tests/test_external_target.py).  The kernels of the measured build are untouched — scripts/isa_digest.py against
-profiles/r1_isa_digest_d9f5554.json; the new work is host orchestration plus new kernels.  A pass shows up as XPASS;
-the markers go once a GPU run has confirmed them.
+History: in round 1 this file carried a module-wide xfail(strict=False) and every `engines()`-built test failed on
+the MI355X behind it.  Cause: `_capi.as_ptr(<temporary array>)` handed ahmc_set_phasepoint the address of an array
+that was freed before the call ran (advancedhmc.jl_amd/_capi.py, `_OwningPtr`) — the engine started every chain from
+a garbage gradient once D*N*8 B outgrew numpy's small-block cache.  The marker is gone: a failure here is a failure.
 """
 import ctypes as C
 
@@ -18,7 +18,6 @@ import ahmc_amd as A
 from test_external_target import TARGETS, iso_fn, make_metric
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="step-synchronous engine additions not yet run on a GPU (round 1 GPU budget spent)"),
               # every loop of the new host code is bounded (NUTS batches by their step bound, static HMC by L, the step-size
               # search by its iteration count); should one hang all the same, the run is cut short instead of stalling
               pytest.mark.timeout(240, method="thread")]
@@ -475,3 +474,49 @@ def test_hip_randomised_configurations(hip, oracle):
                 e_g.set_position(zb.theta, zb.r)
         e_g.close(); e_o.close()
     assert mismatched <= 0.01 * total, (mismatched, total)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("metric", ["unit", "diag_chain", "diag_shared"])
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_hip_split_step_lf_pre_post(hip, oracle, rng, metric, dtype, where):
+    """ahmc_lf_pre / ahmc_lf_post around a caller-side gradient (src/integrator.jl:231-243) on the HIP engine ==
+    the oracle's fused step on the same density, built in — with host arrays (staged, the call owns them only
+    until it returns) and with device arrays (torch), Leapfrog and TemperedLeapfrog, forwards and backwards"""
+    import torch
+
+    D, N = 24, 300
+    m = make_metric(metric, D, N, rng)
+    fn, builtin = TARGETS["funnel"]
+    th0, r0 = rng.normal(size=(D, N)) * 0.5, rng.normal(size=(D, N))
+    rt = 1e-10 if dtype == np.float64 else 2e-3
+    for lf in (A.Leapfrog(np.full(N, 0.05) * (0.5 + rng.random(N))), A.TemperedLeapfrog(np.full(N, 0.04), 1.05)):
+        ext = A.Engine(A.Hamiltonian(m, A.ExternalTarget(D, lambda th: fn(np.asarray(th, dtype=np.float64)))), N, dtype=dtype, lib=hip)
+        ref = A.Engine(A.Hamiltonian(m, builtin(D)), N, dtype=dtype, lib=oracle)
+        for e in (ext, ref):
+            e.set_integrator(lf)
+            e.set_position(th0, r0)
+        for n_steps in (7, -4):
+            ref.step(n_steps)
+            if where == "host":
+                ext.step(n_steps)
+            else:
+                n, fwd = abs(n_steps), 1 if n_steps > 0 else 0
+                tdt = torch.float64 if dtype == np.float64 else torch.float32
+                for i in range(1, n + 1):
+                    ext._call("ahmc_lf_pre", fwd, i, n)
+                    ext.sync()
+                    th = ext.theta()
+                    lp, g = fn(np.asarray(th, dtype=np.float64))
+                    lp_d = torch.as_tensor(np.ascontiguousarray(lp), dtype=tdt).cuda()
+                    g_d = torch.as_tensor(np.ascontiguousarray((-g).T), dtype=tdt).cuda().contiguous()  # row c = chain c
+                    torch.cuda.synchronize()
+                    ext._call("ahmc_lf_post", fwd, i, n, lp_d.data_ptr(), g_d.data_ptr())
+                    ext.sync()
+            za, zb = ext.phasepoint(), ref.phasepoint()
+            np.testing.assert_allclose(za.theta, zb.theta, rtol=rt, atol=rt)
+            np.testing.assert_allclose(za.r, zb.r, rtol=rt, atol=rt)
+            np.testing.assert_allclose(za.lp.value, zb.lp.value, rtol=rt, atol=rt * 10)
+            np.testing.assert_allclose(za.lk.value, zb.lk.value, rtol=rt, atol=rt * 10)
+            np.testing.assert_allclose(za.lp.gradient, zb.lp.gradient, rtol=rt, atol=rt * 10)
+        ext.close(); ref.close()
