@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 # --- enums (mirror include/ahmc_hip.h) --------------------------------------------------------
-AHMC_ABI_VERSION = 2
+AHMC_ABI_VERSION = 3
 OK, ERR_ARGUMENT, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_STATE = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
@@ -24,6 +24,8 @@ INTEGRATOR_LEAPFROG, INTEGRATOR_JITTERED, INTEGRATOR_TEMPERED = 0, 1, 2
 TS_ENDPOINT, TS_MULTINOMIAL, TS_SLICE = 0, 1, 2
 TC_CLASSIC, TC_GENERALISED, TC_STRICT = 0, 1, 2
 ADAPT_NONE, ADAPT_STEPSIZE, ADAPT_MASSMATRIX, ADAPT_NAIVE, ADAPT_STAN = range(5)
+VAR_WELFORD, VAR_NUTPIE, VAR_POOLED = 0, 1, 2
+UNIQUE_ID_BYTES = 128
 
 # stat fields: name -> (id, is_int)
 STAT_FIELDS = {
@@ -52,6 +54,25 @@ class KernelCfg(C.Structure):
         ("L", C.c_int64),
         ("lambda_", C.c_double),
         ("refresh_alpha", C.c_double),
+    ]
+
+
+class AdaptorState(C.Structure):
+    """ahmc_adaptor_state"""
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("var_estimator", C.c_int32),
+        ("init_buffer", C.c_int32),
+        ("term_buffer", C.c_int32),
+        ("window_size", C.c_int32),
+        ("adapting", C.c_int32),
+        ("has_da", C.c_int32),
+        ("n_welford", C.c_int32),
+        ("delta", C.c_double),
+        ("stan_i", C.c_int64),
+        ("n_adapts", C.c_int64),
+        ("wv_n", C.c_int64),
+        ("iteration", C.c_int64),
     ]
 
 
@@ -109,6 +130,7 @@ SIGNATURES = {
     "ahmc_stan_windows": (_i32, [_i32, _i32, _i32, _i64, C.POINTER(_i64), C.POINTER(_i64),
                                  C.POINTER(_i64), _i32, C.POINTER(_i32)]),
     "ahmc_sample": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i32, _vp]),
+    "ahmc_sample_from": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i64, _i32, _vp]),
     "ahmc_get_accum": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
     "ahmc_reset_accum": (_i32, [_vp]),
     "ahmc_get_info": (_i32, [_vp, _i32, C.POINTER(_i64)]),
@@ -117,6 +139,15 @@ SIGNATURES = {
     "ahmc_ext_pending": (_i32, [_vp, C.POINTER(_i64), _vp, _vp]),
     "ahmc_ext_advance": (_i32, [_vp, _vp, _vp]),
     "ahmc_ext_cancel": (_i32, [_vp]),
+    "ahmc_get_adaptor_state": (_i32, [_vp, C.POINTER(AdaptorState), _vp, _vp]),
+    "ahmc_set_adaptor_state": (_i32, [_vp, C.POINTER(AdaptorState), _vp, _vp]),
+    "ahmc_comm_unique_id": (_i32, [_vp]),
+    "ahmc_comm_init": (_i32, [_vp, _vp, _i32, _i32]),
+    "ahmc_set_comm": (_i32, [_vp, _vp, _i32, _i32]),
+    "ahmc_gather_moments": (_i32, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "ahmc_gather_state": (_i32, [_vp, _vp]),
+    "ahmc_ebfmi": (_i32, [_vp, _vp]),
+    "ahmc_ess": (_i32, [_vp, _vp, _i64, _vp]),
 }
 
 

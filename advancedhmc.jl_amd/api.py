@@ -360,6 +360,13 @@ class MassMatrixAdaptor:
     estimator = 0  # AHMC_VAR_WELFORD
 
 
+class PooledVar(MassMatrixAdaptor):
+    """One (D,) M⁻¹ shared by all chains, estimated from all of them — and from all GPUs once the engine has a
+    communicator (include/ahmc_hip.h AHMC_VAR_POOLED).  The reference has no counterpart: in
+    matrix mode it resizes WelfordVar to one estimator per chain (src/adaptation/massmatrix.jl:103-121)."""
+    estimator = 2  # AHMC_VAR_POOLED
+
+
 class NutpieVar(MassMatrixAdaptor):
     """NutpieVar(size) (src/adaptation/massmatrix.jl:160-250): the nutpie-style diagonal estimator
     M⁻¹ = sqrt(var θ / var ∇ℓπ); a drop-in for the WelfordVar behind MassMatrixAdaptor(DiagEuclideanMetric),
@@ -665,22 +672,86 @@ class Engine:
             self._call("ahmc_adapt_point", int(i), int(n_adapts), capi.as_ptr(th), capi.as_ptr(g), capi.as_ptr(al))
 
     # -- bulk driver --
-    def run(self, kernel: HMCKernel, n_samples, n_adapts=0, drop_warmup=False, samples_out=None):
-        """The whole `sample` loop enqueued by one C call (no host synchronisation inside).  With an
-        ExternalTarget the loop runs here, one ask / tell transition + adapt! per iteration."""
+    def run(self, kernel: HMCKernel, n_samples, n_adapts=0, drop_warmup=False, samples_out=None, i_first=1):
+        """The whole `sample` loop enqueued by one C call (no host synchronisation inside): iterations i_first …
+        n_samples (i_first > 1 continues a checkpointed run, ahmc_sample_from).  With an ExternalTarget the loop runs
+        here, one ask / tell transition + adapt! per iteration."""
         k = kernel.cfg()
         if self._external:
             if samples_out is not None:
                 raise capi.UnsupportedError(capi.ERR_UNSUPPORTED, "samples_out with an ExternalTarget: use sample()")
-            for i in range(1, int(n_samples) + 1):
+            for i in range(int(i_first), int(n_samples) + 1):
                 self.transition(kernel)
                 self.adapt(i, int(n_adapts))
             return
-        self._call("ahmc_sample", C.byref(k), int(n_samples), int(n_adapts), 1 if drop_warmup else 0,
+        self._call("ahmc_sample_from", C.byref(k), int(i_first), int(n_samples), int(n_adapts), 1 if drop_warmup else 0,
                    capi.as_ptr(samples_out))
 
     def sync(self):
         self._call("ahmc_sync")
+
+    # -- checkpoint / resume (HMCState, src/abstractmcmc.jl:11-27) --
+    def get_state(self) -> dict:
+        """Everything a resumed run needs: the phase point, h's metric, κ's nominal step sizes, the adaptor, the RNG
+        counter.  `Engine.set_state` on a fresh engine of the same Hamiltonian continues the run bit for bit."""
+        st = capi.AdaptorState()
+        self._call("ahmc_get_adaptor_state", C.byref(st), None, None)
+        da = np.empty((5, self.N), dtype=self.dtype) if st.has_da else None
+        wv = np.empty((st.n_welford, self.N, self.D), dtype=self.dtype) if st.n_welford else None  # C-order view of (n, D, N) column-major
+        self._call("ahmc_get_adaptor_state", C.byref(st), capi.as_ptr(da), capi.as_ptr(wv))
+        z = self.phasepoint() if not getattr(self, "_vector_mode", False) else None
+        if z is None:
+            self._vector_mode = False
+            z = self.phasepoint()
+            self._vector_mode = True
+        return {"adaptor": {k: getattr(st, k) for k, _ in capi.AdaptorState._fields_}, "da": da, "welford": wv,
+                "theta": z.theta, "r": z.r, "lp": z.lp.value, "grad": z.lp.gradient,
+                "metric": self.get_metric(), "metric_kind": self.metric_kind, "stepsize": self.get_stepsize()}
+
+    def set_state(self, state: dict):
+        if state["metric"] is not None:
+            self._call("ahmc_set_metric", state["metric_kind"], capi.as_ptr(np.asfortranarray(state["metric"], dtype=self.dtype)), state["metric"].size)
+        eps = np.ascontiguousarray(state["stepsize"], dtype=self.dtype)
+        self._call("ahmc_set_stepsize", capi.as_ptr(eps), eps.size)
+        th, r = self._mat(state["theta"], "θ"), self._mat(state["r"], "r")
+        lp = np.ascontiguousarray(state["lp"], dtype=self.dtype).reshape(self.N)
+        g = self._mat(state["grad"], "∇ℓπ")
+        self._call("ahmc_set_phasepoint", capi.as_ptr(th), capi.as_ptr(r), capi.as_ptr(lp), capi.as_ptr(g))
+        st = capi.AdaptorState(**state["adaptor"])
+        self._call("ahmc_set_adaptor_state", C.byref(st), capi.as_ptr(state["da"]), capi.as_ptr(state["welford"]))
+
+    # -- multi-GPU: the final gather through the C ABI (RCCL inside) --
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_char * capi.UNIQUE_ID_BYTES)()
+        self.lib.check(self.lib.dll.ahmc_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
+        buf = (C.c_char * capi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._call("ahmc_comm_init", buf, int(n_ranks), int(rank))
+
+    def gather_moments(self) -> dict:
+        mean, var = np.empty(self.D), np.empty(self.D)
+        n, tot, ndiv = C.c_int64(), C.c_int64(), C.c_int64()
+        self._call("ahmc_gather_moments", capi.as_ptr(mean), capi.as_ptr(var), C.byref(n), C.byref(tot), C.byref(ndiv))
+        return {"mean": mean, "var": var, "n_draws": n.value, "total_n_steps": tot.value, "n_divergent": ndiv.value}
+
+    def gather_state(self, theta_all_ptr):
+        """ncclAllGather of θ into the caller's DEVICE buffer (D, N, n_ranks)"""
+        self._call("ahmc_gather_state", theta_all_ptr if isinstance(theta_all_ptr, C.c_void_p) else capi.as_ptr(theta_all_ptr))
+
+    # -- diagnostics computed where the data is --
+    def ebfmi(self):
+        """EBFMI (src/diagnosis.jl:1-3) per chain over the kept transitions of the last `run`"""
+        out = self._out(vec=True)
+        self._call("ahmc_ebfmi", capi.as_ptr(out))
+        return out
+
+    def ess(self, draws_ptr, n_draws):
+        """ESS of every (dimension, chain) series of the (D, N, n_draws) device buffer `run(samples_out=…)` filled"""
+        out = self._out()
+        self._call("ahmc_ess", draws_ptr if isinstance(draws_ptr, C.c_void_p) else capi.as_ptr(draws_ptr), int(n_draws), capi.as_ptr(out))
+        return out
 
     @property
     def stream(self):
@@ -697,7 +768,8 @@ class Engine:
     def reset_accum(self):
         self._call("ahmc_reset_accum")
 
-    INFO = {"group_lanes": 0, "elems_per_lane": 1, "nuts_launches": 2, "nuts_batch": 3, "iteration": 4, "nuts_kernel_ns": 5}
+    INFO = {"group_lanes": 0, "elems_per_lane": 1, "nuts_launches": 2, "nuts_batch": 3, "iteration": 4, "nuts_kernel_ns": 5,
+            "nuts_warm_launches": 6, "nuts_warm_kernel_ns": 7}
 
     def info(self, key):
         """engine introspection (ahmc_get_info): thread geometry, NUTS launch count / batch, iteration"""

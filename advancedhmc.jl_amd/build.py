@@ -100,7 +100,7 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     units = _units()
     with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_one, units))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", OUT]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wl,-Bsymbolic-functions", *objs, "-o", OUT]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")

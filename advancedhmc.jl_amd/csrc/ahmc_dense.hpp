@@ -782,6 +782,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         if (p.accum) {
           p.acc_nsteps()[c] += na_tree;
           p.acc_ndiv()[c] += numerical ? 1 : 0;
+          accumulate_energy(p, c, H);
         }
       }
       ++it;
@@ -1063,6 +1064,7 @@ __global__ __launch_bounds__(256) void k_d_hmc_end(KP<T> p, DP<T> q) {
     if (p.accum) {
       p.acc_nsteps()[c] += p.L;
       p.acc_ndiv()[c] += (isfinite(lp1) && isfinite(lk1)) ? 0 : 1;
+      accumulate_energy(p, c, H);
     }
   }
 }

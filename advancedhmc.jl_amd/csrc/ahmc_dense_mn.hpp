@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_d_mn_end(KP<T> p, DP<T> q) {
     if (p.accum) {
       p.acc_nsteps()[c] += p.L;
       p.acc_ndiv()[c] += numerr;
+      accumulate_energy(p, c, H);
     }
   }
 }

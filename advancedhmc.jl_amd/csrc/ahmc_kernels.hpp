@@ -10,7 +10,7 @@ namespace ahmc {
 // Everything a kernel needs, passed by value.  Arrays are (D,N) column-major / (N,).
 // The context keeps its per-chain arrays in four slabs so that the kernel arguments stay small
 // (a fat kernarg struct exhausts the 102 SGPRs and pushes every uniform value into VGPRs):
-//   vbase: T[5][D*N]  θ, r, -∇ℓπ, Σθ, Σθ²          tbase: T[9][N]  ℓπ, ℓκ, ϵ_nom, ϵ_cur, stats…
+//   vbase: T[5][D*N]  θ, r, -∇ℓπ, Σθ, Σθ²          tbase: T[14][N]  ℓπ, ℓκ, ϵ_nom, ϵ_cur, stats…, energy sums (EBFMI)
 //   ibase: int32[4][N] n_steps, is_accept, depth, numerical_error   lbase: int64[2][N] Σn_steps, Σdiv
 template <class T>
 struct KP {
@@ -36,6 +36,9 @@ struct KP {
   __device__ __forceinline__ T* st_H() const { return sca(6); }
   __device__ __forceinline__ T* st_Herr() const { return sca(7); }
   __device__ __forceinline__ T* st_maxHerr() const { return sca(8); }
+  // running sums over the energies of the kept transitions (EBFMI, src/diagnosis.jl:1-3): n, E_prev, Σ(E_i − E_{i−1})²,
+  // Welford mean and M2 of E
+  __device__ __forceinline__ T* acc_energy() const { return sca(9); }
   __device__ __forceinline__ int32_t* st_nsteps() const { return ibase; }
   __device__ __forceinline__ int32_t* st_accept() const { return ibase + N; }
   __device__ __forceinline__ int32_t* st_depth() const { return ibase + 2 * N; }
@@ -183,9 +186,24 @@ __device__ __forceinline__ void store_point(const KP<T>& p, int64_t c, int d0, i
   }
 }
 
+// one lane per chain: fold the energy H of a kept transition into the chain's running sums
+template <class T>
+__device__ __forceinline__ void accumulate_energy(const KP<T>& p, int64_t c, T H) {
+  T* ea = p.acc_energy();
+  const T n0 = ea[c], prev = ea[p.N + c];
+  const T n = n0 + 1;
+  if (n0 > 0) { const T d = H - prev; ea[2 * p.N + c] += d * d; }
+  const T mean = ea[3 * p.N + c], delta = H - mean;
+  const T mean2 = mean + delta / n;
+  ea[3 * p.N + c] = mean2;
+  ea[4 * p.N + c] += delta * (H - mean2);
+  ea[c] = n;
+  ea[p.N + c] = H;
+}
+
 template <class T, int E>
 __device__ __forceinline__ void accumulate(const KP<T>& p, int64_t c, int d0, int lane, const T (&th)[E], int n_steps,
-                                           int numerr) {
+                                           int numerr, T H) {
   if (!p.accum) return;
   T s1[E], s2[E];
   load_vec<T, E>(s1, p.acc_sum(), c * p.D, d0, p.D, T(0));
@@ -200,6 +218,7 @@ __device__ __forceinline__ void accumulate(const KP<T>& p, int64_t c, int d0, in
   if (lane == 0) {
     p.acc_nsteps()[c] += n_steps;
     p.acc_ndiv()[c] += numerr;
+    accumulate_energy(p, c, H);
   }
 }
 
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(G > 256 ? G : 256) void k_hmc(KP<T> p) {
     p.st_depth()[c] = 0;
     p.st_numerr()[c] = numerr;
   }
-  accumulate<T, E>(p, c, d0, lane, z.th, (int)L, numerr);
+  accumulate<T, E>(p, c, d0, lane, z.th, (int)L, numerr, H);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,6 +575,7 @@ __device__ __forceinline__ T welford_estimate(T M, T n) {
 template <class T>
 struct AdaptK {
   int kind, has_ss, has_mm, nutpie;
+  int pooled;        // AHMC_VAR_POOLED: the kernel only pushes; update / reset are the host's (pooled_update) at the batch end
   int64_t i0;        // adaptation iterations done before this launch
   int64_t n_adapts;
   int64_t stan_i0;   // StanHMCAdaptor state.i before this launch

@@ -259,6 +259,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       do_push = true;
       do_update = true;
     }
+    if (ak->pooled) { do_update = false; wv_reset = false; }  // one (D,) estimate over all chains: pooled on the host side
   };
   auto save_adapt_state = [&]() {  // dual averaging + nominal step size of this chain (the Welford vectors are always in memory)
     if (ak->has_ss && lane == 0) {
@@ -667,7 +668,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           p.st_depth()[ce] = depth;
           p.st_numerr()[ce] = numerical ? 1 : 0;
         }
-        accumulate<T, E>(p, ce, d0, lane, zc.th, na_tree, numerical ? 1 : 0);
+        accumulate<T, E>(p, ce, d0, lane, zc.th, na_tree, numerical ? 1 : 0, H);
         if (p.samples_out) store_vec<T, E>(zc.th, p.samples_out + (int64_t)kt * p.D * p.N, ce * p.D, d0, p.D);
         copy_vec(th_cur, zc.th);
         if constexpr (ADAPT) {

@@ -45,3 +45,34 @@ def gather_moments(dist, local: "torch.Tensor", n_local: int, device):
     mean = tot[0] / n_tot
     var = tot[1] / n_tot - mean * mean
     return mean.cpu().numpy(), var.cpu().numpy(), int(n_tot)
+
+
+class EngineComm:
+    """The RCCL communicator of a sharded run, owned by the engine's context: rank 0 makes the unique id
+    (ahmc_comm_unique_id), the 128 bytes travel through the process group the launcher already set up
+    (torch.distributed — plumbing), every rank joins with ahmc_comm_init; from then on the gathers are C-ABI calls
+    (ahmc_gather_moments, ahmc_gather_state) that run ncclAllReduce / ncclAllGather on the context's stream.
+    Without a process group the world is one rank and no communicator is made."""
+
+    def __init__(self, engine, dist, device):
+        self.engine = engine
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.how = "single rank (no collective)"
+        if dist is not None and dist.is_initialized():
+            import torch
+
+            rank = dist.get_rank()
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).to(device)
+            dist.broadcast(uid, src=0)
+            engine.comm_init(bytes(uid.cpu().numpy().tobytes()), self.world, rank)
+            self.how = f"ahmc_gather_moments: ncclAllReduce of 2*D+3 doubles over {self.world} rank(s), communicator made by ahmc_comm_init"
+
+    def gather_moments(self):
+        g = self.engine.gather_moments()
+        g["how"] = self.how
+        return g
+
+    def close(self):
+        pass  # the context owns the communicator and destroys it with itself

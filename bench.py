@@ -1,32 +1,41 @@
 #!/usr/bin/env python
-"""bench.py — leapfrog-steps/sec of the chain-batched NUTS hot path on MI355X.
+"""bench.py — leapfrog-steps/sec of the chain-batched NUTS hot path on MI355X, end to end.
 
-Workload (BASELINE.json configs[1]): D=128 isotropic Gaussian,
-DiagEuclideanMetric (per-chain M⁻¹), NUTS(δ=0.8) = MultinomialTS + GeneralisedNoUTurn(max_depth
-10, Δ_max 1000) with StanHMCAdaptor, 65 536 chains per GPU, Float64, synthetic θ0 ~ U(0,1).
+Workload (default `--config cfg2` = BASELINE.json configs[1]): D=128 isotropic Gaussian,
+DiagEuclideanMetric (per-chain M⁻¹, init ones), NUTS(δ=0.8) = MultinomialTS + GeneralisedNoUTurn(max_depth 10,
+Δ_max 1000) with StanHMCAdaptor(75/50/25), 65 536 chains per GPU, Float64, synthetic θ0 ~ U(0,1).
 
-A "step" is ONE NUTS transition of all chains.  Setup (untimed): find_good_stepsize + `--adapt`
-Stan-adaptation transitions.  Then W warm-up steps and exactly K timed steps, bracketed by barrier
-+ synchronize; MAX over ranks; rank 0 prints one JSON line.  `value` = Σ n_steps over all chains
-and ranks in the timed region ÷ that time.
+What is timed is the reference's `sample` loop (src/sampler.jl:182-228) — the loop that contains `adapt!`:
+    sample(rng, h, κ, θ0, n_samples = n_adapts + n_draws, StanHMCAdaptor, n_adapts)
+i.e. the warm-up transitions WITH their adaptation and the post-warm-up draws.  SURVEY §8d quotes the metric on
+1 000 + 1 000 transitions; `--steps K` scales that: a "step" is `--transitions-per-step` (default 100) consecutive
+transitions of all chains, the first half of the K steps adapting, the second half drawing, so the driver's K = 20
+is exactly the 1 000 + 1 000 run.  Untimed, as §8d says ("excluding setup and H2D of the initial state"): engine
+creation, θ0 upload, find_good_stepsize.  W warm-up steps (same loop, throw-away engine) run first; then the timed
+region — exactly K steps — bracketed by barrier + synchronize, MAX over ranks, repeated `--repeats` times (default:
+until >= 1 s of timed work and at least 3 runs when they are short), the MEDIAN run is reported (all runs listed).
+`value` = Σ n_steps over all chains, ranks and both phases of that run ÷ its wall time.  The post-adaptation rate (the
+round-1 headline) and the warm-up rate are sub-fields of `config`.
 
-In the sampling phase the engine runs a batch of transitions per launch of the dominant kernel
-k_nuts (chains are independent, so there is no per-transition barrier; `nuts_batch` transitions,
-the K steps split evenly over ⌈K / nuts_batch⌉ launches).  The roofline object is per LAUNCH:
-algorithmic bytes of the leapfrogs one launch executes ÷ the launch's duration, measured by HIP
-events the engine records around each k_nuts launch on its own stream (AHMC_INFO_NUTS_KERNEL_NS) —
-the same quantity rocprofv3's kernel trace reports for those launches (profiles/r1_kernel_stats.csv,
-"timed launches" rows; the `--stats` average also covers the single-transition launches of the
-adaptation phase).  `timed_region_ms_on_stream` is the whole K-step region incl. the helpers
-(k_normals, the log-domain redo pass).
+`roofline` is the roof that binds the dominant kernel: VALU issue.  A fused trajectory kernel keeps the state in
+registers, so SURVEY §8d's state-through-memory byte model is not a roof for it (a fraction > 1 in round 1); it is
+still reported as `hbm_model_frac`.  VALU roof: wave-instructions per leapfrog of the shipped kernel × leapfrogs of
+the launches ÷ their duration (HIP events recorded by the engine around every launch of the kernel on its stream)
+÷ (1024 SIMDs × 2.4 GHz ÷ 4 cycles per wave64 instruction).  Instructions per leapfrog and HBM bytes come from
+rocprofv3 PMC passes over THIS command, committed as profiles/counters_at_head.json together with the digest of the
+kernel sources they were taken on: if the digest does not match the library in use the counters are stale and
+`frac`, `traffic` are null (never rescaled from an old measurement).
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); chains shard with no
-data-path collective (weak scaling, 65 536 chains per GPU, Philox chain offset = rank·N); the
-only collectives are the timing reductions and the final gather of per-dimension moments.
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  `--gpus N` without a torchrun environment
+re-executes itself under `python -m torch.distributed.run --nproc-per-node N`.  Chains shard with no data-path
+collective (weak scaling, Philox chain offset = rank·chains); the only collectives are the timing reductions and the
+final gather of per-dimension moments, which goes through the C ABI (ahmc_gather_moments over RCCL).
 """
 import argparse
 import json
+import math
 import os
+import socket
 import sys
 import time
 
@@ -35,62 +44,109 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md chip table)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md chip table
+VALU_PEAK_GINSTR = 1024 * 2.4e9 / 4 / 1e9   # 256 CUs × 4 SIMDs, 2.4 GHz, one wave64 VALU instruction per 4 cycles
+F64_MFMA_PEAK_TFLOPS = 78.6    # dense f64 matrix peak
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+CONFIGS = {
+    # name: D, chains per GPU, target, metric, adaptor, GPUs the config is quoted on
+    "cfg2": dict(D=128, N=65536, target="iso", metric="diag", adaptor="stan", quoted_gpus=1, seed=0x5EED0002,
+                 text="cfg2: D=128 iso Gaussian, DiagEuclideanMetric per-chain, NUTS(0.8) MultinomialTS+GeneralisedNoUTurn max_depth 10, StanHMCAdaptor"),
+    "cfg3": dict(D=32, N=65536, target="funnel", metric="diag", adaptor="stan", quoted_gpus=1, seed=0x5EED0003,
+                 text="cfg3: D=32 Neal's funnel, DiagEuclideanMetric per-chain, NUTS(0.8, max_depth 10), StanHMCAdaptor"),
+    "cfg4": dict(D=512, N=8192, target="dense", metric="dense", adaptor="stepsize", quoted_gpus=4, seed=0x5EED0004,
+                 text="cfg4 (one GPU's shard of 32 768 chains / 4 GPUs): D=512 correlated Gaussian Sigma_ij=0.9^|i-j| (logdensity as a GEMM), "
+                      "shared DenseEuclideanMetric, NUTS(0.8), StepSizeAdaptor"),
+    "cfg5": dict(D=2048, N=32768, target="hier", metric="diag", adaptor="stan", quoted_gpus=8, seed=0x5EED0005,
+                 text="cfg5 (one GPU's shard of 262 144 chains / 8 GPUs): D=2048 hierarchical Gaussian, DiagEuclideanMetric per-chain, NUTS(0.8), StanHMCAdaptor"),
+}
 
 
-def algorithmic_bytes_per_leapfrog(D, diag, itemsize):
+def algorithmic_bytes_per_leapfrog(D, metric, itemsize):
     """B_lf = (6·D + D_M)·sizeof(T) + 4·sizeof(T)"""
-    return (6 * D + (D if diag else 0)) * itemsize + 4 * itemsize
+    return (6 * D + (D if metric == "diag" else 0)) * itemsize + 4 * itemsize
 
 
-def measured_traffic(D, N):
-    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, separate rocprofv3 passes: profiles/r1_hbm_traffic.json).  bench.py cannot run
-    rocprofv3 on itself, so the committed measurement is reported — only for the workload it was
-    taken on; otherwise null."""
+def sources_digest():
+    """digest of the kernel sources + flags the shipped libahmc_hip.so was built from (advancedhmc.jl_amd/build.py)"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
-            t = json.load(f)
-        if (D, N) != (128, 65536):
-            return None
-        return t["hbm_bytes_per_launch"], t.get("transitions_per_launch")
-    except Exception:
+        return open(os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.digest")).read().strip()
+    except OSError:
         return None
 
 
-def measured_issue(D, N):
-    """What actually bounds the fused kernel: VALU issue.  SQ_ACTIVE_INST_VALU / SIMD cycles and instructions per
-    leapfrog from the committed PMC passes (profiles/r1_sq_counters.json), for the workload they were taken on."""
+def counters_at_head(config):
+    """PMC counters of the dominant kernels, valid only for the kernel sources they were taken on"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_sq_counters.json")) as f:
-            d = json.load(f)["derived"]
-        if (D, N) != (128, 65536):
-            return None
-        return {"valu_busy_fraction_of_simd_cycles": d["valu_busy_fraction_of_simd_cycles"],
-                "valu_instructions_per_leapfrog": d["valu_instructions_per_leapfrog"],
-                "mean_waves_per_simd": d["mean_waves_per_simd"], "source": "profiles/r1_sq_counters.json"}
+        with open(os.path.join(ROOT, "profiles", "counters_at_head.json")) as f:
+            d = json.load(f)
     except Exception:
-        return None
+        return None, "profiles/counters_at_head.json is missing"
+    if d.get("sources_digest") != sources_digest():
+        return None, "profiles/counters_at_head.json was taken on other kernel sources (digest mismatch): stale, not used"
+    c = d.get("configs", {}).get(config)
+    if not c:
+        return None, f"profiles/counters_at_head.json has no counters for {config}"
+    return c, d.get("source", "profiles/counters_at_head.json")
 
 
-def build_engine(A, lib, D, N, seed, chain_offset, stream=0, device=0, dtype=np.float64):
-    metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
-    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+def build_engine(A, lib, cfg, N, seed, chain_offset, stream=0, device=0, dtype=np.float64):
+    """sample_init + find_good_stepsize + adaptor: the untimed setup of the reference's call sequence
+    (src/abstractmcmc.jl:131-166: make_step_size → find_good_stepsize, make_adaptor, sample_init)"""
+    D = cfg["D"]
+    if cfg["metric"] == "dense":
+        metric = A.DenseEuclideanMetric(np.eye(D, order="F"))
+    else:
+        metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
+    if cfg["target"] == "iso":
+        target = A.IsoGaussian(D)
+    elif cfg["target"] == "funnel":
+        target = A.Funnel(D)
+    elif cfg["target"] == "hier":
+        target = A.HierGaussian(D)
+    else:
+        idx = np.arange(D)
+        target = A.DenseGaussian(np.linalg.inv(0.9 ** np.abs(idx[:, None] - idx[None, :])))
+    h = A.Hamiltonian(metric, target)
     eng = A.Engine(h, N, dtype=dtype, rng=A.PhiloxRNG(seed, chain_offset), lib=lib, device=device, stream=stream)
     lf = A.Leapfrog(np.full(N, 0.1))
     eng.set_integrator(lf)
     th0 = np.random.default_rng(seed + chain_offset).random((D, N))
     eng.set_position(np.asfortranarray(th0))
     eng.find_good_stepsize()
-    eng.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)))
+    if cfg["adaptor"] == "stan":
+        eng.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)))
+    else:
+        eng.adaptor_init(A.StepSizeAdaptor(0.8, lf))
     kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
     return eng, kernel
 
 
+def sample_loop(eng, kernel, n_adapts, n_draws, sync):
+    """the timed region: sample(…, n_adapts + n_draws, adaptor, n_adapts).  Two ahmc_sample calls — the adapting
+    transitions, then the draws — so that each phase's Σ n_steps can be read; the iteration counter, the adaptor
+    and the state carry over, i.e. it is the one loop of src/sampler.jl:182-228."""
+    info0 = {k: eng.info(k) for k in ("nuts_launches", "nuts_kernel_ns", "nuts_warm_launches", "nuts_warm_kernel_ns")}
+    sync()
+    t0 = time.perf_counter()
+    if n_adapts > 0:
+        eng.run(kernel, n_adapts, n_adapts)
+    eng.sync()
+    t1 = time.perf_counter()
+    acc_a = eng.accum(moments=False) if n_adapts > 0 else {"total_n_steps": 0, "n_divergent": 0}
+    eng.run(kernel, n_draws, 0)
+    sync()
+    t2 = time.perf_counter()
+    acc_d = eng.accum(moments=True)
+    info = {k: eng.info(k) - v for k, v in info0.items()}
+    return {"dt": t2 - t0, "dt_adapt": t1 - t0, "dt_draw": t2 - t1, "leap_adapt": acc_a["total_n_steps"], "leap_draw": acc_d["total_n_steps"],
+            "div_adapt": acc_a["n_divergent"], "acc": acc_d, "info": info}
+
+
 def usable_cores():
-    """CPU cores this process may actually use: min(visible CPUs, cgroup-v2 CPU quota).  The GPU
-    boxes show 256 logical CPUs but run the container under `cpu.max 1600000 100000` (16 cores);
-    oversubscribing the quota only adds throttling (measured: 32 threads 1.5e7, 256 threads 3e6)."""
+    """CPU cores this process may actually use: min(visible CPUs, cgroup-v2 CPU quota).  The GPU boxes show 256 logical
+    CPUs but run the container under `cpu.max 1600000 100000` (16 cores); oversubscribing the quota only adds throttling."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -101,43 +157,79 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(A, D, n_adapt, steps, seed, chains, threads):
-    """The CPU oracle (scalar restatement of the reference, OpenMP over chains) on a bounded
-    sample of the same workload, timed on this host's usable cores."""
+def cpu_baseline(A, cfg, n_adapts, n_draws, seed, chains, threads):
+    """The CPU oracle (scalar restatement of the reference, OpenMP over chains) on a bounded sample of the SAME loop
+    (adapting transitions + draws, same adaptor), timed on this host's usable cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import build_oracle  # test infrastructure: used here only as the timed CPU baseline
 
     lib = A.CLib(build_oracle.build())
     lib.dll.ahmco_set_num_threads.restype = int
     threads = lib.dll.ahmco_set_num_threads(int(threads))
-    eng, kernel = build_engine(A, lib, D, chains, seed, 0)
-    eng.run(kernel, n_adapt, n_adapt)
-    eng.run(kernel, 1, 0)
-    t0 = time.perf_counter()
-    eng.run(kernel, steps, 0)
-    dt = time.perf_counter() - t0
-    acc = eng.accum(moments=False)
+    eng, kernel = build_engine(A, lib, cfg, chains, seed, 0)
+    r = sample_loop(eng, kernel, n_adapts, n_draws, eng.sync)
     eng.close()
-    return acc["total_n_steps"] / dt, dt, threads
+    return (r["leap_adapt"] + r["leap_draw"]) / r["dt"], r["leap_draw"] / max(r["dt_draw"], 1e-9), r["dt"], threads
+
+
+def respawn_under_torchrun(n):
+    """`bench.py --gpus N` outside a torchrun environment: become the launcher (one rank per GPU)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
+
+
+def launch_check(args):
+    """Plumbing check for a machine without GPUs (tests/test_bench_contract.py): the ranks `--gpus N` asks for exist,
+    rendezvous over gloo, and rank 0 reports their number.  Runs no engine and no compute."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "gpus_requested": args.gpus}))
+    return 0 if seen == world == args.gpus else 1
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--adapt", type=int, default=200, help="untimed Stan adaptation transitions")
-    ap.add_argument("--seed", type=int, default=0x5EED0002)
-    ap.add_argument("--cpu-chains", type=int, default=0, help="0 = 128 per host core, capped at --chains")
-    ap.add_argument("--cpu-steps", type=int, default=1500)
+    ap.add_argument("--steps", type=int, default=20, help="K timed steps; a step = --transitions-per-step transitions of all chains")
+    ap.add_argument("--warmup", type=int, default=2, help="W untimed steps of the same loop on a throw-away engine")
+    ap.add_argument("--transitions-per-step", type=int, default=100)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (0 = the config's)")
+    ap.add_argument("--dim", type=int, default=0, help="D (0 = the config's)")
+    ap.add_argument("--adapt-fraction", type=float, default=0.5, help="share of the K steps that adapt (SURVEY 8d: 1000 of 2000)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed runs (0 = until >= 1 s of timed work, at least 3 when a run is < 4 s)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-chains", type=int, default=0, help="0 = 256 per usable host core, capped at --chains")
+    ap.add_argument("--cpu-transitions", type=int, default=0, help="transitions of the CPU sample (0 = sized for ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64", help="f64 = the reference default and the headline; f32 = what the "
                     "reference's CUDA smoke test uses (test/CUDA/cuda.jl:18), reported for information")
-    ap.add_argument("--ess", type=int, default=0, help="after the timed region: K more transitions with the draws kept in HBM, "
-                    "ESS/sec (min over dimensions, Geyer estimator, 256-chain subset) reported under config.ess")
+    ap.add_argument("--ess", type=int, default=-1, help="after the timed region: this many more draws kept in HBM for the ESS estimate "
+                    "(-1 = 500 for cfg2/cfg3, 0 for the large-D configs; 0 = skip)")
+    ap.add_argument("--launch-check", action="store_true", help="spawn/rendezvous check only (gloo, no GPU, no compute)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(args.gpus)  # does not return
+    if args.launch_check:
+        sys.exit(launch_check(args))
 
     import torch
     import ahmc_amd as A
@@ -145,145 +237,228 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let --gpus spawn them)")
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("AHMC_BENCH_FORCE_DIST"):  # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
 
     lib = A.load_hip_library()  # raises if the HIP engine is not built: no fallback
-    D, N = args.dim, args.chains
+    cfg = dict(CONFIGS[args.config])
+    if args.dim:
+        cfg["D"] = args.dim
+    D, N = cfg["D"], (args.chains or cfg["N"])
+    seed = args.seed or cfg["seed"]
+    T = args.transitions_per_step
+    n_total = args.steps * T
+    n_adapts = int(round(n_total * args.adapt_fraction))
+    n_draws = n_total - n_adapts
     stream = torch.cuda.Stream(device=local_rank)
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
-    eng, kernel = build_engine(A, lib, D, N, args.seed, rank * N, stream=stream.cuda_stream, device=local_rank, dtype=np_dtype)
+    itemsize = 4 if args.dtype == "f32" else 8
+    dev = f"cuda:{local_rank}"
 
-    def barrier():
-        eng.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    def make():
+        return build_engine(A, lib, cfg, N, seed, rank * N, stream=stream.cuda_stream, device=local_rank, dtype=np_dtype)
 
-    # setup (untimed): adaptation, then W warm-up steps in the sampling phase
-    eng.run(kernel, args.adapt, args.adapt)
+    def barrier_for(eng):
+        def f():
+            eng.sync()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+        return f
+
+    # W untimed warm-up steps of the same loop (code objects, allocator, clocks) on a throw-away engine
     if args.warmup > 0:
-        eng.run(kernel, args.warmup, 0)
-    barrier()
+        eng, kernel = make()
+        nw = args.warmup * T
+        sample_loop(eng, kernel, int(round(nw * args.adapt_fraction)), max(1, nw - int(round(nw * args.adapt_fraction))), barrier_for(eng))
+        eng.close()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    launches0, kns0 = eng.info("nuts_launches"), eng.info("nuts_kernel_ns")
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    eng.run(kernel, args.steps, 0)  # K transitions, accumulators reset at the first one
-    ev1.record(stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)
+    runs = []
+    eng = None
+    while True:
+        if eng is not None:
+            eng.close()
+        eng, kernel = make()                      # untimed setup: create, θ0, find_good_stepsize, adaptor
+        r = sample_loop(eng, kernel, n_adapts, n_draws, barrier_for(eng))
+        tt = torch.tensor([r["dt"], r["dt_adapt"], r["dt_draw"]], dtype=torch.float64, device=dev)
+        tn = torch.tensor([float(r["leap_adapt"]), float(r["leap_draw"]), float(r["acc"]["n_divergent"]), float(r["div_adapt"])],
+                          dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        r["dt_max"], r["dt_adapt_max"], r["dt_draw_max"] = (float(x) for x in tt.tolist())
+        r["leap_adapt_all"], r["leap_draw_all"], r["div_all"], r["div_adapt_all"] = (float(x) for x in tn.tolist())
+        r["value"] = (r["leap_adapt_all"] + r["leap_draw_all"]) / r["dt_max"]
+        runs.append(r)
+        spent = sum(x["dt_max"] for x in runs)
+        want = args.repeats if args.repeats > 0 else (3 if runs[0]["dt_max"] < 4.0 else 1)
+        # every rank takes the same decision: dt_max is the all-reduced time
+        if len(runs) >= want and (args.repeats > 0 or spent >= 1.0):
+            break
+        if len(runs) >= 50:
+            break
+    order = sorted(range(len(runs)), key=lambda i: runs[i]["value"])
+    med = runs[order[len(order) // 2]]   # median run (the engine of the LAST run is still open for the ESS leg / the gather)
 
-    acc = eng.accum(moments=True)
-    n_leap = acc["total_n_steps"]
-    n_launches = max(1, eng.info("nuts_launches") - launches0)
-    nuts_ns = eng.info("nuts_kernel_ns") - kns0
+    # final gather of the pooled per-dimension moments of the last run's draws through the C ABI (RCCL all-reduce inside)
+    acc = runs[-1]["acc"]
+    from ahmc_amd.shard import EngineComm
+
+    comm = EngineComm(eng, dist, dev)
+    g = comm.gather_moments()
+    mean, var = g["mean"], g["var"]
+
+    ess_n = args.ess if args.ess >= 0 else (500 if D <= 256 else 0)
     ess_info = None
-    if args.ess > 0 and rank == 0:
-        # ESS/sec (BASELINE.json's secondary metric): draws (K, N, D) written by k_nuts straight into HBM
+    if ess_n > 0:
+        # ESS/sec (BASELINE.json's secondary metric): `ess_n` more draws of the adapted chains written by k_nuts straight
+        # into HBM; ESS per draw (Geyer, per chain and dimension, min over dimensions of the mean over a 256-chain subset)
+        # × the draws/s of the timed run (whole loop incl. warm-up in the denominator)
         from ahmc_amd.diagnostics import ess as ess_fn
 
-        draws = torch.empty((args.ess, N, D), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device=f"cuda:{local_rank}")
+        draws = torch.empty((ess_n, N, D), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device=dev)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        eng.run(kernel, args.ess, 0, samples_out=draws.data_ptr())
+        eng.run(kernel, ess_n, 0, samples_out=draws.data_ptr())
         eng.sync()
-        dt_ess = time.perf_counter() - t1
         sub = draws[:, :256, :].cpu().numpy()                      # (K, 256 chains, D)
-        e = ess_fn(sub, axis=0)                                    # (256, D) per chain and dimension
-        per_chain = e.mean(axis=0)                                 # mean over the subset, per dimension
-        ess_info = {"draws_per_chain": args.ess, "seconds": dt_ess, "min_over_dims_ess_per_chain": float(per_chain.min()),
-                    "ess_per_sec": float(per_chain.min() * N * world / dt_ess),
-                    "estimator": "Geyer initial monotone sequence on FFT autocorrelation, per chain, 256-chain subset"}
+        per_dim = ess_fn(sub, axis=0).mean(axis=0)                 # mean over the subset, per dimension
+        ess_per_draw = float(per_dim.min()) / ess_n
+        te = torch.tensor([ess_per_draw], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(te, op=dist.ReduceOp.SUM)
+            te /= world
+        ess_per_draw = float(te.item())
+        ess_info = {"ess_per_sec": ess_per_draw * n_draws * N * world / med["dt_max"],
+                    "ess_per_sec_sampling_phase_only": ess_per_draw * n_draws * N * world / med["dt_draw_max"],
+                    "ess_per_draw_min_over_dims": ess_per_draw, "estimated_on_draws_per_chain": ess_n,
+                    "estimator": "Geyer initial monotone sequence on FFT autocorrelation per chain and dimension (256-chain subset per rank); "
+                                 "the reference computes no ESS (MCMCChains.jl does): parity unpinned",
+                    "definition": "ESS of the timed run's post-warm-up draws (all chains) / wall time of its whole sample loop"}
         del draws
-    tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    tn = torch.tensor([float(n_leap), float(acc["n_divergent"])], dtype=torch.float64, device=f"cuda:{local_rank}")
-    # per-dimension pooled moments of this shard; the final gather over RCCL —
-    # the same host code the 2-rank gloo test exercises (advancedhmc.jl_amd/shard.py)
-    from ahmc_amd.shard import gather_moments, pooled_moments
-
-    mom_np, n_draws = pooled_moments(acc["sum_theta"], acc["sumsq_theta"], acc["n_transitions"] * N)
-    mom = torch.tensor(mom_np, dtype=torch.float64, device=f"cuda:{local_rank}")
-    if dist is not None:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
-    mean, var, _ = gather_moments(dist, mom, n_draws, f"cuda:{local_rank}")
-    dt_max = float(tt.item())
-    total_leap = float(tn[0].item())
 
     if rank == 0:
-        B_lf = algorithmic_bytes_per_leapfrog(D, True, 8 if args.dtype == "f64" else 4)
-        per_launch_s = nuts_ns / 1e9 / n_launches  # HIP events around k_nuts, engine stream
-        achieved = (n_leap / n_launches) * B_lf / per_launch_s / 1e9  # this rank's dominant kernel
-        traffic = measured_traffic(D, N)
-        if traffic is not None:  # measured per launch of `transitions_per_launch`; rescale to this run's launches
-            hbm, tpl = traffic
-            traffic = hbm * (args.steps / n_launches) / tpl if tpl else hbm
+        B_lf = algorithmic_bytes_per_leapfrog(D, cfg["metric"], itemsize)
+        info = med["info"]
+        G, E = eng.info("group_lanes"), eng.info("elems_per_lane")
+        tname = "double" if args.dtype == "f64" else "float"
+        counters, counters_src = counters_at_head(args.config) if (args.dtype == "f64" and not args.dim and not args.chains) else (None, "counters are per config at its default size and f64")
+
+        def kernel_roof(label, mode, launches, kns, leap):
+            """VALU-issue roof of one instantiation of k_nuts from this run's launches (HIP events) and the counters at HEAD"""
+            if launches <= 0 or kns <= 0:
+                return None
+            per_launch_s = kns / 1e9 / launches
+            lf_per_s = leap / (kns / 1e9)
+            o = {"kernel": f"k_nuts<{tname},{G},{E},mode {mode}>", "phase": label, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
+                 "leapfrogs_per_launch": leap / launches, "leapfrogs_per_s_in_kernel": lf_per_s,
+                 "hbm_model_bytes_per_leapfrog": B_lf, "hbm_model_frac": lf_per_s * B_lf / 1e9 / HBM_PEAK_GBS}
+            c = (counters or {}).get(f"mode{mode}")
+            if c:
+                o["valu_instructions_per_leapfrog"] = c["valu_per_leapfrog"]
+                o["achieved"] = lf_per_s * c["valu_per_leapfrog"] / 1e9
+                o["frac"] = o["achieved"] / VALU_PEAK_GINSTR
+                o["traffic"] = c.get("hbm_bytes_per_leapfrog") and c["hbm_bytes_per_leapfrog"] * leap / launches
+                o["hbm_measured_frac"] = c.get("hbm_bytes_per_leapfrog") and lf_per_s * c["hbm_bytes_per_leapfrog"] / 1e9 / HBM_PEAK_GBS
+                o["valu_busy_fraction_under_rocprof"] = c.get("valu_busy")
+            else:
+                o["achieved"] = o["frac"] = o["traffic"] = None
+            return o
+
+        roof = None
+        if cfg["metric"] != "dense":
+            rd = kernel_roof("draws", 0, info["nuts_launches"], info["nuts_kernel_ns"], med["leap_draw"])
+            rw = kernel_roof("warm-up (adapt! inside the kernel)", 3, info["nuts_warm_launches"], info["nuts_warm_kernel_ns"], med["leap_adapt"])
+            both = [x for x in (rd, rw) if x]
+            both.sort(key=lambda x: -x["launches"] * x["avg_launch_ms"])  # dominant = more device time in the timed region
+            if both:
+                dom = both[0]
+                roof = {"bound": "valu", "unit": "Gwave-instr/s", "peak": VALU_PEAK_GINSTR, "achieved": dom["achieved"], "frac": dom["frac"],
+                        "traffic": dom["traffic"], "kernel": dom["kernel"], "counters": counters_src,
+                        "peak_definition": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+                        "dominant": dom, "other": both[1] if len(both) > 1 else None,
+                        "device_time_share_of_timed_region": sum(x["launches"] * x["avg_launch_ms"] for x in both) / 1e3 / med["dt"]}
+        else:
+            F_lf = 4 * D * D
+            tf = (med["leap_adapt"] + med["leap_draw"]) * F_lf / med["dt"] / 1e12
+            peak = F64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else F32_MFMA_PEAK_TFLOPS
+            roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": tf, "frac": tf / peak, "traffic": None,
+                    "kernel": "k_dgemm (both products of a global step) + k_d_tree, whole timed region",
+                    "algorithmic_flops_per_leapfrog": F_lf,
+                    "note": "useful leapfrogs x 4 D^2 / wall time of the whole loop (tree kernel, momenta and adaptation included)"}
         out = {
             "metric": "leapfrog-steps/sec (whole node) at n_chains x D",
-            "value": total_leap / dt_max,
+            "value": med["value"],
             "unit": "leapfrog-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_per_step": med["dt_max"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"cfg2: D={D} iso Gaussian, DiagEuclideanMetric per-chain, NUTS(0.8) MultinomialTS+GeneralisedNoUTurn "
-                            f"max_depth 10, StanHMCAdaptor ({args.adapt} untimed adaptation steps), {N} chains/GPU",
+                "workload": f"{cfg['text']}, {N} chains/GPU, D={D}; timed = the whole sample loop: {n_adapts} adapting transitions + {n_draws} draws "
+                            f"(find_good_stepsize and the initial H2D are setup, untimed)",
                 "chains_per_gpu": N, "D": D, "parallelism": f"chain-shard x{world}",
-                "mean_leapfrogs_per_transition": total_leap / (args.steps * N * world),
-                "divergent": float(tn[1].item()),
-                "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()),
+                "transitions_per_step": T, "n_adapts": n_adapts, "n_draws": n_draws,
+                "leapfrogs": {"adapt": med["leap_adapt_all"], "draw": med["leap_draw_all"]},
+                "fits_quoted_config": world == cfg["quoted_gpus"],
+                "runs": [x["value"] for x in runs], "reported": "median run",
+                "warmup_phase": {"value": med["leap_adapt_all"] / med["dt_adapt_max"] if n_adapts else None,
+                                 "ms_per_transition": med["dt_adapt_max"] / max(n_adapts, 1) * 1e3,
+                                 "mean_leapfrogs_per_transition": med["leap_adapt_all"] / max(n_adapts * N * world, 1),
+                                 "divergent": med["div_adapt_all"]},
+                "post_adaptation": {"value": med["leap_draw_all"] / med["dt_draw_max"],
+                                    "ms_per_transition": med["dt_draw_max"] / n_draws * 1e3,
+                                    "mean_leapfrogs_per_transition": med["leap_draw_all"] / (n_draws * N * world),
+                                    "divergent": med["div_all"]},
+                "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()) if cfg["target"] == "iso" else None,
+                "gathered_draws": g["n_draws"], "gather": g["how"],
                 "ess": ess_info,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_nuts<%s,%d,%d,mode 0,iso>" % ("double" if args.dtype == "f64" else "float", eng.info("group_lanes"), eng.info("elems_per_lane")),
-                "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_leapfrog": B_lf, "avg_launch_ms": per_launch_s * 1e3,
-                "launches": n_launches, "transitions_per_launch": args.steps / n_launches,
-                "timed_region_ms_on_stream": kernel_ms,
-                "leapfrogs_per_launch": n_leap / n_launches,
-                "note": "state-through-memory model of SURVEY 8d: a fused kernel keeps the trajectory in registers/LDS, so frac > 1 "
-                        "is expected; the kernel is VALU-issue bound (see issue_bound)",
-                "issue_bound": measured_issue(D, N),
-            },
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:  # (the contract: rank 0 at N = 1 only)
             try:
                 cores = usable_cores()
-                # bounded sample sized to the host: 256 chains per usable core (capped at the GPU's own
-                # N), the same adaptation, then `cpu_steps` timed sampling transitions (~10-30 s in all)
                 cpu_chains = args.cpu_chains or min(N, 256 * cores)
-                cpu_steps = args.cpu_steps
-                t_all = time.perf_counter()
-                v, cdt, cores = cpu_baseline(A, D, args.adapt, cpu_steps, args.seed, cpu_chains, cores)
+                # sized for ~15 s: the oracle does ≈1.3e6 leapfrog/s per core on cfg2 (scales with 128 / D), ≈35 leapfrogs per transition
+                if args.cpu_transitions:
+                    cpu_T = args.cpu_transitions
+                else:
+                    rate = 1.3e6 * cores * 128.0 / D
+                    lpt = max(out["config"]["post_adaptation"]["mean_leapfrogs_per_transition"], out["config"]["warmup_phase"]["mean_leapfrogs_per_transition"] or 0)
+                    cpu_T = int(max(40, min(n_total, 15.0 * rate / (cpu_chains * lpt))))
+                ca = int(round(cpu_T * args.adapt_fraction))
+                v, v_draw, cdt, cores = cpu_baseline(A, cfg, ca, cpu_T - ca, seed, cpu_chains, cores)
+                # single thread: what the reference's broadcast path uses (SURVEY §8d (i)); a smaller sample of the same loop
+                c1 = max(8, cpu_chains // (8 * cores))
+                t1n = max(20, cpu_T // 4)
+                v1, _, cdt1, _ = cpu_baseline(A, cfg, int(round(t1n * args.adapt_fraction)), t1n - int(round(t1n * args.adapt_fraction)), seed, c1, 1)
                 out["cpu_baseline"] = {
                     "value": v, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
-                    "sample": f"{cpu_chains} chains x D={D}, same kernel/adaptor, {cpu_steps} timed transitions "
-                              f"({cdt:.1f} s) after {args.adapt} adaptation steps ({time.perf_counter() - t_all:.1f} s in all); "
-                              f"C++ restatement of the reference (oracle/), OpenMP over chains, {cores} threads = the container's "
+                    "sample": f"{cpu_chains} chains x D={D}, the same sample loop ({ca} adapting transitions + {cpu_T - ca} draws, same kernel / adaptor), "
+                              f"{cdt:.1f} s; C++ restatement of the reference (oracle/), OpenMP over chains, {cores} threads = the container's "
                               f"CPU quota ({os.cpu_count()} logical CPUs visible), not Julia",
+                    "post_adaptation_value": v_draw,
+                    "single_thread": {"value": v1, "cores": 1, "sample": f"{c1} chains, {t1n} transitions of the same loop, {cdt1:.1f} s"},
                 }
             except Exception as ex:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out))
+    comm.close()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

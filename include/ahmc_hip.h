@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHMC_ABI_VERSION 2
+#define AHMC_ABI_VERSION 3
 
 typedef struct ahmc_ctx ahmc_ctx;
 
@@ -222,7 +222,13 @@ int32_t ahmc_adapt(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void* theta
  * metric: WelfordVar (src/adaptation/massmatrix.jl:64-157) or NutpieVar (:160-250: Welford
  * estimators of the positions AND of the gradients, M⁻¹ = sqrt(var θ / var ∇)).  Call before
  * ahmc_adaptor_init.                                                                          */
-enum { AHMC_VAR_WELFORD = 0, AHMC_VAR_NUTPIE = 1 };
+/* AHMC_VAR_POOLED (no reference counterpart — in matrix mode the reference resizes the estimator
+ * to (D,N), one per chain, massmatrix.jl:103-121): the metric stays ONE shared (D,) M⁻¹.  Every chain still runs its
+ * own WelfordVar (:141-150); an update pools them (Chan's merge of equal-count partitions: μ = mean_c μ_c,
+ * M = Σ_c M_c + n Σ_c (μ_c − μ)², n_tot = n·N) over the chains of this context and, when a communicator is set
+ * (ahmc_comm_init / ahmc_set_comm), over all ranks — one all-gather of 2·D + 1 doubles per update (with
+ * StanHMCAdaptor: per window end) — and applies get_estimation (:152-157) to the pooled (n_tot, M).              */
+enum { AHMC_VAR_WELFORD = 0, AHMC_VAR_NUTPIE = 1, AHMC_VAR_POOLED = 2 };
 int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t estimator);
 /* adapt! on an explicit phase point (src/adaptation/Adaptation.jl:24-26 PositionOrPhasePoint): as
  * ahmc_adapt plus grad (D,N) = z.ℓπ.gradient, which NutpieVar needs; with NutpieVar a theta
@@ -235,6 +241,31 @@ int32_t ahmc_adapt_point(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void*
 int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t window_size,
                           int64_t n_adapts, int64_t* window_start, int64_t* window_end,
                           int64_t* splits, int32_t cap, int32_t* n_splits);
+
+/* Checkpoint / resume of the adaptor (the reference's state is a value, HMCState(i, transition,
+ * metric, κ, adaptor) src/abstractmcmc.jl:11-27; resuming = calling step again with it).  The metric and the nominal
+ * step sizes are fields of h / κ: save and restore them with ahmc_get/set_metric and ahmc_get/set_stepsize, the
+ * phase point with ahmc_get/set_phasepoint (or ahmc_set_position) — restore those FIRST, then the adaptor.  `da`:
+ * T (5,N) = DAState m, ϵ, μ, x̄, H̄ (stepsize.jl:13-23; m as T); `welford`: T (n_welford, D, N) = WelfordVar μ, M, var
+ * (massmatrix.jl:84-101) [+ NutpieVar's gradient estimator μ_g, M_g (:172-190)].  Either array may be NULL in get
+ * (only the header is filled: call once to learn has_da / n_welford).  A run resumed this way continues bit for bit.
+ * DenseEuclideanMetric adaptors (WelfordCov) are AHMC_ERR_UNSUPPORTED.                                           */
+typedef struct {
+  int32_t kind;           /* AHMC_ADAPT_*                                                    */
+  int32_t var_estimator;  /* AHMC_VAR_*                                                      */
+  int32_t init_buffer, term_buffer, window_size; /* StanHMCAdaptor(…; 75, 50, 25)            */
+  int32_t adapting;       /* the adaptor has not seen iteration n_adapts yet                 */
+  int32_t has_da;         /* `da` is meaningful                                              */
+  int32_t n_welford;      /* 0, 3 or 5 (D,N) arrays in `welford`                             */
+  double delta;           /* target acceptance rate                                          */
+  int64_t stan_i;         /* StanHMCAdaptorState.i (stan_adaptor.jl:7-11)                    */
+  int64_t n_adapts;       /* n_adapts the window schedule was built for (0: not yet)         */
+  int64_t wv_n;           /* WelfordVar.n                                                    */
+  int64_t iteration;      /* the Philox iteration counter (transitions done)                 */
+} ahmc_adaptor_state;
+int32_t ahmc_get_adaptor_state(ahmc_ctx* ctx, ahmc_adaptor_state* state, void* da, void* welford);
+int32_t ahmc_set_adaptor_state(ahmc_ctx* ctx, const ahmc_adaptor_state* state, const void* da,
+                               const void* welford);
 
 /* ------------------------------------------------------------------------------------------ */
 /* driver: sample(rng, h, κ, θ, n_samples, adaptor, n_adapts) (src/sampler.jl:159-248)        */
@@ -264,6 +295,12 @@ typedef struct {
  * (pinned host memory keeps the call asynchronous; a pageable buffer must stay valid until then too). */
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples,
                     int64_t n_adapts, int32_t drop_warmup, void* samples_out);
+/* The same loop from iteration i_first on (i = i_first … n_samples; ahmc_sample = i_first 1): the continuation of a
+ * run that was checkpointed after iteration i_first − 1 (ahmc_get/set_adaptor_state) — also mid-warm-up, where the
+ * window schedule and adapt!'s iteration argument depend on the absolute i.  samples_out is indexed by the absolute
+ * iteration as in ahmc_sample (a resumed call hands in the full-size buffer or NULL).                             */
+int32_t ahmc_sample_from(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_first, int64_t n_samples,
+                         int64_t n_adapts, int32_t drop_warmup, void* samples_out);
 
 /* running accumulators over kept transitions: Σ n_steps (all chains), number of kept
  * transitions, number of divergent transitions, per-chain Σθ and Σθ² (D,N) (may be NULL)     */
@@ -315,6 +352,40 @@ int32_t ahmc_ext_pending(ahmc_ctx* ctx, int64_t* n_pending, int32_t* chains_out,
 int32_t ahmc_ext_advance(ahmc_ctx* ctx, const void* lp, const void* grad_neg);
 int32_t ahmc_ext_cancel(ahmc_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------ */
+/* multi-GPU: the final gather of a chain-sharded run                           */
+/*
+ * Chains are independent, so a sharded run exchanges nothing while sampling (each rank: its own context, Philox
+ * chain_offset = its first global chain); the reference has no counterpart (no collective anywhere).
+ * The only communication is at the end — and at the window ends of AHMC_VAR_POOLED — over RCCL / xGMI.
+ * The communicator is either handed in (ahmc_set_comm: an ncclComm_t the host made with its own RCCL binding; the
+ * library resolves ncclAllReduce / ncclAllGather from the RCCL copy already loaded in the process, so the handle and
+ * the entry points match) or made here: rank 0 calls ahmc_comm_unique_id, the host broadcasts the 128 bytes by any
+ * means it has, every rank calls ahmc_comm_init.  No communicator = a world of one.                            */
+#define AHMC_UNIQUE_ID_BYTES 128
+int32_t ahmc_comm_unique_id(void* id_out /* AHMC_UNIQUE_ID_BYTES */);
+int32_t ahmc_comm_init(ahmc_ctx* ctx, const void* id, int32_t n_ranks, int32_t rank); /* owned by ctx */
+int32_t ahmc_set_comm(ahmc_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank);  /* caller's; NULL detaches */
+/* Pooled moments of the kept draws of ALL ranks (the accumulators of ahmc_sample): a device reduction over the
+ * chains, one ncclAllReduce of 2·D + 3 doubles, then mean[D], var[D] (host doubles, may be NULL), the number of
+ * draws, Σ n_steps and the number of divergent transitions.  Every rank receives the same values.              */
+int32_t ahmc_gather_moments(ahmc_ctx* ctx, double* mean, double* var, int64_t* n_draws,
+                            int64_t* total_n_steps, int64_t* n_divergent);
+/* ncclAllGather of the positions: theta_all (DEVICE pointer, (D, N, n_ranks) elements of T) receives rank r's (D,N)
+ * block at offset r·D·N.  All ranks must hold the same N.                                                       */
+int32_t ahmc_gather_state(ahmc_ctx* ctx, void* theta_all);
+
+/* ------------------------------------------------------------------------------------------ */
+/* diagnostics on the device                                             */
+/* EBFMI(Es) = mean(diff(Es).^2) / var(Es) (src/diagnosis.jl:1-3) per chain over the energies of the kept transitions
+ * since the accumulators were last reset (ahmc_sample resets them at its first kept transition): out T[N], NaN for
+ * fewer than two transitions.  Running sums kept by the transition kernels; no per-iteration read-back.         */
+int32_t ahmc_ebfmi(ahmc_ctx* ctx, void* out);
+/* Effective sample size of every (dimension, chain) series of `draws` = the (D, N, n_draws) buffer ahmc_sample fills
+ * (device pointer): out T (D,N), host or device.  Geyer's initial monotone sequence on the autocovariances.  The
+ * reference computes no ESS (MCMCChains.jl does; no reference test calls it): the definition is this engine's.  */
+int32_t ahmc_ess(ahmc_ctx* ctx, const void* draws, int64_t n_draws, void* out);
+
 /* Engine introspection (no reference counterpart; used by bench.py to price the roofline per launch
  * and by the tests to assert which thread geometry ran).                                        */
 typedef enum {
@@ -323,7 +394,9 @@ typedef enum {
   AHMC_INFO_NUTS_LAUNCHES = 2,    /* launches of the dominant NUTS kernel since ahmc_create      */
   AHMC_INFO_NUTS_BATCH = 3,       /* transitions per NUTS launch in the sampling phase           */
   AHMC_INFO_ITERATION = 4,        /* transitions done (the Philox iteration counter)             */
-  AHMC_INFO_NUTS_KERNEL_NS = 5    /* Σ device time of those launches, ns (HIP events; synchronises) */
+  AHMC_INFO_NUTS_KERNEL_NS = 5,   /* Σ device time of those launches, ns (HIP events; synchronises) */
+  AHMC_INFO_NUTS_WARM_LAUNCHES = 6,  /* the same two for the warm-up instantiation of the kernel (adapt! inside)  */
+  AHMC_INFO_NUTS_WARM_KERNEL_NS = 7
 } ahmc_info;
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out);
 

@@ -804,6 +804,13 @@ struct Ctx : CtxBase {
   // accumulators
   int64_t acc_nsteps = 0, acc_ntrans = 0, acc_ndiv = 0;
   std::vector<T> acc_sum, acc_sumsq;
+  std::vector<T> acc_energy;  // (5,N): n, E_prev, Σ(ΔE)², mean(E), M2(E) over the kept transitions (ahmc_ebfmi)
+  int64_t windows_n_adapts = 0;
+  bool adapting = false;
+  // cross-rank hook of the CPU checker (there is no RCCL here): the multi-rank tests hand in an all-gather over gloo
+  int (*xgather)(const double* mine, double* all, int64_t count, void* user) = nullptr;
+  void* xgather_user = nullptr;
+  int x_ranks = 1, x_rank = 0;
   bool ref_compat = false;
   // External target, ask / tell (ahmc_ext_*): every chain runs the ordinary scalar code of this file inside its own
   // coroutine; the target evaluation of an AHMC_TARGET_EXTERNAL context parks the coroutine until the caller has
@@ -1052,9 +1059,19 @@ void accumulate(Ctx<T>* c) {
     c->acc_sumsq.assign(c->D * c->N, T(0));
   }
   c->acc_ntrans += 1;
+  if (c->acc_energy.empty()) c->acc_energy.assign(5 * c->N, T(0));
   for (int64_t i = 0; i < c->N; ++i) {
     c->acc_nsteps += c->stat[i].n_steps;
     c->acc_ndiv += c->stat[i].numerical_error;
+    // running sums for EBFMI (src/diagnosis.jl:1-3), the recursion the HIP kernels use (accumulate_energy)
+    T* ea = c->acc_energy.data();
+    const T H = c->stat[i].hamiltonian_energy, n0 = ea[i], prev = ea[c->N + i], n = n0 + 1;
+    if (n0 > 0) { const T d = H - prev; ea[2 * c->N + i] += d * d; }
+    const T mean = ea[3 * c->N + i], delta = H - mean, mean2 = mean + delta / n;
+    ea[3 * c->N + i] = mean2;
+    ea[4 * c->N + i] += delta * (H - mean2);
+    ea[i] = n;
+    ea[c->N + i] = H;
   }
 #pragma omp parallel for schedule(static)
   for (int64_t k = 0; k < c->D * c->N; ++k) {
@@ -1406,6 +1423,46 @@ void wv_update(Ctx<T>* c) {  // update! (:60-62) + get_estimation (:152-157)
   }
 }
 
+// AHMC_VAR_POOLED (include/ahmc_hip.h): the per-chain WelfordVar states pooled into one (D,) estimate — Chan's merge
+// of equal-count partitions over the chains, then over the ranks (in rank order), then get_estimation (:152-157)
+template <class T>
+int wv_update_pooled(Ctx<T>* c) {
+  if (c->wv_n < c->wv_nmin) return AHMC_OK;
+  const int64_t D = c->D, N = c->N;
+  const double n = (double)c->wv_n;
+  std::vector<double> part((size_t)(2 * D + 1));
+  for (int64_t d = 0; d < D; ++d) {
+    double s_mu = 0, s_M = 0;
+    for (int64_t ch = 0; ch < N; ++ch) { s_mu += (double)c->wv_mu[d + ch * D]; s_M += (double)c->wv_M[d + ch * D]; }
+    const double mean = s_mu / (double)N;
+    double s_d = 0;
+    for (int64_t ch = 0; ch < N; ++ch) { const double df = (double)c->wv_mu[d + ch * D] - mean; s_d += df * df; }
+    part[(size_t)d] = mean;
+    part[(size_t)(D + d)] = s_M + n * s_d;
+  }
+  part[(size_t)(2 * D)] = n * (double)N;
+  std::vector<double> all = part;
+  int R = 1;
+  if (c->xgather && c->x_ranks > 1) {
+    R = c->x_ranks;
+    all.assign(part.size() * (size_t)R, 0.0);
+    if (c->xgather(part.data(), all.data(), (int64_t)part.size(), c->xgather_user) != 0) return fail(c, AHMC_ERR_RUNTIME, "pooled update: the all-gather hook failed");
+  }
+  const size_t stride = (size_t)(2 * D + 1);
+  for (int64_t d = 0; d < D; ++d) {
+    double na = all[(size_t)(2 * D)], mu = all[(size_t)d], M = all[(size_t)(D + d)];
+    for (int p2 = 1; p2 < R; ++p2) {
+      const double nb = all[p2 * stride + 2 * D], mub = all[p2 * stride + d], Mb = all[p2 * stride + D + d];
+      const double delta = mub - mu, nt = na + nb;
+      mu = mu + delta * (nb / nt);
+      M = M + Mb + delta * delta * (na * nb / nt);
+      na = nt;
+    }
+    c->wv_var[d] = (T)(na / ((na + 5) * (na - 1)) * M + 1e-3 * (5 / (na + 5)));
+  }
+  return AHMC_OK;
+}
+
 template <class T>
 void wc_reset(Ctx<T>* c) {  // reset!(wc) (massmatrix.jl:316-321)
   c->wc_n = 0;
@@ -1445,9 +1502,12 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
   const bool has_cov = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DENSE;
   if (has_mm && c->var_estimator == AHMC_VAR_NUTPIE && th_ext && !g_ext)  // massmatrix.jl:234-236
     return fail(c, AHMC_ERR_ARGUMENT, "`NutpieVar` adaptation requires position and gradient information!");
-  if (i == 1 && c->adapt_kind == AHMC_ADAPT_STAN) {  // initialize! (stan_adaptor.jl:105-115)
+  if (c->adapt_kind == AHMC_ADAPT_STAN && (i == 1 || c->windows_n_adapts != n_adapts)) {  // initialize! (stan_adaptor.jl:105-115)
     c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);
+    c->windows_n_adapts = n_adapts;
   }
+  if (i == n_adapts) c->adapting = false;
+  const bool pooled = has_mm && c->var_estimator == AHMC_VAR_POOLED;
   if (c->adapt_kind == AHMC_ADAPT_STAN) {  // adapt!(tp::StanHMCAdaptor, ...) (:137-159)
     c->stan_i += 1;
     da_adapt(c, alpha_ext);
@@ -1455,7 +1515,9 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
     if (in_window && has_mm) {
       wv_push(c, th_ext, g_ext);
-      if (window_end) wv_update(c);
+      if (window_end) {
+        if (pooled) { int rc = wv_update_pooled(c); if (rc) return rc; } else wv_update(c);
+      }
     }
     if (in_window && has_cov) {
       wc_push(c, th_ext);
@@ -1468,7 +1530,10 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     }
   } else {
     if (has_ss) da_adapt(c, alpha_ext);  // NaiveHMCAdaptor: ssa then pc (Adaptation.jl:52-60)
-    if (has_mm) { wv_push(c, th_ext, g_ext); wv_update(c); }
+    if (has_mm) {
+      wv_push(c, th_ext, g_ext);
+      if (pooled) { int rc = wv_update_pooled(c); if (rc) return rc; } else wv_update(c);
+    }
     if (has_cov) { wc_push(c, th_ext); wc_update(c); }
   }
   if (i == n_adapts && has_ss) {  // finalize! (stepsize.jl:55-62): ϵ = exp(x̄)
@@ -1476,7 +1541,7 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
   }
   // update(h, adaptor), update(κ, adaptor) (src/sampler.jl:3-22)
   if (has_mm) {
-    int rc = set_metric(c, AHMC_METRIC_DIAG, c->wv_var.data(), (int64_t)c->wv_var.size());
+    int rc = set_metric(c, AHMC_METRIC_DIAG, c->wv_var.data(), pooled ? c->D : (int64_t)c->wv_var.size());
     if (rc) return rc;
   }
   if (has_cov) {  // update(h, adaptor): DenseEuclideanMetric(getM⁻¹) recomputes the Cholesky factor (metric.jl:104-109)
@@ -1497,6 +1562,11 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
   c->da_delta = (T)delta;
   c->stan_init = ib; c->stan_term = tb; c->stan_window = ws;
   c->stan_i = 0;
+  c->windows_n_adapts = 0;
+  c->adapting = kind != AHMC_ADAPT_NONE;
+  if (kind != AHMC_ADAPT_NONE && kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG && c->var_estimator == AHMC_VAR_POOLED &&
+      c->metric_per_chain)
+    return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: AHMC_VAR_POOLED adapts ONE shared (D,) M⁻¹: set a (D,) DiagEuclideanMetric");
   // NesterovDualAveraging(δ, ϵ) → DAState(ϵ) (stepsize.jl:25-33)
   c->da_eps = c->eps_nom;
   c->da_m.assign(c->N, 0);
@@ -1933,7 +2003,7 @@ int32_t ahmc_adapt_point(ahmc_ctx* ctx, int64_t i, int64_t n_adapts, const void*
 
 int32_t ahmc_set_var_estimator(ahmc_ctx* ctx, int32_t est) {
   FOR_CTX_MUT(ctx, {
-    if (est != AHMC_VAR_WELFORD && est != AHMC_VAR_NUTPIE) return fail(c, AHMC_ERR_ARGUMENT, "set_var_estimator: unknown estimator");
+    if (est != AHMC_VAR_WELFORD && est != AHMC_VAR_NUTPIE && est != AHMC_VAR_POOLED) return fail(c, AHMC_ERR_ARGUMENT, "set_var_estimator: unknown estimator");
     c->var_estimator = est;
     return AHMC_OK;
   });
@@ -1950,22 +2020,38 @@ int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t wind
   return AHMC_OK;
 }
 
+// (one internal body, reached without the PLT: a process may hold the HIP engine AND the CPU checker, both exporting
+// these names — a call from one exported function to another could bind to the other library's)
+static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_first, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup,
+                                void* samples_out);
+
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup, void* samples_out) {
+  return sample_from_impl(ctx, cfg, 1, n_samples, n_adapts, drop_warmup, samples_out);
+}
+
+int32_t ahmc_sample_from(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_first, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup,
+                         void* samples_out) {
+  return sample_from_impl(ctx, cfg, i_first, n_samples, n_adapts, drop_warmup, samples_out);
+}
+
+static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_first, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup,
+                                void* samples_out) {
   FOR_CTX_MUT(ctx, {
     if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample: cfg is NULL");
+    if (i_first < 1) return fail(c, AHMC_ERR_ARGUMENT, "sample_from: i_first must be >= 1");
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "sample before set_position");
     if (drop_warmup && c->adapt_kind == AHMC_ADAPT_NONE)
       return fail(c, AHMC_ERR_ARGUMENT, "Cannot drop warmup samples if there is no adaptation phase.");  // src/sampler.jl:172
     T* so = static_cast<T*>(samples_out);
     bool reset_done = false;
-    for (int64_t i = 1; i <= n_samples; ++i) {  // src/sampler.jl:182-228
+    for (int64_t i = i_first; i <= n_samples; ++i) {  // src/sampler.jl:182-228
       int rc = cfg->nuts ? nuts_transition_all(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, (T)cfg->refresh_alpha)
                          : hmc_transition(c, cfg->L, cfg->lambda, cfg->sampler, (T)cfg->refresh_alpha);
       if (rc) return rc;
       rc = adapt(c, i, n_adapts);
       if (rc) return rc;
       if (!drop_warmup || i > n_adapts) {
-        if (!reset_done) { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); reset_done = true; }
+        if (!reset_done) { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); c->acc_energy.clear(); reset_done = true; }
         accumulate(c);
         int64_t j = i - (drop_warmup ? n_adapts : 0);
         if (so) std::memcpy(so + (j - 1) * c->D * c->N, c->th.data(), sizeof(T) * c->D * c->N);
@@ -1988,7 +2074,180 @@ int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transit
 }
 
 int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
-  FOR_CTX_MUT(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); return AHMC_OK; });
+  FOR_CTX_MUT(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); c->acc_energy.clear(); return AHMC_OK; });
+}
+
+// ---- adaptor checkpoint / resume, the final gather, device-side diagnostics (ABI v3) ----
+int32_t ahmc_get_adaptor_state(ahmc_ctx* ctx, ahmc_adaptor_state* s, void* da_out, void* wv_out) {
+  FOR_CTX(ctx, {
+    if (!s) return fail(c, AHMC_ERR_ARGUMENT, "get_adaptor_state: state is NULL");
+    const bool has_mm = c->adapt_kind != AHMC_ADAPT_NONE && c->adapt_kind != AHMC_ADAPT_STEPSIZE;
+    if (has_mm && c->metric_kind == AHMC_METRIC_DENSE)
+      return fail(c, AHMC_ERR_UNSUPPORTED, "get_adaptor_state: the WelfordCov state of a DenseEuclideanMetric adaptor does not round-trip yet");
+    std::memset(s, 0, sizeof(*s));
+    s->kind = c->adapt_kind; s->var_estimator = c->var_estimator;
+    s->init_buffer = c->stan_init; s->term_buffer = c->stan_term; s->window_size = c->stan_window;
+    s->adapting = c->adapting ? 1 : 0;
+    s->delta = (double)c->da_delta;
+    s->stan_i = c->stan_i; s->n_adapts = c->windows_n_adapts; s->wv_n = c->wv_n; s->iteration = (int64_t)c->iteration;
+    s->n_welford = (has_mm && c->metric_kind == AHMC_METRIC_DIAG && !c->wv_mu.empty()) ? (c->var_estimator == AHMC_VAR_NUTPIE ? 5 : 3) : 0;
+    s->has_da = (c->adapt_kind != AHMC_ADAPT_NONE && c->adapt_kind != AHMC_ADAPT_MASSMATRIX && !c->da_m.empty()) ? 1 : 0;
+    const size_t N = (size_t)c->N, DN = (size_t)c->D * N;
+    if (da_out && s->has_da) {
+      T* o = static_cast<T*>(da_out);
+      for (size_t i = 0; i < N; ++i) { o[i] = (T)c->da_m[i]; o[N + i] = c->da_eps[i]; o[2 * N + i] = c->da_mu[i]; o[3 * N + i] = c->da_xbar[i]; o[4 * N + i] = c->da_Hbar[i]; }
+    }
+    if (wv_out && s->n_welford) {
+      T* o = static_cast<T*>(wv_out);
+      const std::vector<T>* src[5] = {&c->wv_mu, &c->wv_M, &c->wv_var, &c->wg_mu, &c->wg_M};
+      for (int k = 0; k < s->n_welford; ++k) std::memcpy(o + (size_t)k * DN, src[k]->data(), sizeof(T) * DN);
+    }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_adaptor_state(ahmc_ctx* ctx, const ahmc_adaptor_state* s, const void* da_in, const void* wv_in) {
+  FOR_CTX_MUT(ctx, {
+    if (!s) return fail(c, AHMC_ERR_ARGUMENT, "set_adaptor_state: state is NULL");
+    if (s->kind < AHMC_ADAPT_NONE || s->kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "set_adaptor_state: unknown adaptor kind");
+    if (s->has_da && !da_in) return fail(c, AHMC_ERR_ARGUMENT, "set_adaptor_state: the state has a dual-averaging part but da is NULL");
+    if (s->n_welford && !wv_in) return fail(c, AHMC_ERR_ARGUMENT, "set_adaptor_state: the state has a variance estimator but welford is NULL");
+    c->var_estimator = s->var_estimator;
+    int rc = adaptor_init(c, s->kind, s->delta, s->init_buffer, s->term_buffer, s->window_size);
+    if (rc) return rc;
+    c->adapting = s->adapting != 0;
+    c->stan_i = s->stan_i; c->wv_n = s->wv_n; c->iteration = (uint64_t)s->iteration; c->windows_n_adapts = s->n_adapts;
+    if (s->kind == AHMC_ADAPT_STAN && s->n_adapts > 0) c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, s->n_adapts);
+    const size_t N = (size_t)c->N, DN = (size_t)c->D * N;
+    if (s->has_da) {
+      const T* in = static_cast<const T*>(da_in);
+      for (size_t i = 0; i < N; ++i) { c->da_m[i] = (int32_t)in[i]; c->da_eps[i] = in[N + i]; c->da_mu[i] = in[2 * N + i]; c->da_xbar[i] = in[3 * N + i]; c->da_Hbar[i] = in[4 * N + i]; }
+    }
+    if (s->n_welford) {
+      if (c->wv_mu.empty()) return fail(c, AHMC_ERR_STATE, "set_adaptor_state: a variance estimator needs a DiagEuclideanMetric (set the metric first)");
+      if (s->n_welford == 5 && c->wg_mu.empty()) return fail(c, AHMC_ERR_STATE, "set_adaptor_state: NutpieVar state for a WelfordVar adaptor");
+      const T* in = static_cast<const T*>(wv_in);
+      std::vector<T>* dst[5] = {&c->wv_mu, &c->wv_M, &c->wv_var, &c->wg_mu, &c->wg_M};
+      for (int k = 0; k < s->n_welford; ++k) std::memcpy(dst[k]->data(), in + (size_t)k * DN, sizeof(T) * DN);
+    }
+    return AHMC_OK;
+  });
+}
+
+// the CPU checker has no RCCL: a world larger than one is wired by the test harness through ahmco_set_allgather
+int32_t ahmc_comm_unique_id(void* id_out) {
+  if (!id_out) return AHMC_ERR_ARGUMENT;
+  std::memset(id_out, 0, AHMC_UNIQUE_ID_BYTES);
+  return AHMC_OK;
+}
+int32_t ahmc_comm_init(ahmc_ctx* ctx, const void* id, int32_t n_ranks, int32_t rank) {
+  FOR_CTX_MUT(ctx, {
+    (void)id;
+    if (n_ranks != 1 || rank != 0) return fail(c, AHMC_ERR_UNSUPPORTED, "comm_init: the CPU checker has no RCCL (multi-rank tests use ahmco_set_allgather)");
+    c->x_ranks = 1; c->x_rank = 0;
+    return AHMC_OK;
+  });
+}
+int32_t ahmc_set_comm(ahmc_ctx* ctx, void* comm, int32_t n_ranks, int32_t rank) {
+  FOR_CTX_MUT(ctx, {
+    if (comm) return fail(c, AHMC_ERR_UNSUPPORTED, "set_comm: the CPU checker has no RCCL (multi-rank tests use ahmco_set_allgather)");
+    (void)n_ranks; (void)rank;
+    c->x_ranks = 1; c->x_rank = 0; c->xgather = nullptr;
+    return AHMC_OK;
+  });
+}
+int32_t ahmco_set_allgather(ahmc_ctx* ctx, int (*fn)(const double*, double*, int64_t, void*), void* user, int32_t n_ranks, int32_t rank) {
+  FOR_CTX_MUT(ctx, {
+    c->xgather = fn; c->xgather_user = user; c->x_ranks = fn ? n_ranks : 1; c->x_rank = fn ? rank : 0;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_gather_moments(ahmc_ctx* ctx, double* mean, double* var, int64_t* n_draws, int64_t* total_n_steps, int64_t* n_divergent) {
+  FOR_CTX(ctx, {
+    const int64_t D = c->D, N = c->N;
+    std::vector<double> part((size_t)(2 * D + 3), 0.0);
+    if (!c->acc_sum.empty())
+      for (int64_t d = 0; d < D; ++d)
+        for (int64_t ch = 0; ch < N; ++ch) { part[(size_t)d] += (double)c->acc_sum[d + ch * D]; part[(size_t)(D + d)] += (double)c->acc_sumsq[d + ch * D]; }
+    part[(size_t)(2 * D)] = (double)c->acc_nsteps;
+    part[(size_t)(2 * D + 1)] = (double)c->acc_ndiv;
+    part[(size_t)(2 * D + 2)] = (double)c->acc_ntrans * (double)N;
+    std::vector<double> tot = part;
+    if (c->xgather && c->x_ranks > 1) {
+      std::vector<double> all(part.size() * (size_t)c->x_ranks);
+      if (c->xgather(part.data(), all.data(), (int64_t)part.size(), c->xgather_user) != 0) return fail(c, AHMC_ERR_RUNTIME, "gather_moments: the all-gather hook failed");
+      std::fill(tot.begin(), tot.end(), 0.0);
+      for (int r = 0; r < c->x_ranks; ++r)
+        for (size_t k = 0; k < part.size(); ++k) tot[k] += all[(size_t)r * part.size() + k];
+    }
+    const double n = tot[(size_t)(2 * D + 2)];
+    for (int64_t d = 0; d < D; ++d) {
+      const double m = n > 0 ? tot[(size_t)d] / n : 0.0;
+      if (mean) mean[d] = m;
+      if (var) var[d] = n > 0 ? tot[(size_t)(D + d)] / n - m * m : 0.0;
+    }
+    if (n_draws) *n_draws = (int64_t)(n + 0.5);
+    if (total_n_steps) *total_n_steps = (int64_t)(tot[(size_t)(2 * D)] + 0.5);
+    if (n_divergent) *n_divergent = (int64_t)(tot[(size_t)(2 * D + 1)] + 0.5);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_gather_state(ahmc_ctx* ctx, void* theta_all) {
+  FOR_CTX(ctx, {
+    if (!theta_all) return fail(c, AHMC_ERR_ARGUMENT, "gather_state: theta_all is NULL");
+    if (c->x_ranks > 1) return fail(c, AHMC_ERR_UNSUPPORTED, "gather_state: the CPU checker gathers positions in the test harness");
+    std::memcpy(theta_all, c->th.data(), sizeof(T) * c->D * c->N);
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_ebfmi(ahmc_ctx* ctx, void* out) {
+  FOR_CTX(ctx, {
+    if (!out) return fail(c, AHMC_ERR_ARGUMENT, "ebfmi: out is NULL");
+    T* o = static_cast<T*>(out);
+    for (int64_t i = 0; i < c->N; ++i) {
+      if (c->acc_energy.empty() || c->acc_energy[i] < 2) { o[i] = std::numeric_limits<T>::quiet_NaN(); continue; }
+      const T n = c->acc_energy[i], sd2 = c->acc_energy[2 * c->N + i], M2 = c->acc_energy[4 * c->N + i];
+      o[i] = (sd2 / (n - 1)) / (M2 / (n - 1));
+    }
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_ess(ahmc_ctx* ctx, const void* draws_v, int64_t K, void* out_v) {
+  FOR_CTX(ctx, {
+    if (!draws_v || !out_v) return fail(c, AHMC_ERR_ARGUMENT, "ess: NULL argument");
+    if (K < 4) return fail(c, AHMC_ERR_ARGUMENT, "ess: at least 4 draws per chain");
+    const T* draws = static_cast<const T*>(draws_v);
+    T* out = static_cast<T*>(out_v);
+    const int64_t DN = c->D * c->N;
+    _Pragma("omp parallel for schedule(static)")
+    for (int64_t s2 = 0; s2 < DN; ++s2) {
+      double mean = 0;
+      for (int64_t k = 0; k < K; ++k) mean += (double)draws[k * DN + s2];
+      mean /= (double)K;
+      auto gamma = [&](int64_t t) {
+        double g = 0;
+        for (int64_t k = 0; k + t < K; ++k) g += ((double)draws[k * DN + s2] - mean) * ((double)draws[(k + t) * DN + s2] - mean);
+        return g / (double)K;
+      };
+      const double g0 = gamma(0);
+      if (!(g0 > 0)) { out[s2] = (T)K; continue; }
+      double tau = -1, prev = 1e300;
+      for (int64_t t = 0; 2 * t + 1 < K; ++t) {
+        double P = (gamma(2 * t) + gamma(2 * t + 1)) / g0;
+        if (!(P > 0)) break;
+        P = P < prev ? P : prev;
+        prev = P;
+        tau += 2 * P;
+      }
+      if (tau < 1.0 / (double)K) tau = 1.0 / (double)K;
+      out[s2] = (T)((double)K / tau);
+    }
+    return AHMC_OK;
+  });
 }
 
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
@@ -1997,7 +2256,7 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
     switch (what) {  // the scalar oracle has no thread geometry: one "lane" holding the whole chain
       case AHMC_INFO_GROUP_LANES: *out = 1; break;
       case AHMC_INFO_ELEMS_PER_LANE: *out = c->D; break;
-      case AHMC_INFO_NUTS_LAUNCHES: case AHMC_INFO_NUTS_KERNEL_NS: *out = 0; break;
+      case AHMC_INFO_NUTS_LAUNCHES: case AHMC_INFO_NUTS_KERNEL_NS: case AHMC_INFO_NUTS_WARM_LAUNCHES: case AHMC_INFO_NUTS_WARM_KERNEL_NS: *out = 0; break;
       case AHMC_INFO_NUTS_BATCH: *out = 1; break;
       case AHMC_INFO_ITERATION: *out = (int64_t)c->iteration; break;
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
