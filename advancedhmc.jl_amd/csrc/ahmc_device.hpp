@@ -199,6 +199,50 @@ __device__ __forceinline__ double xor32_sum(double v) {
   return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 
+// The same pair all-reduce on the MATRIX pipe for a chain that owns a whole wave (G = 64).  The trajectory kernels are
+// VALU-issue bound (≈95 % VALU busy) while the MFMA pipe idles; v_mfma_*_16x16x4 sums over its k index,
+// which the operand layout (probed on gfx950, ahmc_dense.hpp) maps to the four 16-lane row groups of the wave:
+//     a: A[i = lane%16][k = lane/16]     b: B[k = lane/16][j = lane%16]
+//     f64 acc[v]: D[i = lane/16 + 4v][j]     f32 acc[v]: D[i = 4·(lane/16) + v][j]
+//   1. D = A·1 with A = a: D[i][·] = Σ_k a[lane i + 16k]; every lane then adds its 4 accumulator rows: y = the sum of a
+//      over a quarter of the lanes (which quarter depends on the dtype's row mapping; the four quarters tile the wave)
+//   2. the same for b
+//   3. D = A′·1 with A′[i][k] = (row i belongs to the "a" half ? ya : yb) of row group k: Σ_k over the four quarters —
+//      the a-rows of D hold Σa, the b-rows Σb, and every lane owns one row of each (acc[0] and acc[2] / acc[1]).
+// 3 MFMA + 6 adds + 2 selects instead of 30 VALU; all lanes receive the same bits (every output element goes through
+// the same FMA chain on the same inputs).  The summation ORDER differs from the DPP butterfly, i.e. last-ulp
+// differences against it — inside the 1e-9 parity tolerance against the oracle, which sums in index order anyway.
+#ifndef AHMC_MFMA_REDUCE
+#define AHMC_MFMA_REDUCE 0
+#endif
+template <class T> struct MfmaRed;
+template <> struct MfmaRed<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static constexpr unsigned SEL = 8u;  // rows i >= 8 (acc[2], acc[3]) carry b
+  static constexpr int RA = 0, RB = 2;
+};
+template <> struct MfmaRed<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static constexpr unsigned SEL = 1u;  // odd rows (acc[1], acc[3]) carry b
+  static constexpr int RA = 0, RB = 1;
+};
+template <class T>
+__device__ __forceinline__ void wave64_allsum2_mfma(T& a, T& b) {
+  using M = MfmaRed<T>;
+  const typename M::acc_t z = {T(0), T(0), T(0), T(0)};
+  const T one = T(1);
+  const typename M::acc_t da = M::mma(a, one, z);
+  const typename M::acc_t db = M::mma(b, one, z);
+  const T ya = (da[0] + da[1]) + (da[2] + da[3]);
+  const T yb = (db[0] + db[1]) + (db[2] + db[3]);
+  const T sel = (threadIdx.x & M::SEL) ? yb : ya;
+  const typename M::acc_t d = M::mma(sel, one, z);
+  a = d[M::RA];
+  b = d[M::RB];
+}
+
 // all-reduce of a PAIR of values across groups of 16/32/64 lanes in ~half the instructions of two
 // butterflies.  The first exchange is transposed — even lanes collect `a`, odd lanes collect `b`
 // — so every later stage moves one value instead of two; rotations inside the 16-lane row keep
@@ -208,6 +252,10 @@ __device__ __forceinline__ double xor32_sum(double v) {
 template <int G, class T>
 __device__ __forceinline__ void wave_allsum2(T& a, T& b) {
   static_assert(G == 16 || G == 32 || G == 64, "pair reduction needs whole 16-lane rows");
+  if constexpr (AHMC_MFMA_REDUCE && G == 64) {
+    wave64_allsum2_mfma(a, b);
+    return;
+  }
   const bool odd = (threadIdx.x & 1u) != 0;
   const T keep = odd ? b : a, send = odd ? a : b;
   T x = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]

@@ -173,6 +173,16 @@ def test_tempered_and_jittered(hip, oracle, rng):
     assert_points_close(g.phasepoint(), o.phasepoint(), np.float64, "jittered transition")
 
 
+def realign(g, o, same):
+    """A chain that took another decision (a last-ulp difference at a U-turn or acceptance test) carries on from another
+    state: put the HIP engine's chains back on the oracle's positions so that EVERY transition is held to the parity
+    bar, not only the first (the next momentum is drawn afresh, so θ is the whole state that matters)."""
+    if not same.all():
+        th = o.phasepoint().theta
+        g.set_position(th)
+        o.set_position(th)
+
+
 def compare_transition_stats(sg, so, dtype, min_match):
     same = (sg["n_steps"] == so["n_steps"]) & (sg["is_accept"] == so["is_accept"]) & (sg["tree_depth"] == so["tree_depth"])
     frac = same.mean()
@@ -200,11 +210,12 @@ def test_static_hmc_transitions(hip, oracle, rng, dtype, min_match, TS, metric):
     for it in range(5):
         for e in (g, o):
             e.transition(k)
-        same = compare_transition_stats(g.stats(), o.stats(), dtype, min_match if it == 0 else 0.5)
+        same = compare_transition_stats(g.stats(), o.stats(), dtype, min_match)
         if dtype == np.float64:
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(zg.r[:, same], zo.r[:, same], rtol=1e-8, atol=1e-8)
+        realign(g, o, same)
 
 
 @pytest.mark.parametrize("dtype,min_match", [(np.float64, 0.999), (np.float32, 0.9)])
@@ -223,12 +234,13 @@ def test_nuts_transitions(hip, oracle, rng, dtype, min_match, TS, TC):
         for e in (g, o):
             e.transition(k)
         sg, so = g.stats(), o.stats()
-        same = compare_transition_stats(sg, so, dtype, min_match if it == 0 else 0.5)
+        same = compare_transition_stats(sg, so, dtype, min_match)
         assert sg["tree_depth"].max() >= 3  # the trees are non-trivial
         if dtype == np.float64:
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(zg.lp.gradient[:, same], zo.lp.gradient[:, same], rtol=1e-8, atol=1e-8)
+        realign(g, o, same)
 
 
 @pytest.mark.parametrize("D,target", [(32, "funnel"), (128, "iso"), (100, "hier"), (3, "iso")])
@@ -247,8 +259,9 @@ def test_nuts_geometries_and_targets(hip, oracle, rng, D, target):
         for e in (g, o):
             e.transition(k)
         sg, so = g.stats(), o.stats()
-        compare_transition_stats(sg, so, np.float64, 0.995 if it == 0 else 0.5)
+        same = compare_transition_stats(sg, so, np.float64, 0.995)
         n_div += int(sg["numerical_error"].sum())
+        realign(g, o, same)
     if target == "funnel":
         assert n_div > 0, "the funnel at eps=0.5 must produce divergent transitions (Δ_max test, :500-507)"
 
@@ -280,9 +293,10 @@ def test_multiwave_chains(hip, oracle, rng, D, target):
             for e in (g, o):
                 e.transition(k)
             sg, so = g.stats(), o.stats()
-            same = compare_transition_stats(sg, so, dtype, 0.95 if it == 0 else 0.5)
+            same = compare_transition_stats(sg, so, dtype, 0.95)
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
+            realign(g, o, same)
         for e in (g, o):  # re-synchronise the two engines for the next kernel
             e.set_position(o.phasepoint().theta)
     eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
@@ -346,11 +360,12 @@ def test_dense_transitions(hip, oracle, rng, metric, target):
             for e in (g, o):
                 e.transition(k)
             sg, so = g.stats(), o.stats()
-            same = compare_transition_stats(sg, so, dtype, 0.99 if it == 0 else 0.5)
+            same = compare_transition_stats(sg, so, dtype, 0.99)
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(zg.r[:, same], zo.r[:, same], rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(zg.lp.gradient[:, same], zo.lp.gradient[:, same], rtol=1e-8, atol=1e-8)
+            realign(g, o, same)
         if not isinstance(k.tau.termination_criterion, A.FixedNSteps):
             assert sg["tree_depth"].max() >= 3
         for e in (g, o):
@@ -784,3 +799,142 @@ def test_full_size_properties(hip):
     np.testing.assert_allclose(-(z1.lp.value + z1.lk.value), s1["hamiltonian_energy"], rtol=1e-12)
     np.testing.assert_allclose(z1.lp.gradient, z1.theta, rtol=1e-12)  # -∇ℓπ = θ for N(0, I)
     assert np.all(np.isfinite(z1.theta)) and not s1["numerical_error"].any()
+
+
+def test_cfg2_pipeline_against_oracle(hip, oracle):
+    """The pipeline bench.py times, against the oracle chain for chain: D=128 iso Gaussian, per-chain Diag metric,
+    θ0 ~ U(0,1), find_good_stepsize, then NUTS(0.8) + StanHMCAdaptor through the FUSED warm-up (k_nuts MODE 3 / 4:
+    adapt! inside the kernel, batches of transitions per launch) and the batched draws (MODE 0 / 1).
+
+    Dual averaging feeds every transition's α back into the next step size, so a last-bit difference grows by ≈2× per
+    iteration (1e-16 → 1e-6 in ≈30); a free-running comparison is therefore only meaningful over short horizons.  The
+    run is cut into chunks of 10 iterations: each chunk starts both engines from the ORACLE's complete state (θ, ϵ,
+    M⁻¹, DAState, Welford (n, μ, M), window counter — ahmc_get/set_adaptor_state) and is compared at its end, which
+    holds every iteration of the warm-up — init buffer, the window (76…100), the metric update and the dual-averaging
+    reset at its end, the term buffer, finalize! at n_adapts — and the first draws to the chain-for-chain bar."""
+    D, N, n_adapts, n_total, chunk = 128, 384, 150, 170, 10
+    metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.1))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+    th0 = np.asfortranarray(np.random.default_rng(2).random((D, N)))
+    g, o = pair(hip, oracle, h, N, np.float64, seed=0x5EED0002, lf=lf)
+    for e in (g, o):
+        e.set_position(th0)
+    eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
+    assert (eg == eo).mean() >= 0.99
+    g.set_integrator(A.Leapfrog(eo))   # (a chain that sat on a tie of the search would start from another ϵ)
+    for e in (g, o):
+        e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)))
+    worst = 1.0
+    for lo in range(1, n_total + 1, chunk):
+        hi = min(lo + chunk - 1, n_total)
+        so = o.get_state()
+        g.set_state(so)                                     # both start the chunk from the oracle's state
+        for e in (g, o):
+            e.run(k, hi, n_adapts, i_first=lo)
+        sg, so2 = g.get_state(), o.get_state()
+        assert sg["adaptor"] == so2["adaptor"]              # iteration / window / Welford counters
+        # a chain is "on track" if it took the same decisions throughout the chunk: its θ then agrees to rounding
+        on = np.isclose(sg["theta"], so2["theta"], rtol=1e-7, atol=1e-7).all(axis=0)
+        worst = min(worst, on.mean())
+        assert on.mean() >= 0.97, (lo, hi, on.mean())       # ≤ 3 % of the chains flip a decision somewhere in 10 transitions
+        np.testing.assert_allclose(sg["stepsize"][on], so2["stepsize"][on], rtol=1e-6, err_msg=f"ϵ after iterations {lo}..{hi}")
+        np.testing.assert_allclose(sg["metric"][:, on], so2["metric"][:, on], rtol=1e-6, err_msg=f"M⁻¹ after {lo}..{hi}")
+        if sg["da"] is not None:
+            np.testing.assert_allclose(sg["da"][:, on], so2["da"][:, on], rtol=1e-6, atol=1e-9, err_msg=f"DAState after {lo}..{hi}")
+        if sg["welford"] is not None:
+            w_g, w_o = sg["welford"][:, on, :], so2["welford"][:, on, :]
+            np.testing.assert_allclose(w_g, w_o, rtol=1e-6, atol=1e-8, err_msg=f"Welford after {lo}..{hi}")
+        if lo <= 100 <= hi:
+            assert not np.allclose(so2["metric"], 1.0), "the window end at iteration 100 must have updated M⁻¹"
+    st = o.get_state()
+    assert st["adaptor"]["adapting"] == 0 and st["adaptor"]["iteration"] == n_total
+    # after the warm-up both sides carry the finalized step sizes: NUTS on N(0, I) at δ = 0.8 in D = 128
+    assert 0.3 < np.median(st["stepsize"]) < 0.8, np.median(st["stepsize"])
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("offset", [0, 30000, 65536 - 256])
+def test_full_size_slice_against_oracle(hip, oracle, offset):
+    """cfg2 at FULL size on the HIP engine (65 536 chains × D = 128, per-chain M⁻¹ and ϵ, dispatch order by step size,
+    batched launches) — and 256 of its chains replayed by the oracle with the same global Philox stream
+    (chain_offset): the chains of a full launch must be the chains of a small one, bit-for-decision."""
+    D, N, n = 128, 65536, 256
+    rs = np.random.default_rng(11)
+    minv = np.asfortranarray(0.5 + rs.random((D, N)))
+    eps = 0.25 * (0.6 + 0.8 * rs.random(N))
+    th0 = np.asfortranarray(rs.normal(size=(D, N)))
+    k_of = lambda e: A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(e), A.GeneralisedNoUTurn()))  # noqa: E731
+    g = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(minv), A.IsoGaussian(D)), N, rng=A.PhiloxRNG(42), lib=hip)
+    g.set_integrator(A.Leapfrog(eps))
+    g.set_position(th0)
+    g.run(k_of(eps), 4)           # 4 transitions in ONE launch, chains dispatched in ascending-ϵ order
+    sl = slice(offset, offset + n)
+    o = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(np.asfortranarray(minv[:, sl])), A.IsoGaussian(D)), n,
+                 rng=A.PhiloxRNG(42, chain_offset=offset), lib=oracle)
+    o.set_integrator(A.Leapfrog(eps[sl]))
+    o.set_position(th0[:, sl])
+    o.run(k_of(eps[sl]), 4)
+    sg, so = g.stats(), o.stats()
+    same = (sg["n_steps"][sl] == so["n_steps"]) & (sg["tree_depth"][sl] == so["tree_depth"])
+    zg, zo = g.phasepoint(), o.phasepoint()
+    on = np.isclose(zg.theta[:, sl], zo.theta, rtol=1e-8, atol=1e-8).all(axis=0)
+    assert on.mean() >= 0.98, on.mean()                      # 4 free-running transitions: a flipped decision stays flipped
+    assert (same | ~on).all()
+    np.testing.assert_allclose(sg["hamiltonian_energy"][sl][on], so["hamiltonian_energy"][on], rtol=1e-9)
+    np.testing.assert_allclose(sg["acceptance_rate"][sl][on], so["acceptance_rate"][on], rtol=1e-8, atol=1e-10)
+    ag, ao = g.accum(), o.accum()
+    np.testing.assert_allclose(ag["sum_theta"][:, sl][:, on], ao["sum_theta"][:, on], rtol=1e-8, atol=1e-8)
+    g.close(); o.close()
+
+
+def test_fixed_integration_time_hmcda(hip, oracle, rng):
+    """FixedIntegrationTime(λ) (src/trajectory.jl:240-243; the HMCDA sampler of src/constructors.jl): nsteps =
+    max(1, floor(λ / ϵ_nominal)) with ONE nominal step size — scalar ϵ for many chains; a single chain's own adapted ϵ"""
+    D, N = 12, 300
+    h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), A.IsoGaussian(D))
+    th = rng.normal(size=(D, N))
+    for lam, eps, L in ((1.0, 0.1, 10), (0.95, 0.3, 3), (0.05, 0.2, 1)):    # floor(1.0/0.1) = 10, floor(3.17) = 3, max(1, 0) = 1
+        lf = A.Leapfrog(eps)
+        k = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedIntegrationTime(lam)))
+        g, o = pair(hip, oracle, h, N, np.float64, seed=21, lf=lf)
+        for e in (g, o):
+            e.set_position(th)
+        for _ in range(3):
+            for e in (g, o):
+                e.transition(k)
+            sg, so = g.stats(), o.stats()
+            assert (sg["n_steps"] == L).all() and (so["n_steps"] == L).all()
+            same = compare_transition_stats(sg, so, np.float64, 0.999)
+            zg, zo = g.phasepoint(), o.phasepoint()
+            np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
+            realign(g, o, same)
+        g.close(); o.close()
+    # a vector of step sizes is the reference's error (Q6), on both engines
+    for lib in (hip, oracle):
+        e = A.Engine(h, N, rng=1, lib=lib)
+        e.set_integrator(A.Leapfrog(np.full(N, 0.1)))
+        e.set_position(th)
+        with pytest.raises(A.ArgumentError):
+            e.transition(A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(np.full(N, 0.1)), A.FixedIntegrationTime(1.0))))
+        e.close()
+    # HMCDA proper: ONE chain, λ fixed, ϵ adapted by dual averaging — L follows the adapted ϵ (sample loop, bulk driver)
+    h1 = A.Hamiltonian(A.DiagEuclideanMetric(np.ones(D)), A.IsoGaussian(D))
+    res = []
+    for lib in (hip, oracle):
+        e = A.Engine(h1, 1, rng=5, lib=lib)
+        lf = A.Leapfrog(0.05)
+        e.set_integrator(lf)
+        e.set_position(th[:, 0])
+        e.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+        k = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedIntegrationTime(1.0)))
+        ns = []
+        for i in range(1, 41):
+            e.run(k, i, 30, i_first=i)
+            ns.append(int(e.stats()["n_steps"][0]))
+        res.append((ns, e.get_stepsize()[0], e.theta().copy()))
+        e.close()
+    assert res[0][0] == res[1][0] and len(set(res[0][0])) > 2, res[0][0]     # L changed as ϵ adapted, identically
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-8)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6, atol=1e-8)
