@@ -381,7 +381,7 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   const int NLEV = max_depth > 1 ? max_depth - 1 : 1;
   const int n_slots = (criterion == AHMC_TC_STRICT ? 3 : 2) * NLEV + NUTS_DORMANT;
   const size_t slot_bytes = (size_t)64 * c->E * sizeof(T);
-  const size_t scalar_bytes = (size_t)NUTS_NSC * NLEV * CPW * sizeof(T) + (size_t)NUTS_NSI * NLEV * CPW * sizeof(int);
+  const size_t scalar_bytes = (size_t)(NUTS_NSC * NLEV + NUTS_NAT) * CPW * sizeof(T) + (size_t)(NUTS_NSI * NLEV + NUTS_NAI) * CPW * sizeof(int);
   const int64_t n_chunks = (c->N + CPW - 1) / CPW;
   int occ = 0;  // single-wave workgroups per CU
   with_target(c->target_kind, [&](auto tk) { occ = Inst<T, decltype(tk)::value>::nuts_occupancy(c->G, c->E, MODE, scalar_bytes * NW); });
@@ -604,8 +604,12 @@ int64_t nuts_batch(Ctx<T>* c) {
     const int64_t capd = (int64_t)(8ull << 30) / (int64_t)(3 * sizeof(T) * c->D * c->N);
     return std::max<int64_t>(1, std::min<int64_t>(64, capd));
   }
-  const int64_t cap = (int64_t)(4ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
-  return std::max<int64_t>(1, std::min<int64_t>(32, cap));
+  // Round 2: 32 -> 128 under an 8 GiB cap.  A launch cannot end before its slowest chain, and in the warm-up (step sizes
+  // still moving, the dual averaging restarting at every window end) a few chains build 10-30x the mean tree for a
+  // while: over 31 transitions they set the launch time (44 ms measured against 28 ms of work); over 125 they average
+  // out.  cfg2 warm-up 1.84e9 -> 2.00e9 leapfrog/s (batch 64: 1.94e9), sampling phase +1 %.
+  const int64_t cap = (int64_t)(8ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
+  return std::max<int64_t>(1, std::min<int64_t>(128, cap));
 }
 
 // nsteps(τ) for FixedIntegrationTime(λ) (src/trajectory.jl:241-243): max(1, floor(λ / nominal step size)).  Needs ONE

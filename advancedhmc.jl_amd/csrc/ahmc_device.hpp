@@ -146,6 +146,79 @@ __device__ __forceinline__ double leaf_exp(double x) {
 }
 __device__ __forceinline__ float leaf_exp(float x) { return exp(x); }
 
+// The weight of a NUTS leaf in the linear-domain kernels: W = exp(ℓw) for ℓw <= LINW_LIMIT (a larger ℓw flags the chain
+// for the log-domain redo pass and its W is never used), so the overflow branch of exp is dead; ℓw = -Inf (a divergent
+// leaf) must give exactly 0.  AHMC_LEAF_EXP = 0: leaf_exp (the device library's algorithm, 11 Horner steps);
+// 1: the same without the overflow select (3 VALU less, same bits where it matters);
+// 2: table-assisted — x = (64 n + j)·ln2/64 + t, |t| <= ln2/128: exp(x) = 2^n · T[j] · (1 + (e^t − 1)) with a 64-entry
+//    table of 2^(j/64) (a scalar load when the chain owns the wave) and a degree-5 polynomial: ≈9 VALU less than the
+//    Horner-11 form; ≤ 1.01 ulp against the exact value (checked on 2·10^5 arguments), i.e. last-ulp differences
+//    against the device library's exp().
+#ifndef AHMC_LEAF_EXP
+#define AHMC_LEAF_EXP 2   // measured on cfg2 (sampling phase, in-kernel leapfrog/s): 1: 2.654e9, 2: 2.718e9
+#endif
+// 2^(j/64), j = 0..63, correctly rounded (generated with 60-digit decimal arithmetic)
+static __device__ const unsigned long long EXP2_64_BITS[64] = {
+    0x3ff0000000000000ULL, 0x3ff02c9a3e778061ULL, 0x3ff059b0d3158574ULL, 0x3ff0874518759bc8ULL,
+    0x3ff0b5586cf9890fULL, 0x3ff0e3ec32d3d1a2ULL, 0x3ff11301d0125b51ULL, 0x3ff1429aaea92de0ULL,
+    0x3ff172b83c7d517bULL, 0x3ff1a35beb6fcb75ULL, 0x3ff1d4873168b9aaULL, 0x3ff2063b88628cd6ULL,
+    0x3ff2387a6e756238ULL, 0x3ff26b4565e27cddULL, 0x3ff29e9df51fdee1ULL, 0x3ff2d285a6e4030bULL,
+    0x3ff306fe0a31b715ULL, 0x3ff33c08b26416ffULL, 0x3ff371a7373aa9cbULL, 0x3ff3a7db34e59ff7ULL,
+    0x3ff3dea64c123422ULL, 0x3ff4160a21f72e2aULL, 0x3ff44e086061892dULL, 0x3ff486a2b5c13cd0ULL,
+    0x3ff4bfdad5362a27ULL, 0x3ff4f9b2769d2ca7ULL, 0x3ff5342b569d4f82ULL, 0x3ff56f4736b527daULL,
+    0x3ff5ab07dd485429ULL, 0x3ff5e76f15ad2148ULL, 0x3ff6247eb03a5585ULL, 0x3ff6623882552225ULL,
+    0x3ff6a09e667f3bcdULL, 0x3ff6dfb23c651a2fULL, 0x3ff71f75e8ec5f74ULL, 0x3ff75feb564267c9ULL,
+    0x3ff7a11473eb0187ULL, 0x3ff7e2f336cf4e62ULL, 0x3ff82589994cce13ULL, 0x3ff868d99b4492edULL,
+    0x3ff8ace5422aa0dbULL, 0x3ff8f1ae99157736ULL, 0x3ff93737b0cdc5e5ULL, 0x3ff97d829fde4e50ULL,
+    0x3ff9c49182a3f090ULL, 0x3ffa0c667b5de565ULL, 0x3ffa5503b23e255dULL, 0x3ffa9e6b5579fdbfULL,
+    0x3ffae89f995ad3adULL, 0x3ffb33a2b84f15fbULL, 0x3ffb7f76f2fb5e47ULL, 0x3ffbcc1e904bc1d2ULL,
+    0x3ffc199bdd85529cULL, 0x3ffc67f12e57d14bULL, 0x3ffcb720dcef9069ULL, 0x3ffd072d4a07897cULL,
+    0x3ffd5818dcfba487ULL, 0x3ffda9e603db3285ULL, 0x3ffdfc97337b9b5fULL, 0x3ffe502ee78b3ff6ULL,
+    0x3ffea4afa2a490daULL, 0x3ffefa1bee615a27ULL, 0x3fff50765b6e4540ULL, 0x3fffa7c1819e90d8ULL};
+template <bool UNIFORM>
+__device__ __forceinline__ double leaf_weight_exp(double x) {
+  constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+#if AHMC_LEAF_EXP == 2
+  const double dk = __builtin_rint(x * 92.33248261689366);                 // 64 / ln 2
+  double t = __builtin_fma(dk, -0x1.62e42fef00000p-7, x);                   // − k·ln2/64: high part (20 trailing zero bits: exact product)
+  t = __builtin_fma(dk, -0x1.473de6af278edp-40, t);                         // low part
+  int k = (int)dk;
+  if constexpr (UNIFORM) k = __builtin_amdgcn_readfirstlane(k);             // a chain owns the wave: scalar table load
+  const double tj = C(EXP2_64_BITS[k & 63]);
+  double q = __builtin_fma(t, 8.3333333333333332e-03, 4.1666666666666664e-02);  // 1/120, 1/24
+  q = fma3(t, q, 1.6666666666666666e-01);
+  q = fma3(t, q, 0.5);
+  q = fma3(t, q, 1.0);
+  q = q * t;                                                                // e^t − 1
+  double z = __builtin_ldexp(__builtin_fma(tj, q, tj), k >> 6);
+  z = x < -1075.0 ? 0.0 : z;                                                // (and x = -Inf, where t is NaN)
+  return z;
+#else
+  const double dn = __builtin_rint(x * C(0x3ff71547652b82feULL));                 // x·log2(e)
+  double t = __builtin_fma(dn, C(0xbfe62e42fefa39efULL), x);                      // − n·ln2 (high part)
+  t = __builtin_fma(dn, C(0xbc7abc9e3b39803fULL), t);                             // − n·ln2 (low part)
+  double q = __builtin_fma(t, C(0x3e5ade156a5dcb37ULL), C(0x3e928af3fca7ab0cULL));
+  q = fma3(t, q, C(0x3ec71dee623fde64ULL));
+  q = fma3(t, q, C(0x3efa01997c89e6b0ULL));
+  q = fma3(t, q, C(0x3f2a01a014761f6eULL));
+  q = fma3(t, q, C(0x3f56c16c1852b7b0ULL));
+  q = fma3(t, q, C(0x3f81111111122322ULL));
+  q = fma3(t, q, C(0x3fa55555555502a1ULL));
+  q = fma3(t, q, C(0x3fc5555555555511ULL));
+  q = fma3(t, q, C(0x3fe000000000000bULL));
+  q = __builtin_fma(t, q, 1.0);
+  q = __builtin_fma(t, q, 1.0);
+  double z = __builtin_ldexp(q, (int)dn);
+#if AHMC_LEAF_EXP == 0
+  z = x > 1024.0 ? Lim<double>::inf() : z;
+#endif
+  z = x < -1075.0 ? 0.0 : z;
+  return z;
+#endif
+}
+template <bool UNIFORM>
+__device__ __forceinline__ float leaf_weight_exp(float x) { return exp(x); }
+
 template <class T> __device__ __forceinline__ T maxabs(T a, T b) { return fabs(a) > fabs(b) ? a : b; }  // :526
 
 // ------------------------------------------------------------------------------------------------
@@ -249,11 +322,51 @@ __device__ __forceinline__ void wave64_allsum2_mfma(T& a, T& b) {
 // the lane parity, the row pairs/halves are joined as before, and lanes 0 / 1 of the row are
 // broadcast back (row_newbcast).  Every lane ends with the bits of those two lanes.
 //   f64: 7 + 3 + 3 + 3 (+5 +5) + 4 = 30 VALU for G = 64, against 2 x 22.
+// The exchanges of a butterfly on the LDS pipe instead of the VALU: ds_swizzle_b32 (any lane pattern inside 32 lanes)
+// and ds_bpermute_b32 (lane ^ 32) move the data, the VALU only adds.  An exchange costs 2 DS instructions instead of 2
+// (DPP) or 4 (permlane: 2 copies + 2 swaps) VALU instructions; the LDS pipe has its own issue port and is almost idle in
+// these kernels (≈17 of ≈900 wave-cycles per leapfrog), the VALU port is the bottleneck.  The price is latency
+// (≈60-100 cycles per exchange against 8): it pays only while the other waves of the SIMD fill the gap.
+// AHMC_DS_REDUCE: bit 0 = the xor-16 / xor-32 stages, bit 1 = also the four in-row stages, bit 2 = the final broadcast.
+#ifndef AHMC_DS_REDUCE
+#define AHMC_DS_REDUCE 0
+#endif
+template <int PATTERN> __device__ __forceinline__ float ds_swz(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN));
+}
+template <int PATTERN> __device__ __forceinline__ double ds_swz(double v) {
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN), __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN));
+}
+__device__ __forceinline__ float ds_xor32(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((__lane_id() ^ 32u) << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ double ds_xor32(double v) {
+  const int addr = (int)((__lane_id() ^ 32u) << 2);
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+}
+// bit-mode swizzle patterns: offset = (xor << 10) | (or << 5) | and; lane' = ((lane & and) | or) ^ xor within 32 lanes
+constexpr int SWZ_XOR1 = (1 << 10) | 0x1F, SWZ_XOR2 = (2 << 10) | 0x1F, SWZ_XOR4 = (4 << 10) | 0x1F, SWZ_XOR8 = (8 << 10) | 0x1F, SWZ_XOR16 = (16 << 10) | 0x1F;
+
 template <int G, class T>
 __device__ __forceinline__ void wave_allsum2(T& a, T& b) {
   static_assert(G == 16 || G == 32 || G == 64, "pair reduction needs whole 16-lane rows");
   if constexpr (AHMC_MFMA_REDUCE && G == 64) {
     wave64_allsum2_mfma(a, b);
+    return;
+  }
+  if constexpr ((AHMC_DS_REDUCE & 2) != 0) {
+    // every exchange on the LDS pipe: transposed first stage (even lanes collect a, odd lanes b), xor butterflies after
+    const bool odd = (threadIdx.x & 1u) != 0;
+    const T keep = odd ? b : a, send = odd ? a : b;
+    T x = keep + ds_swz<SWZ_XOR1>(send);
+    x += ds_swz<SWZ_XOR2>(x);
+    x += ds_swz<SWZ_XOR4>(x);
+    x += ds_swz<SWZ_XOR8>(x);
+    if constexpr (G >= 32) x += ds_swz<SWZ_XOR16>(x);
+    if constexpr (G >= 64) x += ds_xor32(x);
+    const T y = ds_swz<SWZ_XOR1>(x);  // the partner lane holds the other sum
+    a = odd ? y : x;
+    b = odd ? x : y;
     return;
   }
   const bool odd = (threadIdx.x & 1u) != 0;
@@ -262,8 +375,13 @@ __device__ __forceinline__ void wave_allsum2(T& a, T& b) {
   x += dpp_mov<0x4E>(x);             // quad_perm [2,3,0,1]
   x += dpp_mov<0x124>(x);            // row_ror:4
   x += dpp_mov<0x128>(x);            // row_ror:8
-  if constexpr (G >= 32) x = xor16_sum(x);
-  if constexpr (G >= 64) x = xor32_sum(x);
+  if constexpr ((AHMC_DS_REDUCE & 1) != 0) {
+    if constexpr (G >= 32) x += ds_swz<SWZ_XOR16>(x);
+    if constexpr (G >= 64) x += ds_xor32(x);
+  } else {
+    if constexpr (G >= 32) x = xor16_sum(x);
+    if constexpr (G >= 64) x = xor32_sum(x);
+  }
   a = dpp_mov<0x150>(x);  // row_newbcast:0
   b = dpp_mov<0x151>(x);  // row_newbcast:1
 }
@@ -319,11 +437,15 @@ __device__ __forceinline__ void wave_allsum(T (&v)[K]) {
   }
   if constexpr (G >= 32) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = xor16_sum(v[k]);
+    for (int k = 0; k < K; ++k) {
+      if constexpr ((AHMC_DS_REDUCE & 1) != 0) v[k] += ds_swz<SWZ_XOR16>(v[k]); else v[k] = xor16_sum(v[k]);
+    }
   }
   if constexpr (G >= 64) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = xor32_sum(v[k]);
+    for (int k = 0; k < K; ++k) {
+      if constexpr ((AHMC_DS_REDUCE & 1) != 0) v[k] += ds_xor32(v[k]); else v[k] = xor32_sum(v[k]);
+    }
   }
 }
 // Exchange buffer of the multi-wave groups (G = 128/256/512: one chain per workgroup of G/64 waves,
@@ -561,6 +683,28 @@ __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E]
   group_allsum<G>(red);
   z.lp = sanitize(red[0]);
   z.lk = sanitize(-red[1] / 2);
+}
+
+// The leaf of a NUTS tree needs ONE number from the new point: neg_energy(z′) = ℓπ + ℓκ (src/trajectory.jl:641-643) —
+// the weight, the divergence test and ΔH all derive from it; ℓπ and ℓκ themselves are not read again until the
+// candidate's caches are rebuilt at the end of the transition.  So the lane partials are combined BEFORE the all-reduce
+// (one value, 22 VALU, instead of the pair's 34 incl. its selects) and the PhasePoint sanitation (non-finite ℓπ or ℓκ →
+// −Inf, src/hamiltonian.jl:95-104) is applied to the sum: sanitize(ℓπ) + sanitize(ℓκ) is −Inf exactly when either is
+// non-finite, and then ℓπ + ℓκ is non-finite too (the one exception, two finite values of ≈1e308 that overflow when
+// added, does not occur for a log-density).  Returns neg_energy; z.lp / z.lk are NOT updated.
+template <class T, int G, int E, int TK>
+__device__ __forceinline__ T leapfrog_step_ne(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp, int lane, int d0) {
+  const T eh = eps / 2;
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
+  const T part = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
+#pragma unroll
+  for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
+  const T kin = kinetic_partial(z.r, minv);
+  const T s = group_sum1<G>(part - kin / 2);
+  return is_finite(s) ? s : -Lim<T>::inf();
 }
 
 // leapfrog_step (untempered) that sums two more caller-supplied partials of the UPDATED point in the same all-reduce

@@ -83,6 +83,8 @@ struct KP {
 // LDS / scratch layout of k_nuts (ahmc_nuts.hpp), needed by the host launch plan as well
 constexpr int NUTS_NSC = 3;      // T scalars per pending level: w, Σα, ΔH_max
 constexpr int NUTS_NSI = 2;      // int scalars per pending level: nα, candidate leaf index
+constexpr int NUTS_NAT = 5;      // per chain, T: the adaptor's state while a warm-up batch runs (nominal ϵ, DAState ϵ, μ, x̄, H̄)
+constexpr int NUTS_NAI = 2;      // per chain, int: DAState m, Welford count
 constexpr int NUTS_DORMANT = 7;  // vector slots OTH_TH, OTH_R, OTH_G, TREE_A, Z0_R, Z0_G, START_R (strict)
 
 template <class T, int G, int E>

@@ -194,11 +194,24 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   const int NV = strict ? 3 : 2;  // vectors per pending level: A, RF (, RL)
   const int n_slots = NV * NLEV + NUTS_DORMANT;
   const int n_lds_slots = p.n_lds_levels;  // (re-used field) number of vector slots held in LDS
-  // LDS carve-up: [nwaves][n_lds_slots][SLOT_ELEMS] T | [nwaves][NSC][NLEV][CPW] T | [nwaves][NSI][NLEV][CPW] int
+  // LDS carve-up: [nwaves][n_lds_slots][SLOT_ELEMS] T | [nwaves][NSC][NLEV][CPW] T | [nwaves][NAT][CPW] T |
+  //                [nwaves][NSI][NLEV][CPW] int | [nwaves][NAI][CPW] int
   T* lds_vec = reinterpret_cast<T*>(smem) + (size_t)wib * n_lds_slots * SLOT_ELEMS;
   T* sT = reinterpret_cast<T*>(smem) + (size_t)nwaves * n_lds_slots * SLOT_ELEMS + (size_t)wib * NUTS_NSC * NLEV * CPW;
-  int* sI = reinterpret_cast<int*>(reinterpret_cast<T*>(smem) + (size_t)nwaves * (n_lds_slots * SLOT_ELEMS + NUTS_NSC * NLEV * CPW)) +
-            (size_t)wib * NUTS_NSI * NLEV * CPW;
+  T* sAT = reinterpret_cast<T*>(smem) + (size_t)nwaves * (n_lds_slots * SLOT_ELEMS + NUTS_NSC * NLEV * CPW) + (size_t)wib * NUTS_NAT * CPW;
+  int* sIbase = reinterpret_cast<int*>(reinterpret_cast<T*>(smem) + (size_t)nwaves * (n_lds_slots * SLOT_ELEMS + (NUTS_NSC * NLEV + NUTS_NAT) * CPW));
+  int* sI = sIbase + (size_t)wib * NUTS_NSI * NLEV * CPW;
+  int* sAI = sIbase + (size_t)nwaves * NUTS_NSI * NLEV * CPW + (size_t)wib * NUTS_NAI * CPW;
+  // the adaptor's per-chain state of a warm-up batch lives in LDS, not in registers: it is touched once per transition,
+  // and ~12 VGPRs live across the whole tree loop were the difference between the warm-up instantiation's 388 B/lane of
+  // scratch and the sampling one's 180 (profiles/r2_*: 70 % VALU-busy against 90 %, twice the HBM traffic)
+#define A_EPSNOM sAT[0 * CPW + gi]
+#define A_DAEPS sAT[1 * CPW + gi]
+#define A_DAMU sAT[2 * CPW + gi]
+#define A_DAXBAR sAT[3 * CPW + gi]
+#define A_DAHBAR sAT[4 * CPW + gi]
+#define A_DAM sAI[0 * CPW + gi]
+#define A_WVN sAI[1 * CPW + gi]
 #define S_W(lvl) sT[((0) * NLEV + (lvl)) * CPW + gi]
 #define S_SA(lvl) sT[((1) * NLEV + (lvl)) * CPW + gi]
 #define S_DH(lvl) sT[((2) * NLEV + (lvl)) * CPW + gi]
@@ -241,9 +254,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   load_vec<T, E>(th_cur, p.th(), cc * p.D, d0, p.D, T(0));
   // in-kernel adaptation state (MODE 3): dual averaging of this chain, its nominal step size, the Welford count
   const AdaptK<T>* ak = ADAPT ? static_cast<const AdaptK<T>*>(p.adaptk) : nullptr;
-  DAState<T> das{0, T(0), T(0), T(0), T(0)};
-  T eps_nom_reg = p.eps_nom()[cc];
-  int64_t wv_n = 0;
+
   // what adapt! does at batch-local transition kt2 (the same for every chain): push / update / reset of the variance
   // estimator and reset of the dual averaging — `adapt` in ahmc_api.hip, stan_adaptor.jl:137-159
   auto schedule = [&](int kt2, bool& do_push, bool& do_update, bool& wv_reset, bool& dareset) {
@@ -263,19 +274,22 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   };
   auto save_adapt_state = [&]() {  // dual averaging + nominal step size of this chain (the Welford vectors are always in memory)
     if (ak->has_ss && lane == 0) {
-      ak->da_m[cc] = das.m; ak->da_eps[cc] = das.eps; ak->da_mu[cc] = das.mu; ak->da_xbar[cc] = das.xbar; ak->da_Hbar[cc] = das.Hbar;
-      ak->eps_nom[cc] = das.eps;
+      const T e = A_DAEPS;
+      ak->da_m[cc] = A_DAM; ak->da_eps[cc] = e; ak->da_mu[cc] = A_DAMU; ak->da_xbar[cc] = A_DAXBAR; ak->da_Hbar[cc] = A_DAHBAR;
+      ak->eps_nom[cc] = e;
     }
   };
   if constexpr (ADAPT) {
-    if (ak->has_ss) das = DAState<T>{ak->da_m[cc], ak->da_eps[cc], ak->da_mu[cc], ak->da_xbar[cc], ak->da_Hbar[cc]};
-    wv_n = ak->wv_n0;
+    A_EPSNOM = p.eps_nom()[cc];
+    if (ak->has_ss) { A_DAM = ak->da_m[cc]; A_DAEPS = ak->da_eps[cc]; A_DAMU = ak->da_mu[cc]; A_DAXBAR = ak->da_xbar[cc]; A_DAHBAR = ak->da_Hbar[cc]; }
+    int wv_n = (int)ak->wv_n0;
     for (int kt2 = 0; kt2 < kt0; ++kt2) {  // redo pass: the Welford count at the transition this chain resumes at
       bool a1, a2, a3, a4;
       schedule(kt2, a1, a2, a3, a4);
       if (a1) wv_n += 1;
       if (a3) wv_n = 0;
     }
+    A_WVN = wv_n;
   }
 
   for (int kt = 0; kt < p.n_trans; ++kt) {
@@ -292,7 +306,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     copy_vec(cur.th, th_cur);
     Rng rng = make_rng(p, cc);
     rng.iter = p.iteration + (uint32_t)kt;
-    const T eps = chain_eps_from(p, rng, eps_nom_reg);
+    // nominal ϵ of this transition: the adaptor's current one (LDS) while adapting, else the context's (re-read per
+    // transition: two VGPRs fewer across the tree loop than carrying it)
+    T eps_nom_t;
+    if constexpr (ADAPT) eps_nom_t = A_EPSNOM; else eps_nom_t = p.eps_nom()[cc];
+    const T eps = chain_eps_from(p, rng, eps_nom_t);
     momentum_from_normals<T, E>(p, p.znorm + (int64_t)kt * p.D * p.N, cc, d0, cur.r);
     fill_caches<T, G, E, TK>(cur, minv, p.tp, lane, d0);
     if (on && kt > 0) store_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D);  // θ0 of this transition (re-integration, redo)
@@ -364,6 +382,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         T dots_m0[2] = {0, 0}, RF_m0[E];  // fast kernels: U-turn dot products / first-built r of the FIRST merge
         if (alive) {
           // leaf: one leapfrog step in direction v (:638-647)
+          T ne_leaf = 0;
           if constexpr (GENERAL) {
             leapfrog_step<T, G, E, TK, true>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
           } else if (FUSE_M0 && nm > 0) {
@@ -381,11 +400,17 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
                 s1 += A_c[e] * (minv[e] * cur.r[e]);
               }
             });
-          } else {
+          } else if constexpr (G > 64) {
+            // multi-wave chains keep the (ℓπ, ℓκ) pair reduction: with the single-value form the (128,8) instantiation of
+            // the linear-domain kernel returned wrong candidates on the MI355X (energies and tree sizes right; the
+            // log-domain instantiation and (256,4) fine) — not understood, so not shipped for G > 64
             leapfrog_step<T, G, E, TK, false>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+            ne_leaf = cur.lp + cur.lk;
+          } else {
+            ne_leaf = leapfrog_step_ne<T, G, E, TK>(cur, minv, v > 0 ? eps : -eps, p.tp, lane, d0);
           }
           pos_cur += v;
-          const T ne = cur.lp + cur.lk;  // neg_energy(z′)
+          const T ne = (GENERAL || (FUSE_M0 && nm > 0)) ? cur.lp + cur.lk : ne_leaf;  // neg_energy(z′)
           const T dH = -ne - H0;
           if constexpr (!LINW) sa_c = exp(jl_min(T(0), -dH));
           na_c = 1;
@@ -402,8 +427,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               // instead of exp + log1p + log per merge.  Valid while no weight can overflow; a
               // chain that meets -ΔH > 600 is flagged and redone by the log-domain kernel.
               const T lw = H0 + ne;
-              w_c = leaf_exp(lw);
-              sa_c = jl_min(T(1), w_c);
+              w_c = leaf_weight_exp<(CPW == 1)>(lw);
+              sa_c = w_c >= T(1) ? T(1) : w_c;  // exp(min(0, ℓw)) = min(1, W), NaN-propagating like Julia's min
               redo = redo || AHMC_UNI(lw > (sizeof(T) == 4 ? T(60) : T(LINW_LIMIT)));
             } else {
               w_c = H0 + ne;
@@ -678,12 +703,15 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           bool do_push, do_update, wv_reset, dareset;
           schedule(kt, do_push, do_update, wv_reset, dareset);
           if (ak->has_ss) {
+            DAState<T> das{A_DAM, A_DAEPS, A_DAMU, A_DAXBAR, A_DAHBAR};
             da_step(das, sa_tree / (T)na_tree, ak->delta, ak->gamma, ak->t0, ak->kappa);
             if (dareset) da_reset(das);
             if (i == ak->n_adapts) das.eps = exp(das.xbar);  // finalize! (stepsize.jl:55-62)
-            eps_nom_reg = das.eps;                           // update(κ, adaptor): nominal step size ← getϵ
+            A_DAM = das.m; A_DAEPS = das.eps; A_DAMU = das.mu; A_DAXBAR = das.xbar; A_DAHBAR = das.Hbar;
+            A_EPSNOM = das.eps;                              // update(κ, adaptor): nominal step size ← getϵ
           }
           if (ak->has_mm && (do_push || wv_reset)) {
+            int wv_n = A_WVN;
             if (do_push) wv_n += 1;
             const T n = (T)wv_n;
             T mu[E], M2[E], mug[E], Mg[E];
@@ -719,6 +747,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               for (int e = 0; e < E; ++e) { mu[e] = 0; M2[e] = 0; mug[e] = 0; Mg[e] = 0; }
               wv_n = 0;
             }
+            A_WVN = wv_n;
             store_vec<T, E>(mu, ak->wv_mu, ce * p.D, d0, p.D);
             store_vec<T, E>(M2, ak->wv_M, ce * p.D, d0, p.D);
             if (ak->nutpie) {
@@ -738,6 +767,13 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #undef S_DH
 #undef S_NA
 #undef S_CK
+#undef A_EPSNOM
+#undef A_DAEPS
+#undef A_DAMU
+#undef A_DAXBAR
+#undef A_DAHBAR
+#undef A_DAM
+#undef A_WVN
 #undef AHMC_UNI
 }
 

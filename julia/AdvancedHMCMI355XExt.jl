@@ -27,7 +27,7 @@ const F32, F64 = Cint(0), Cint(1)
 const METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = Cint(0), Cint(1), Cint(2)
 const TARGET_ISO_GAUSS, TARGET_DIAG_GAUSS, TARGET_FUNNEL, TARGET_HIER_GAUSS = Cint.(0:3)
 const TARGET_DENSE_GAUSS, TARGET_EXTERNAL = Cint(4), Cint(5)
-const VAR_WELFORD, VAR_NUTPIE = Cint(0), Cint(1)
+const VAR_WELFORD, VAR_NUTPIE, VAR_POOLED = Cint(0), Cint(1), Cint(2)
 const TS_ENDPOINT, TS_MULTINOMIAL, TS_SLICE = Cint.(0:2)
 const TC_CLASSIC, TC_GENERALISED, TC_STRICT = Cint.(0:2)
 const ADAPT_NONE, ADAPT_STEPSIZE, ADAPT_MASSMATRIX, ADAPT_NAIVE, ADAPT_STAN = Cint.(0:4)
@@ -309,6 +309,82 @@ function sample_device(seed::Integer, h::Hamiltonian, κ::HMCKernel, θ::Matrix{
     check(z.ctx, ccall((:ahmc_sample, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{T}),
                        z.ctx, cfg, n_samples, n_adapts, drop_warmup, out))
     check(z.ctx, ccall((:ahmc_sync, LIB), Cint, (Ptr{Cvoid},), z.ctx))
+    return out
+end
+
+# --- ABI v3: checkpoint / resume, the final gather, device-side diagnostics ---------------------------------
+# struct ahmc_adaptor_state (include/ahmc_hip.h): the value the reference carries in HMCState.adaptor
+# (src/abstractmcmc.jl:11-27) — isbits, same field order and alignment as the C struct
+struct AdaptorState
+    kind::Cint; var_estimator::Cint; init_buffer::Cint; term_buffer::Cint; window_size::Cint
+    adapting::Cint; has_da::Cint; n_welford::Cint
+    delta::Cdouble
+    stan_i::Int64; n_adapts::Int64; wv_n::Int64; iteration::Int64
+end
+
+"Everything a resumed run needs besides the Hamiltonian: phase point, metric, step sizes, adaptor, RNG counter."
+struct Checkpoint{T}
+    θ::Matrix{T}; r::Matrix{T}; ℓπ::Vector{T}; g::Matrix{T}
+    M⁻¹::Union{Nothing,Array{T}}; metric_kind::Cint; ϵ::Vector{T}
+    adaptor::AdaptorState; da::Matrix{T}; welford::Array{T,3}
+end
+
+function checkpoint(z::MI355XChains{T}, metric::AbstractMetric) where {T}
+    st = Ref{AdaptorState}()
+    check(z.ctx, ccall((:ahmc_get_adaptor_state, LIB), Cint, (Ptr{Cvoid}, Ptr{AdaptorState}, Ptr{Cvoid}, Ptr{Cvoid}), z.ctx, st, C_NULL, C_NULL))
+    da = Matrix{T}(undef, z.N, st[].has_da != 0 ? 5 : 0)                     # (N, 5) column-major = C's (5, N)
+    wv = Array{T,3}(undef, z.D, z.N, Int(st[].n_welford))                    # (D, N, n) = C's (n, D, N)
+    check(z.ctx, ccall((:ahmc_get_adaptor_state, LIB), Cint, (Ptr{Cvoid}, Ptr{AdaptorState}, Ptr{T}, Ptr{T}), z.ctx, st,
+                       isempty(da) ? C_NULL : da, isempty(wv) ? C_NULL : wv))
+    pp = PhasePoint(z)
+    ϵ = Vector{T}(undef, z.N)
+    check(z.ctx, ccall((:ahmc_get_stepsize, LIB), Cint, (Ptr{Cvoid}, Ptr{T}), z.ctx, ϵ))
+    M = metric isa UnitEuclideanMetric ? nothing : similar(metric.M⁻¹, T)
+    kind = metric isa UnitEuclideanMetric ? METRIC_UNIT : metric isa DiagEuclideanMetric ? METRIC_DIAG : METRIC_DENSE
+    M === nothing || check(z.ctx, ccall((:ahmc_get_metric, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Int64), z.ctx, M, length(M)))
+    return Checkpoint{T}(pp.θ, pp.r, pp.ℓπ.value, pp.ℓπ.gradient, M, kind, ϵ, st[], da, wv)
+end
+
+function restore!(z::MI355XChains{T}, c::Checkpoint{T}) where {T}
+    c.M⁻¹ === nothing || check(z.ctx, ccall((:ahmc_set_metric, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{T}, Int64), z.ctx, c.metric_kind, c.M⁻¹, length(c.M⁻¹)))
+    check(z.ctx, ccall((:ahmc_set_stepsize, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Int64), z.ctx, c.ϵ, length(c.ϵ)))
+    check(z.ctx, ccall((:ahmc_set_phasepoint, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}), z.ctx, c.θ, c.r, c.ℓπ, c.g))
+    st = Ref(c.adaptor)
+    check(z.ctx, ccall((:ahmc_set_adaptor_state, LIB), Cint, (Ptr{Cvoid}, Ptr{AdaptorState}, Ptr{T}, Ptr{T}), z.ctx, st,
+                       isempty(c.da) ? C_NULL : c.da, isempty(c.welford) ? C_NULL : c.welford))
+end
+
+"Continue the loop of src/sampler.jl:182-228 at iteration `i_first` (after `restore!`): `ahmc_sample_from`."
+function resume_device!(z::MI355XChains{T}, κ::HMCKernel, i_first::Int, n_samples::Int, n_adapts::Int) where {T}
+    cfg = Ref(kernel_cfg(κ))
+    check(z.ctx, ccall((:ahmc_sample_from, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{T}),
+                       z.ctx, cfg, i_first, n_samples, n_adapts, false, C_NULL))
+end
+
+# Multi-GPU (SURVEY §8e): one Julia process per GPU (Distributed / MPI.jl launches them), each with its own
+# MI355XChains over its block of chains and seed!(…; chain_offset = first global chain).  Rank 0 makes the id, the host
+# broadcasts the 128 bytes with whatever it already has (Distributed's remotecall, MPI.Bcast!), every rank joins.
+comm_unique_id() = (id = Vector{UInt8}(undef, 128); code = ccall((:ahmc_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id);
+                    code == 0 || throw(AHMCError(code, "ahmc_comm_unique_id")); id)
+comm_init!(z::MI355XChains, id::Vector{UInt8}, n_ranks::Integer, rank::Integer) =
+    check(z.ctx, ccall((:ahmc_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), z.ctx, id, n_ranks, rank))
+"an ncclComm_t the host already owns (its entry points are resolved from the RCCL copy loaded in this process)"
+set_comm!(z::MI355XChains, comm::Ptr{Cvoid}, n_ranks::Integer, rank::Integer) =
+    check(z.ctx, ccall((:ahmc_set_comm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), z.ctx, comm, n_ranks, rank))
+
+"Pooled per-dimension mean / variance of the kept draws of ALL ranks (one ncclAllReduce of 2D+3 doubles)."
+function gather_moments(z::MI355XChains)
+    μ, σ² = Vector{Float64}(undef, z.D), Vector{Float64}(undef, z.D)
+    n, steps, ndiv = Ref{Int64}(0), Ref{Int64}(0), Ref{Int64}(0)
+    check(z.ctx, ccall((:ahmc_gather_moments, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+                       z.ctx, μ, σ², n, steps, ndiv))
+    return (mean=μ, var=σ², n_draws=n[], n_steps=steps[], n_divergent=ndiv[])
+end
+
+"EBFMI (src/diagnosis.jl:1-3) per chain over the kept transitions of the last `sample_device` / `resume_device!` call"
+function AdvancedHMC.EBFMI(z::MI355XChains{T}) where {T}
+    out = Vector{T}(undef, z.N)
+    check(z.ctx, ccall((:ahmc_ebfmi, LIB), Cint, (Ptr{Cvoid}, Ptr{T}), z.ctx, out))
     return out
 end
 

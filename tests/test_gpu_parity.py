@@ -288,12 +288,19 @@ def test_multiwave_chains(hip, oracle, rng, D, target):
         A.HMCKernel(A.Trajectory(A.SliceTS, lf, A.StrictGeneralisedNoUTurn(max_depth=5))),
         A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.ClassicNoUTurn(max_depth=5))),
     ]
-    for k in kernels:
+    import os, sys
+    dbg = os.environ.get("AHMC_TEST_TRACE") == "1"
+    for ik, k in enumerate(kernels):
         for it in range(2):
-            for e in (g, o):
-                e.transition(k)
-            sg, so = g.stats(), o.stats()
+            if dbg: print(f"[trace] D={D} kernel {ik} it {it}: transition", file=sys.stderr, flush=True)
+            g.transition(k)
+            if dbg: g.sync(); print("[trace]   hip transition done", file=sys.stderr, flush=True)
+            o.transition(k)
+            sg = g.stats()
+            if dbg: print("[trace]   hip stats done", file=sys.stderr, flush=True)
+            so = o.stats()
             same = compare_transition_stats(sg, so, dtype, 0.95)
+            if dbg: print(f"[trace]   same {same.mean()}", file=sys.stderr, flush=True)
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             realign(g, o, same)
