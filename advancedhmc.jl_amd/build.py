@@ -47,10 +47,28 @@ def _sources_digest() -> str:
     return h.hexdigest()
 
 
+KERNEL_SOURCES = ("ahmc_device.hpp", "ahmc_kernels.hpp", "ahmc_nuts.hpp", "ahmc_inst.hpp", "ahmc_inst.hip")
+
+
+def kernel_digest() -> str:
+    """sha256 over the DEVICE code of the trajectory kernels (k_nuts, k_hmc, k_leapfrog, …) and the compiler flags: what
+    decides their instruction counts.  bench.py matches it against profiles/counters_at_head.json — host-side edits
+    (ahmc_api.hip …) do not invalidate PMC counters taken on the same kernels."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     digest = _sources_digest()
     stamp = OUT + ".digest"  # next to the .so (csrc/build/ holds only objects and does not travel to the GPU box)
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == digest:
+        if not os.path.exists(OUT + ".kdigest"):
+            with open(OUT + ".kdigest", "w") as f:
+                f.write(kernel_digest())
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -109,6 +127,8 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
             os.remove(os.path.join(CSRC, f))
     with open(stamp, "w") as f:
         f.write(digest)
+    with open(OUT + ".kdigest", "w") as f:  # (travels with the .so: the GPU box never sees a stale pairing)
+        f.write(kernel_digest())
     if verbose:
         print("linked", OUT)
     return OUT

@@ -173,6 +173,8 @@ struct Ctx : CtxBase {
   int* dn_list = nullptr;
   size_t dn_slots = 0, dn_batch_elems = 0;
   int64_t dn_global_steps = 0, dn_chain_steps = 0;
+  hipStream_t stream2 = nullptr;  // second pipeline of the dense NUTS loop (dn_nuts_transition)
+  hipEvent_t ev_split = nullptr, ev_join = nullptr;
   // WelfordCov of the shared dense metric: μ (D) [+ batch mean + column-sum partials], M, batch scatter, estimate
   T *wc_mu = nullptr, *wc_M = nullptr, *wc_S = nullptr, *wc_cov = nullptr;
   T* dn_C = nullptr;   // M⁻¹·P (dense metric + dense target), see dn_refresh_fused
@@ -196,6 +198,9 @@ struct Ctx : CtxBase {
     if (comm && comm_owned) comm_destroy_raw(comm);
     if (red) (void)hipFree(red);
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    for (hipEvent_t e : {ev_split, ev_join})
+      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {stage_ready[0], stage_ready[1], stage_free[0], stage_free[1]})
       if (e) (void)hipEventDestroy(e);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
@@ -601,8 +606,10 @@ int64_t nuts_batch(Ctx<T>* c) {
   if (dense_engine(c)) {
     // dense engine: chains run asynchronously through the batch and only its end has idle chains, so longer
     // is better; three (batch, D, N) arrays (normals, momenta, M⁻¹·momenta) kept under 8 GiB
-    const int64_t capd = (int64_t)(8ull << 30) / (int64_t)(3 * sizeof(T) * c->D * c->N);
-    return std::max<int64_t>(1, std::min<int64_t>(64, capd));
+    // (round 2: 64 under 8 GiB -> 256 under 48 GiB of the 288: the end of a batch, where only the chains with the
+    // longest trees are left, is the part of it that runs below full occupancy)
+    const int64_t capd = (int64_t)(48ull << 30) / (int64_t)(3 * sizeof(T) * c->D * c->N);
+    return std::max<int64_t>(1, std::min<int64_t>(256, capd));
   }
   // Round 2: 32 -> 128 under an 8 GiB cap.  A launch cannot end before its slowest chain, and in the warm-up (step sizes
   // still moving, the dual averaging restarting at every window end) a few chains build 10-30x the mean tree for a
@@ -934,10 +941,37 @@ int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, in
 
 }  // namespace
 
+// roctx ranges around every C-ABI call: with AHMC_ROCTX=1 the library loads roctx (rocprofiler-sdk's,
+// else roctracer's) and each entry point shows up by name in `rocprofv3 --marker-trace` timelines next to the kernels
+// it enqueued.  Off by default: one predictable branch per call.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    const char* on = getenv("AHMC_ROCTX");
+    if (!on || atoi(on) == 0) return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+inline RoctxApi& roctx_api() { static RoctxApi a; return a; }
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char* name) : on(roctx_api().push != nullptr) { if (on) roctx_api().push(name); }
+  ~RoctxRange() { if (on) roctx_api().pop(); }
+};
+
 #define FOR_CTX(ctx, ...)                                                                              \
   do {                                                                                                 \
     CtxBase* _b = reinterpret_cast<CtxBase*>(ctx);                                                     \
     if (!_b) return AHMC_ERR_ARGUMENT;                                                                 \
+    RoctxRange _roctx(__func__);                                                                       \
     (void)hipSetDevice(_b->device);                                                                    \
     if (_b->dtype == AHMC_F32) { using T = float; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ }    \
     else { using T = double; auto* c = static_cast<Ctx<T>*>(_b); __VA_ARGS__ }                         \

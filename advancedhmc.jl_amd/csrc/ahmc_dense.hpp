@@ -387,6 +387,12 @@ __global__ __launch_bounds__(256) void k_d_compact(const DChain<T>* __restrict__
 }
 
 template <class T>
+__global__ __launch_bounds__(256) void k_d_iota(int* __restrict__ out, int start, int64_t n) {  // out[j] = start + j
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = start + (int)j;
+}
+
+template <class T>
 __device__ __forceinline__ T* dslot(const DP<T>& q, const KP<T>& p, int slot, int64_t c) {
   return q.W + ((int64_t)slot * p.N + c) * p.D;
 }

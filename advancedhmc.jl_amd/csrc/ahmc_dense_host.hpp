@@ -74,8 +74,8 @@ int dn_ensure(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
     HIPCHK(hipMemsetAsync(c->dn_S, 0, (size_t)c->N * sizeof(DChain<T>), c->stream));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_es), (size_t)c->N * sizeof(T)));
     HIPCHK(hipMemsetAsync(c->dn_es, 0, (size_t)c->N * sizeof(T), c->stream));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), 2 * sizeof(int)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_list), 2 * (size_t)c->N * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), 4 * sizeof(int)));                   // [0] batch counter, [1..2] compaction counts
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_list), 4 * (size_t)c->N * sizeof(int)));       // two ping-pong lists per pipeline
   }
   return AHMC_OK;
 }
@@ -451,43 +451,94 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // global steps until every chain has finished the batch.  Every CHUNK steps the list of chains
   // still running is compacted and its length read back, so the tail of the batch (few chains with
   // long trees left) costs GEMMs over those chains only.
+  //
+  // Two pipelines (round 2).  A global step is a GEMM (MFMA-bound, ≈190 µs at 8 192 chains) followed by the tree kernel
+  // (a chain of dependent memory round trips, ≈75 µs) — each waits for the other, so the matrix pipe idles a quarter of
+  // the time.  Chains are independent: the chain set is cut in two halves, each stepping through GEMM → tree on its
+  // own stream with its own running-chain list, and the hardware overlaps one half's tree kernel with the other
+  // half's GEMM.  (Dense target only: the built-in families' cache kernel has no chain list.)
   const int CHUNK = 16;
   const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
-  const int* list = nullptr;
-  int64_t n_list = c->N;
-  int pp = 0;
-  for (int64_t done_steps = 0; done_steps < max_steps && n_list > 0;) {
-    q.list = list;
-    q.n_list = n_list;
+  const int split_env = getenv("AHMC_DENSE_SPLIT") ? atoi(getenv("AHMC_DENSE_SPLIT")) : 1;  // (read per call: the tests toggle it)
+  const int NP = (split_env != 0 && dt && c->N >= 2048) ? 2 : 1;
+  struct Pipe { hipStream_t s; const int* list; int64_t n_list; int pp; int* lists; int* cnt; int active; };
+  Pipe pipes[2];
+  if (NP == 2 && !c->stream2) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_split, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  for (int k = 0; k < NP; ++k) {
+    Pipe& h = pipes[k];
+    h.s = k == 0 ? c->stream : c->stream2;
+    h.lists = c->dn_list + (size_t)k * 2 * c->N;
+    h.cnt = c->dn_active + 1 + k;
+    h.pp = 0;
+    h.active = 0;
+    if (NP == 1) { h.list = nullptr; h.n_list = c->N; }
+    else {
+      const int64_t lo = k == 0 ? 0 : c->N / 2, n = k == 0 ? c->N / 2 : c->N - c->N / 2;
+      hipLaunchKernelGGL((k_d_iota<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, h.lists + c->N, (int)lo, n);  // (second buffer: the first compaction writes the first)
+      h.list = h.lists + c->N;
+      h.n_list = n;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  hipStream_t main_stream = c->stream;
+  if (NP == 2) {  // everything enqueued so far (momenta, start of transition 0, the lists) precedes the second pipeline
+    HIPCHK(hipEventRecord(c->ev_split, main_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_split, 0));
+  }
+  auto bail = [&](int code) { c->stream = main_stream; return code; };
+  for (int64_t done_steps = 0; done_steps < max_steps && (pipes[0].n_list > 0 || (NP == 2 && pipes[1].n_list > 0));) {
     for (int s = 0; s < CHUNK; ++s) {
-      // one global step = g′ = Pθ′ (or the built-in family's kernel), w′ = M⁻¹g′, then the fused
-      // second-half / tree / first-half kernel: three launches
-      if (dt && dm && c->dn_fused_ok) {
-        rc = dn_gemm(c, c->tparams, c->th, c->g, n_list, list, c->dn_C, Wcur);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
-        if (rc) return rc;
-      } else {
-        rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, n_list, list) : launch_fill_caches_builtin(c);
-        if (rc) return rc;
-        if (dm) {
-          rc = dn_gemm(c, c->dn_minv, c->g, Wcur, n_list, list);
-          if (rc) return rc;
+      for (int k = 0; k < NP; ++k) {
+        Pipe& h = pipes[k];
+        if (h.n_list <= 0) continue;
+        c->stream = h.s;  // (the helpers enqueue on the context's stream)
+        q.list = h.list;
+        q.n_list = h.n_list;
+        // one global step = g′ = Pθ′ (or the built-in family's kernel), w′ = M⁻¹g′, then the fused
+        // second-half / tree / first-half kernel
+        if (dt && dm && c->dn_fused_ok) {
+          rc = dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list, c->dn_C, Wcur);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
+          if (rc) return bail(rc);
+        } else {
+          rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list) : launch_fill_caches_builtin(c);
+          if (rc) return bail(rc);
+          if (dm) {
+            rc = dn_gemm(c, c->dn_minv, c->g, Wcur, h.n_list, h.list);
+            if (rc) return bail(rc);
+          }
         }
+        launch_d_tree(c, criterion, (unsigned)h.n_list, p, q, minv_d, pc, dt ? 1 : 0, 1);
       }
-      launch_d_tree(c, criterion, (unsigned)n_list, p, q, minv_d, pc, dt ? 1 : 0, 1);
     }
     done_steps += CHUNK;
     c->dn_global_steps += CHUNK;
-    int* out = c->dn_list + (size_t)pp * c->N;
-    int* cnt = c->dn_active + 1;
-    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL((k_d_compact<T>), dim3((unsigned)((n_list + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, list, n_list, out, cnt);
-    int active = 0;
-    HIPCHK(hipMemcpyAsync(&active, cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    list = out;
-    n_list = active;
-    pp ^= 1;
-    c->dn_chain_steps += (int64_t)CHUNK * q.n_list;
+    for (int k = 0; k < NP; ++k) {
+      Pipe& h = pipes[k];
+      if (h.n_list <= 0) continue;
+      c->stream = h.s;
+      int* out = h.lists + (size_t)h.pp * c->N;
+      if (hipMemsetAsync(h.cnt, 0, sizeof(int), h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipMemsetAsync failed"));
+      hipLaunchKernelGGL((k_d_compact<T>), dim3((unsigned)((h.n_list + 255) / 256)), dim3(256), 0, h.s, c->dn_S, h.list, h.n_list, out, h.cnt);
+      if (hipMemcpyAsync(&h.active, h.cnt, sizeof(int), hipMemcpyDeviceToHost, h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipMemcpyAsync failed"));
+    }
+    for (int k = 0; k < NP; ++k) {
+      Pipe& h = pipes[k];
+      if (h.n_list <= 0) continue;
+      if (hipStreamSynchronize(h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipStreamSynchronize failed"));
+      c->dn_chain_steps += (int64_t)CHUNK * h.n_list;
+      h.list = h.lists + (size_t)h.pp * c->N;
+      h.n_list = h.active;
+      h.pp ^= 1;
+    }
+  }
+  c->stream = main_stream;
+  if (NP == 2) {  // whatever is enqueued on the context's stream next comes after the second pipeline
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join, 0));
   }
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] dense NUTS batch of %d: %lld global steps so far, %lld chain-slots stepped\n", n_trans, (long long)c->dn_global_steps, (long long)c->dn_chain_steps);

@@ -69,9 +69,10 @@ def algorithmic_bytes_per_leapfrog(D, metric, itemsize):
 
 
 def sources_digest():
-    """digest of the kernel sources + flags the shipped libahmc_hip.so was built from (advancedhmc.jl_amd/build.py)"""
+    """digest of the DEVICE code of the trajectory kernels + compiler flags the shipped libahmc_hip.so was built from
+    (advancedhmc.jl_amd/build.py: kernel_digest)"""
     try:
-        return open(os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.digest")).read().strip()
+        return open(os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.kdigest")).read().strip()
     except OSError:
         return None
 

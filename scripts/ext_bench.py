@@ -6,7 +6,10 @@
 The density is the isotropic Gaussian of cfg2 evaluated OUTSIDE the engine: by torch on the device, reading θ in
 place at ahmc_theta_ptr and handing device pointers back (default), or by numpy on the host through the (D,N) copies
 of the protocol (--host: the PCIe-inclusive figure).  Reports chain-leapfrogs/s, requests, µs per request, and the
-fused engine's figure for the same chains and step sizes as the yardstick.  NOT YET RUN (written without a GPU)."""
+fused engine's figure for the same chains and step sizes as the yardstick.  One untimed transition first: the first
+ahmc_ext_begin allocates the step-synchronous engine's buffers (round 2 measurement, 16 384 x 128: 0.22 ms per
+request in steady state — 0.16 ms of it ahmc_ext_advance = ingest + k_d_tree + compaction + the 4-byte read-back —
+against 2.0 ms when the allocations are averaged in; scripts/ext_trace.py splits a request into its calls)."""
 import argparse
 import ctypes as C
 import json
@@ -47,6 +50,8 @@ def main():
     e.set_position(th0)
     out = {"D": D, "N": N, "transitions": args.transitions, "closure": "host numpy" if args.host else "device torch"}
     requests = 0
+    e._call("ahmc_ext_begin", C.byref(k), 1)  # untimed: allocations of the step-synchronous engine
+    e._ext_drive()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if args.host:

@@ -416,6 +416,32 @@ def test_dense_bulk_sample_and_stepsize_adaptation(hip, rng):
     np.testing.assert_allclose(var, np.diag(cov), rtol=0.08)
 
 
+def test_dense_two_pipelines_equal_one(hip, rng, monkeypatch):
+    """the dense NUTS loop cut into two chain halves on two streams (one half's tree kernel overlapping the other's
+    GEMM) must give exactly the chains of the single pipeline: chains are independent and a column's arithmetic
+    does not depend on which other columns share its GEMM launch"""
+    D, N = 48, 2304
+    h = _dense_hamiltonian(D, N, rng, "dense", "dense")
+    lf = A.Leapfrog(np.full(N, 0.15) * (0.6 + 0.8 * rng.random(N)))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=7)))
+    th0 = 0.5 * rng.normal(size=(D, N))
+    res = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("AHMC_DENSE_SPLIT", split)
+        e = A.Engine(h, N, rng=31, lib=hip)
+        e.set_integrator(lf)
+        e.set_position(th0)
+        e.run(k, 5)
+        res.append((e.phasepoint(), e.stats(), e.accum()))
+        e.close()
+    (z1, s1, a1), (z0, s0, a0) = res
+    np.testing.assert_array_equal(z1.theta, z0.theta)
+    np.testing.assert_array_equal(z1.r, z0.r)
+    np.testing.assert_array_equal(s1["n_steps"], s0["n_steps"])
+    np.testing.assert_array_equal(a1["sum_theta"], a0["sum_theta"])
+    assert a1["total_n_steps"] == a0["total_n_steps"] and s1["tree_depth"].max() >= 3
+
+
 def test_dense_covariance_adaptation(hip, oracle, rng):
     """WelfordCov behind the shared DenseEuclideanMetric (src/adaptation/massmatrix.jl:283-340): batch (Chan) update on
     the MFMA units == the oracle pushing the chains one after another, on identical (θ, α); then NUTS + StanHMCAdaptor
