@@ -405,19 +405,29 @@ __device__ __forceinline__ void vcopy(T* __restrict__ dst, const T* __restrict__
 // (leaf, merges, end of subtree, end of doubling, end of transition, start of the next transition)
 // and publish the signed step of its next leapfrog.  MultinomialTS / SliceTS with
 // GeneralisedNoUTurn; log-domain weights as the reference (src/trajectory.jl:144-206,626-742).
-constexpr int DT_THREADS = 256;  // measured on cfg4: 128 -> 2.21e7, 256 -> 2.25e7, 512 -> 2.14e7 leapfrog/s (one wave per chain: 2.01e7)  // threads per chain in k_d_tree
+// Threads per chain in the tree kernel (template parameter DT).  Measured on cfg4 (D = 512): 128 -> 2.21e7, 256 -> 2.25e7,
+// 512 -> 2.14e7 leapfrog/s (one wave per chain: 2.01e7).  Round 2: the thread count follows D — a chain of D <= 128 gets
+// ONE wave (the workgroup barriers become wave-local, no idle waves), D <= 256 two: the step-synchronous engine also
+// serves user log-densities of any dimension (ahmc_ext_*), where a request at D = 128 paid 127 µs for a kernel shaped
+// for D = 512.
+constexpr int DT_THREADS = 256;
+inline int dt_threads_for(int64_t D) { return D <= 128 ? 64 : (D <= 256 ? 128 : DT_THREADS); }
 // all-reduce of a pair over the DT_THREADS threads of the workgroup (every decision of d_tree_advance is taken on
 // such sums or on per-chain scalars, so all threads follow the same control flow and reach the barriers together)
-template <class T>
+template <int DT, class T>
 __device__ __forceinline__ void block_allsum2(T& a, T& b) {
-  __shared__ double xb[DT_THREADS / 64][2];
+  if constexpr (DT == 64) {  // one wave per chain: no cross-wave exchange, no barrier
+    wave_allsum2<64>(a, b);
+    return;
+  }
+  __shared__ double xb[DT / 64][2];
   wave_allsum2<64>(a, b);
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { xb[w][0] = (double)a; xb[w][1] = (double)b; }
   __syncthreads();
   T sa = 0, sb = 0;
 #pragma unroll
-  for (int k = 0; k < DT_THREADS / 64; ++k) { sa += (T)xb[k][0]; sb += (T)xb[k][1]; }  // fixed order: same bits in every wave
+  for (int k = 0; k < DT / 64; ++k) { sa += (T)xb[k][0]; sb += (T)xb[k][1]; }  // fixed order: same bits in every wave
   __syncthreads();
   a = sa;
   b = sb;
@@ -433,8 +443,9 @@ template <int CRIT>
 struct DLevel {
   static constexpr int STRIDE = CRIT == 2 ? DS_PER_LEVEL + 3 : DS_PER_LEVEL;  // vector slots per pending level
 };
-template <class T, int CRIT = 1>
-__device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int64_t c, int lane /* thread of the chain's workgroup, 0 .. DT_THREADS-1 */, T lp_in, T lk_in) {
+template <class T, int CRIT = 1, int DT = DT_THREADS>
+__device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int64_t c, int lane /* thread of the chain's workgroup, 0 .. DT-1 */, T lp_in, T lk_in) {
+  constexpr int DT_THREADS = DT;  // (shadows the default: every loop below strides by the workgroup's size)
   constexpr int LS = DLevel<CRIT>::STRIDE;
   DChain<T>& S = q.S[c];
   const int D = p.D;
@@ -538,7 +549,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         }
         rho_v = s_rho;
         vf_v = p_vf;
-        block_allsum2(dots[0], dots[1]);
+        block_allsum2<DT>(dots[0], dots[1]);
         sub_term = (dots[0] <= 0) || (dots[1] <= 0);
       } else if constexpr (CRIT == 0) {
         // ClassicNoUTurn (:551-557): ends = the pending half's first-built leaf (θ in the ρ slot, v_first) and the
@@ -553,7 +564,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         }
         rho_v = p_rho;  // the merged subtree's first-built leaf is the pending half's
         vf_v = p_vf;
-        block_allsum2(dots[0], dots[1]);
+        block_allsum2<DT>(dots[0], dots[1]);
         sub_term = (dots[0] >= 0) || (dots[1] >= 0);
       } else {
         // StrictGeneralisedNoUTurn (:579-617).  F = the pending (first-built) half, S = the half just completed:
@@ -577,9 +588,9 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         rho_v = s_rho;
         vf_v = p_vf;
         rf_v = p_rf;
-        block_allsum2(dots[0], dots[1]);
-        block_allsum2(dots[2], dots[3]);
-        block_allsum2(dots[4], dots[5]);
+        block_allsum2<DT>(dots[0], dots[1]);
+        block_allsum2<DT>(dots[2], dots[3]);
+        block_allsum2<DT>(dots[4], dots[5]);
         sub_term = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
       }
       merged = lvl + 1;
@@ -673,7 +684,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         dots[1] += rho * o_v[d];
         t_rho[d] = rho;
       }
-      block_allsum2(dots[0], dots[1]);
+      block_allsum2<DT>(dots[0], dots[1]);
       turn = (dots[0] <= 0) || (dots[1] <= 0);
     } else if constexpr (CRIT == 0) {
       const T* o_th = dslot(q, p, DS_OTH_TH, c);
@@ -687,7 +698,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         dots[0] += dth * (-vl);
         dots[1] += (-dth) * vr;
       }
-      block_allsum2(dots[0], dots[1]);
+      block_allsum2<DT>(dots[0], dots[1]);
       turn = (dots[0] >= 0) || (dots[1] >= 0);
     } else {
       // strict at the top: (ρ_tree + ρ_sub ; ends current edge, other edge), (ρ_tree + r_sub.first ; ends other edge,
@@ -709,9 +720,9 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         dots[5] += rho3 * V[d];
         t_rho[d] = rho;
       }
-      block_allsum2(dots[0], dots[1]);
-      block_allsum2(dots[2], dots[3]);
-      block_allsum2(dots[4], dots[5]);
+      block_allsum2<DT>(dots[0], dots[1]);
+      block_allsum2<DT>(dots[2], dots[3]);
+      block_allsum2<DT>(dots[4], dots[5]);
       turn = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
     }
     const bool done = sub_term || turn || (jw + 1 >= p.max_depth);
@@ -833,7 +844,7 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
         dslot(q, p, DS_START_G, c)[d] = vd;
       }
     }
-    block_allsum2(dots[0], dots[1]);
+    block_allsum2<DT>(dots[0], dots[1]);
     const T lp = lp_start;
     const T lk = sanitize(-dots[0] / 2);
     const T H0 = -(lp + lk);
@@ -865,9 +876,10 @@ __device__ __forceinline__ T d_tree_advance(const KP<T>& p, const DP<T>& q, int6
 //   next leapfrog (k_d_pre).  `do_post` = 0 for the very first call of a batch (no leapfrog in flight yet).
 // One chain per workgroup of 256 threads (2 elements per thread at D = 512): the kernel is a chain of dependent
 // memory round trips, so more threads per chain = fewer trips (one wave per chain: 75 µs per call, this: see DESIGN).
-template <class T>
-__global__ __launch_bounds__(DT_THREADS) void k_d_tree(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
-  const int lane = threadIdx.x;  // one chain per workgroup of DT_THREADS threads
+template <class T, int DT = DT_THREADS>
+__global__ __launch_bounds__(DT) void k_d_tree(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
+  constexpr int DT_THREADS = DT;
+  const int lane = threadIdx.x;  // one chain per workgroup of DT threads
   const int64_t j = blockIdx.x;
   if (j >= q.n_list) return;
   const int64_t c = q.list ? q.list[j] : j;
@@ -892,7 +904,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree(KP<T> p, DP<T> q, const T
       s[0] += rn * vn;
       s[1] += th[d] * gd;
     }
-    block_allsum2(s[0], s[1]);
+    block_allsum2<DT>(s[0], s[1]);
     lk = sanitize(-s[0] / 2);
     if (dense_target) lp = sanitize(-s[1] / 2);
     if (lane == 0) {
@@ -900,7 +912,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree(KP<T> p, DP<T> q, const T
       if (dense_target) p.lp()[c] = lp;
     }
   }
-  const T e = d_tree_advance(p, q, c, lane, lp, lk);
+  const T e = d_tree_advance<T, 1, DT>(p, q, c, lane, lp, lk);
   if (lane == 0) q.es[c] = e;
   if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237)
     for (int d = lane; d < D; d += DT_THREADS) {
@@ -917,9 +929,10 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree(KP<T> p, DP<T> q, const T
 // (TEMPER): k_d_tree's body around d_tree_advance<T, CRIT> (kept as a second kernel so that the code of the default
 // one does not move).  A NUTS leaf is step(lf, h, z, 1): temper multiplies r by √α before the first half-step and
 // divides it by √α after the second (src/integrator.jl:198-209 with n_steps = 1); v = M⁻¹r goes with it.
-template <class T, int CRIT, bool TEMPER>
-__global__ __launch_bounds__(DT_THREADS) void k_d_tree_crit(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
-  const int lane = threadIdx.x;  // one chain per workgroup of DT_THREADS threads
+template <class T, int CRIT, bool TEMPER, int DT = DT_THREADS>
+__global__ __launch_bounds__(DT) void k_d_tree_crit(KP<T> p, DP<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
+  constexpr int DT_THREADS = DT;
+  const int lane = threadIdx.x;  // one chain per workgroup of DT threads
   const int64_t j = blockIdx.x;
   if (j >= q.n_list) return;
   const int64_t c = q.list ? q.list[j] : j;
@@ -953,7 +966,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree_crit(KP<T> p, DP<T> q, co
       s[0] += rn * vn;
       s[1] += th[d] * gd;
     }
-    block_allsum2(s[0], s[1]);
+    block_allsum2<DT>(s[0], s[1]);
     lk = sanitize(-s[0] / 2);
     if (dense_target) lp = sanitize(-s[1] / 2);
     if (lane == 0) {
@@ -961,7 +974,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_d_tree_crit(KP<T> p, DP<T> q, co
       if (dense_target) p.lp()[c] = lp;
     }
   }
-  const T e = d_tree_advance<T, CRIT>(p, q, c, lane, lp, lk);
+  const T e = d_tree_advance<T, CRIT, DT>(p, q, c, lane, lp, lk);
   if (lane == 0) q.es[c] = e;
   if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237)
     for (int d = lane; d < D; d += DT_THREADS) {

@@ -399,14 +399,26 @@ int dn_nuts_batch_momenta(Ctx<T>* c, int n_trans, double refresh_alpha) {
 template <class T>
 void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, const DP<T>& q, const T* minv_d, int per_chain, int dense_target, int do_post) {
   const bool temper = c->integ_kind == AHMC_INTEGRATOR_TEMPERED;
-#define AHMC_LAUNCH_TREE(K) hipLaunchKernelGGL(K, dim3(grid), dim3(DT_THREADS), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post)
+  const int dt = dt_threads_for(c->D);
+#define AHMC_LAUNCH_TREE(K) hipLaunchKernelGGL(K, dim3(grid), dim3(dt), 0, c->stream, p, q, minv_d, per_chain, dense_target, do_post)
+#define AHMC_TREE_BY_DT(CR, TP)                                                        \
+  do {                                                                                 \
+    if (dt == 64) AHMC_LAUNCH_TREE((k_d_tree_crit<T, CR, TP, 64>));                    \
+    else if (dt == 128) AHMC_LAUNCH_TREE((k_d_tree_crit<T, CR, TP, 128>));             \
+    else AHMC_LAUNCH_TREE((k_d_tree_crit<T, CR, TP, 256>));                            \
+  } while (0)
   if (criterion == AHMC_TC_CLASSIC) {
-    if (temper) AHMC_LAUNCH_TREE((k_d_tree_crit<T, 0, true>)); else AHMC_LAUNCH_TREE((k_d_tree_crit<T, 0, false>));
+    if (temper) AHMC_TREE_BY_DT(0, true); else AHMC_TREE_BY_DT(0, false);
   } else if (criterion == AHMC_TC_STRICT) {
-    if (temper) AHMC_LAUNCH_TREE((k_d_tree_crit<T, 2, true>)); else AHMC_LAUNCH_TREE((k_d_tree_crit<T, 2, false>));
-  } else {
-    if (temper) AHMC_LAUNCH_TREE((k_d_tree_crit<T, 1, true>)); else AHMC_LAUNCH_TREE((k_d_tree<T>));
+    if (temper) AHMC_TREE_BY_DT(2, true); else AHMC_TREE_BY_DT(2, false);
+  } else if (temper) {
+    AHMC_TREE_BY_DT(1, true);
+  } else {  // the default and the measured kernel
+    if (dt == 64) AHMC_LAUNCH_TREE((k_d_tree<T, 64>));
+    else if (dt == 128) AHMC_LAUNCH_TREE((k_d_tree<T, 128>));
+    else AHMC_LAUNCH_TREE((k_d_tree<T, 256>));
   }
+#undef AHMC_TREE_BY_DT
 #undef AHMC_LAUNCH_TREE
 }
 

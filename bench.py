@@ -458,7 +458,14 @@ def main():
                 }
             except Exception as ex:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
-        print(json.dumps(out))
+        try:  # RCCL writes its version banner to the C stdout when the first communicator is made: push it out first, so
+            import ctypes  # that the JSON line is the LAST line of stdout whatever the buffering
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)  # flushed NOW: with a process group alive the interpreter's exit path (RCCL / c10d
+        sys.stdout.flush()                  # teardown) was seen to drop a block-buffered stdout — the line must not depend on it
     comm.close()
     eng.close()
     if dist is not None:

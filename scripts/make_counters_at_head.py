@@ -40,7 +40,7 @@ for cfg in sys.argv[1:]:
         c[mode] = {k: r.get(k) for k in ("valu_per_leapfrog", "salu_per_leapfrog", "lds_per_leapfrog", "vmem_per_leapfrog", "mfma_f64_per_leapfrog",
                                           "hbm_bytes_per_leapfrog", "valu_busy", "mean_waves_per_simd")}
     out["configs"][cfg] = c
-    keep = {k: s.get(k) for k in ("config", "command", "kernel_digest", "kernel_stats", "mode0_launches", "mode3_launches", "counters", "leapfrogs_by_pass")}
+    keep = {k: s.get(k) for k in ("config", "command", "kernel_digest", "kernel_stats", "mode0_launches", "mode3_launches", "counters", "leapfrogs_by_pass", "per_kernel_counters")}
     keep["bench_plain"] = s.get("bench_plain")
     with open(os.path.join(ROOT, "profiles", f"r2_{cfg}_profile_summary.json"), "w") as f:
         json.dump(keep, f, indent=1)

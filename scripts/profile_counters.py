@@ -76,6 +76,31 @@ for name in ("fetch", "write", "sq1", "sq2", "grbm"):
             for cn, v in cur.execute("select counter_name, sum(value) from counters_collection where kernel_name = ? group by counter_name", (kn,)):
                 per_mode[f"mode{m}"][cn] += v / lf[f"mode{m}"]   # per leapfrog, with THIS pass's leapfrog count
 out["leapfrogs_by_pass"] = lf_by_pass
+# every kernel of the run: counters summed over all its dispatches (what the dense engine's kernels — k_dgemm, k_d_tree —
+# are read from: bytes moved, MFMA instructions, time from the kernel trace)
+per_kernel = defaultdict(lambda: defaultdict(float))
+for name in ("fetch", "write", "sq1", "sq2", "grbm"):
+    cur = db(name)
+    if not cur:
+        continue
+    for kn, cn, v in cur.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
+        per_kernel[kn][cn] += v
+tk = {k["name"]: k for k in out.get("kernel_stats", [])}
+rows = []
+for kn, c in per_kernel.items():
+    if kn not in tk:
+        continue
+    r = {"kernel": kn, "calls": tk[kn]["calls"], "total_ms": tk[kn]["total_us"] / 1e3, "percent": tk[kn]["percent"]}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        r["hbm_gbytes"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / 1e9
+        r["hbm_tb_per_s_by_trace_time"] = r["hbm_gbytes"] / 1e3 / (r["total_ms"] / 1e3) if r["total_ms"] else None
+    for k2 in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+        if k2 in c:
+            r[k2] = c[k2]
+    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+        r["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)
+    rows.append(r)
+out["per_kernel_counters"] = sorted(rows, key=lambda r: -r["total_ms"])
 res = {}
 for mode, c in per_mode.items():
     if not c:
