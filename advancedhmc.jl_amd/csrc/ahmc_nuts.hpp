@@ -188,10 +188,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   // Fast kernels of the multi-wave groups: the first merge's U-turn dot products are reduced together with the leaf's
   // energies (one barrier pair less per such leaf; cfg5 +7 %).  Measured SLOWER for one wave per chain (cfg2 2.12e9 ->
   // 1.87e9 although 216 -> 212 VALU per leapfrog), so G <= 64 keeps two reductions.
-#ifndef AHMC_FUSE_M0_ALL
-#define AHMC_FUSE_M0_ALL 0
-#endif
-  constexpr bool FUSE_M0 = !GENERAL && (G > 64 || AHMC_FUSE_M0_ALL);
+  constexpr bool FUSE_M0 = !GENERAL && G > 64;
   constexpr bool ADAPT = MODE >= 3;  // MODE 0 / 1 + adapt!(…) after every transition, inside the kernel (AdaptK)
   const bool strict = GENERAL && p.criterion == 2;
   const int NV = strict ? 3 : 2;  // vectors per pending level: A, RF (, RL)
