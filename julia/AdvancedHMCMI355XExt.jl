@@ -273,9 +273,18 @@ adaptor_code(::MassMatrixAdaptor) = ADAPT_MASSMATRIX
 adaptor_code(::NaiveHMCAdaptor) = ADAPT_NAIVE
 adaptor_code(::StanHMCAdaptor) = ADAPT_STAN
 
-function adaptor_init!(z::MI355XChains, a::AbstractAdaptor, δ::Real)
+"""
+    PooledVar
+
+Marker for `adaptor_init!(z, adaptor, δ; pooled=true)`: ONE shared `(D,)` M⁻¹ estimated from all chains (and all GPUs
+once `comm_init!` has been called) — `AHMC_VAR_POOLED`.  The reference has no counterpart: in matrix mode it resizes
+WelfordVar to one estimator per chain (src/adaptation/massmatrix.jl:103-121).  Needs `DiagEuclideanMetric(M⁻¹::Vector)`.
+"""
+struct PooledVar end
+
+function adaptor_init!(z::MI355XChains, a::AbstractAdaptor, δ::Real; pooled::Bool=false)
     pc = a isa MassMatrixAdaptor ? a : (hasproperty(a, :pc) ? a.pc : nothing)
-    est = pc isa AdvancedHMC.Adaptation.NutpieVar ? VAR_NUTPIE : VAR_WELFORD   # src/adaptation/massmatrix.jl:160-250
+    est = pooled ? VAR_POOLED : pc isa AdvancedHMC.Adaptation.NutpieVar ? VAR_NUTPIE : VAR_WELFORD   # src/adaptation/massmatrix.jl:160-250
     check(z.ctx, ccall((:ahmc_set_var_estimator, LIB), Cint, (Ptr{Cvoid}, Cint), z.ctx, est))
     ib, tb, ws = a isa StanHMCAdaptor ? (a.init_buffer, a.term_buffer, a.window_size) : (75, 50, 25)
     check(z.ctx, ccall((:ahmc_adaptor_init, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint, Cint),

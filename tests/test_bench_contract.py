@@ -66,3 +66,30 @@ def test_bench_json_contract(config):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in b, k
     assert b["kind"] == "port" and b["value"] > 0 and b["single_thread"]["value"] > 0
+
+
+def test_counters_are_refused_when_taken_on_other_kernels(tmp_path, monkeypatch):
+    """bench.py's roofline reads PMC counters from profiles/counters_at_head.json only when they were taken on the device
+    code of the library in use (round 1 rescaled constants from a stale file): a digest mismatch gives None + a reason"""
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    bench = importlib.import_module("bench")
+    real = bench.sources_digest()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "sources_digest", lambda: real or "d" * 64)
+    good = {"sources_digest": real or "d" * 64, "source": "test", "configs": {"cfg2": {"mode0": {"valu_per_leapfrog": 190.0}}}}
+    (prof / "counters_at_head.json").write_text(json.dumps(good))
+    c, why = bench.counters_at_head("cfg2")
+    assert c["mode0"]["valu_per_leapfrog"] == 190.0 and why == "test"
+    c, why = bench.counters_at_head("cfg3")
+    assert c is None and "cfg3" in why
+    good["sources_digest"] = "0" * 64
+    (prof / "counters_at_head.json").write_text(json.dumps(good))
+    c, why = bench.counters_at_head("cfg2")
+    assert c is None and "stale" in why
+    (prof / "counters_at_head.json").unlink()
+    c, why = bench.counters_at_head("cfg2")
+    assert c is None and "missing" in why
