@@ -16,7 +16,12 @@ for CFG in "$@"; do
   echo "$CMD" > $O/cmd.txt
   timeout 600 $CMD > $O/bench_plain.json 2> $O/bench_plain.err
   timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/kt.json 2> $O/kt.err
-  pmc() { name=$1; shift; timeout 900 rocprofv3 --pmc "$@" --kernel-trace -d $O/$name -o $name -- $CMD > $O/$name.json 2> $O/$name.err; }
+  # PROFILE_PASSES bounds the run for the dense configs (hundreds of thousands of dispatches per pass: the five
+  # databases of a 4-step cfg4 run filled the box's disk)
+  P=" ${PROFILE_PASSES:-fetch write sq1 sq2 grbm} "
+  pmc() { name=$1; shift; case "$P" in *" $name "*) ;; *) return;; esac
+          timeout 900 rocprofv3 --pmc "$@" --kernel-trace -d $O/$name -o $name -- $CMD > $O/$name.json 2> $O/$name.err
+          find $O/$name -name "*.csv" -size +8M -delete; }
   pmc fetch FETCH_SIZE
   pmc write WRITE_SIZE
   pmc sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_F64
