@@ -175,6 +175,7 @@ struct Ctx : CtxBase {
   int64_t dn_global_steps = 0, dn_chain_steps = 0;
   hipStream_t stream2 = nullptr;  // second pipeline of the dense NUTS loop (dn_nuts_transition)
   hipEvent_t ev_split = nullptr, ev_join = nullptr;
+  hipEvent_t ev_gemm[2] = {nullptr, nullptr}, ev_tree[2] = {nullptr, nullptr};  // AHMC_DENSE_SPLIT=2: GEMM stream <-> tree stream hand-over per chain half
   // WelfordCov of the shared dense metric: μ (D) [+ batch mean + column-sum partials], M, batch scatter, estimate
   T *wc_mu = nullptr, *wc_M = nullptr, *wc_S = nullptr, *wc_cov = nullptr;
   T* dn_C = nullptr;   // M⁻¹·P (dense metric + dense target), see dn_refresh_fused
@@ -199,7 +200,7 @@ struct Ctx : CtxBase {
     if (red) (void)hipFree(red);
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
-    for (hipEvent_t e : {ev_split, ev_join})
+    for (hipEvent_t e : {ev_split, ev_join, ev_gemm[0], ev_gemm[1], ev_tree[0], ev_tree[1]})
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {stage_ready[0], stage_ready[1], stage_free[0], stage_free[1]})
       if (e) (void)hipEventDestroy(e);

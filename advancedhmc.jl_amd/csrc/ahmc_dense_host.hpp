@@ -469,6 +469,14 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // the time.  Chains are independent: the chain set is cut in two halves, each stepping through GEMM → tree on its
   // own stream with its own running-chain list, and the hardware overlaps one half's tree kernel with the other
   // half's GEMM.  (Dense target only: the built-in families' cache kernel has no chain list.)
+  //
+  // AHMC_DENSE_SPLIT=1 (default) gives each half its own stream.  Nothing then keeps the halves out of phase: both GEMMs
+  // are enqueued together and share the matrix pipe, then both tree kernels share HBM — which is what the measured
+  // +2.5 % says happened.  AHMC_DENSE_SPLIT=2 orders the work by KIND instead: every GEMM on the context's stream (A0 B0
+  // A1 B1 …), every tree kernel on the second stream (A0 B0 A1 …), with an event per half in each direction (tree k
+  // waits for GEMM k; the next GEMM of that half waits for its tree kernel).  Stream order then forces the phase shift:
+  // GEMM B(s) can only run beside tree A(s), GEMM A(s+1) beside tree B(s).  Same kernels on the same data: bit-identical
+  // results.  (Not yet measured on the GPU — DESIGN §7.)
   const int CHUNK = 16;
   const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
   const int split_env = getenv("AHMC_DENSE_SPLIT") ? atoi(getenv("AHMC_DENSE_SPLIT")) : 1;  // (read per call: the tests toggle it)
@@ -480,9 +488,16 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     HIPCHK(hipEventCreateWithFlags(&c->ev_split, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
+  const bool by_kind = NP == 2 && split_env == 2 && dm && c->dn_fused_ok;  // (one GEMM launch per half and step)
+  if (by_kind && !c->ev_gemm[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipEventCreateWithFlags(&c->ev_gemm[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->ev_tree[k], hipEventDisableTiming));
+    }
+  }
   for (int k = 0; k < NP; ++k) {
     Pipe& h = pipes[k];
-    h.s = k == 0 ? c->stream : c->stream2;
+    h.s = (k == 0 && !by_kind) ? c->stream : c->stream2;  // (by kind: the stream of the half's tree kernel, compaction and read-back)
     h.lists = c->dn_list + (size_t)k * 2 * c->N;
     h.cnt = c->dn_active + 1 + k;
     h.pp = 0;
@@ -502,6 +517,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_split, 0));
   }
   auto bail = [&](int code) { c->stream = main_stream; return code; };
+  bool tree_recorded[2] = {false, false};
   for (int64_t done_steps = 0; done_steps < max_steps && (pipes[0].n_list > 0 || (NP == 2 && pipes[1].n_list > 0));) {
     for (int s = 0; s < CHUNK; ++s) {
       for (int k = 0; k < NP; ++k) {
@@ -512,7 +528,15 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
         q.n_list = h.n_list;
         // one global step = g′ = Pθ′ (or the built-in family's kernel), w′ = M⁻¹g′, then the fused
         // second-half / tree / first-half kernel
-        if (dt && dm && c->dn_fused_ok) {
+        if (by_kind) {
+          c->stream = main_stream;
+          if (tree_recorded[k] && hipStreamWaitEvent(main_stream, c->ev_tree[k], 0) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipStreamWaitEvent failed"));
+          rc = dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list, c->dn_C, Wcur);
+          if (rc) return bail(rc);
+          if (hipEventRecord(c->ev_gemm[k], main_stream) != hipSuccess || hipStreamWaitEvent(h.s, c->ev_gemm[k], 0) != hipSuccess)
+            return bail(fail(c, AHMC_ERR_RUNTIME, "hipEventRecord / hipStreamWaitEvent failed"));
+          c->stream = h.s;
+        } else if (dt && dm && c->dn_fused_ok) {
           rc = dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list, c->dn_C, Wcur);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
           if (rc) return bail(rc);
         } else {
@@ -524,6 +548,10 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
           }
         }
         launch_d_tree(c, criterion, (unsigned)h.n_list, p, q, minv_d, pc, dt ? 1 : 0, 1);
+        if (by_kind) {
+          if (hipEventRecord(c->ev_tree[k], h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipEventRecord failed"));
+          tree_recorded[k] = true;
+        }
       }
     }
     done_steps += CHUNK;
