@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""Find VGPR spill stores that the compiler placed under a NARROWED exec mask (between an `s_and_saveexec` and the
+`s_or_b64 exec, exec, …` that restores it) whose slot is reloaded elsewhere: only the active lanes' copies reach scratch,
+a later full-wave reload hands the other lanes stale memory.  This is what made the (128,8) multi-wave instantiation of
+k_nuts return wrong candidates / fault when its leaf used the single-value reduction: the lane-0-only block
+of the cross-wave exchange (`if ((threadIdx.x & 63) == 0) b[w] = v;`) received the spill of a wave-uniform 64-bit index.
+
+    python scripts/isa_masked_spills.py            # every unit of the shipped build (csrc/build/*.o)
+    python scripts/isa_masked_spills.py file.s ...  # disassembly files (llvm-objdump -d --no-show-raw-insn)
+
+Exit status 1 if any kernel has such a store."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def disassemble(obj, tmp):
+    import shutil
+
+    cp = os.path.join(tmp, os.path.basename(obj))
+    shutil.copyfile(obj, cp)
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", cp], capture_output=True, check=True)
+    co = cp + ".0.hipv4-amdgcn-amd-amdhsa--gfx950"
+    return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+
+
+def scan(text, label):
+    bad = []
+    kernel, lines, addrs, targets, kbase = None, [], [], set(), 0
+
+    def flush():
+        if not kernel:
+            return
+        tset = {kbase + t for t in targets}
+        # stores under a narrowed exec: a region opens at s_and(n2)_saveexec and closes at the next instruction that writes exec
+        # (linear order; nested regions close their parents too — conservative in the direction of fewer reports).  A store in
+        # a region is suspicious when the LAST definition of the stored registers lies BEFORE the region opened, i.e. the value
+        # was made under the wider mask and only the active lanes' copies reach the slot, and the slot is reloaded outside.
+        masked = []
+        region = None
+        loads = {}
+        for i, t in enumerate(lines):
+            m = re.search(r"scratch_load_\w+ .*offset:(\d+)", t)
+            if m:
+                loads.setdefault(int(m.group(1)), []).append((i, region is not None))
+            if re.match(r"s_and(n2)?_saveexec_b64", t):
+                region = i
+                continue
+            if region is not None and re.match(r"(s_or_b64|s_mov_b64|s_xor_b64|s_andn2_b64|s_and_b64|s_or_saveexec_b64) exec", t.replace("s_or_saveexec_b64 ", "s_or_saveexec_b64 exec ")):
+                region = None
+                continue
+            m = re.search(r"scratch_store_\w+ off, v\[?(\d+)(?::(\d+))?\]?, .*offset:(\d+)", t)
+            if m and region is not None:
+                lo, hi = int(m.group(1)), int(m.group(2) or m.group(1))
+                masked.append((i, region, lo, hi, int(m.group(3)), t.split("//")[0].strip()))
+
+        def writes(t, lo, hi):
+            mm = re.match(r"(v_\w+|scratch_load_\w+|global_load_\w+|flat_load_\w+|ds_read\w*|buffer_load_\w+)\s+v\[?(\d+)(?::(\d+))?\]?", t)
+            if not mm or mm.group(1).startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                return False
+            a, b = int(mm.group(2)), int(mm.group(3) or mm.group(2))
+            if a <= hi and b >= lo:
+                return True
+            if "permlane" in mm.group(1):  # the swaps write their second operand too
+                m2 = re.search(r",\s*v(\d+)", t)
+                return bool(m2) and lo <= int(m2.group(1)) <= hi
+            return False
+
+        # every store per slot: a slot that ALSO receives a store under the full mask is the compiler's way of merging two
+        # paths through memory (store the bypass value for all lanes, overwrite the active lanes inside the region) — legal;
+        # the dangerous case is a slot whose ONLY stores are masked ones of values made under the wider mask
+        all_stores = {}
+        reg = None
+        for i, t in enumerate(lines):
+            if re.match(r"s_and(n2)?_saveexec_b64", t):
+                reg = i
+            elif reg is not None and re.match(r"(s_or_b64|s_mov_b64|s_xor_b64|s_andn2_b64|s_and_b64) exec", t):
+                reg = None
+            m = re.search(r"scratch_store_\w+ .*offset:(\d+)", t)
+            if m:
+                all_stores.setdefault(int(m.group(1)), []).append(reg is not None)
+        for i, r, lo, hi, off, t in masked:
+            d = next((j for j in range(i - 1, -1, -1) if writes(lines[j], lo, hi)), -1)
+            outside = [j for j, inside in loads.get(off, []) if not inside]
+            # only straight-line regions are judged (linear order says nothing across loops): no branch between the saveexec
+            # and the store other than the skip branch right behind the saveexec, and no branch target inside
+            straight = all(not re.match(r"s_c?branch", lines[j]) for j in range(r + 2, i)) and not any(addrs[j] in tset for j in range(r + 1, i + 1))
+            if d < r and outside and all(all_stores.get(off, [True])) and straight:
+                bad.append((kernel, i + 1, t + f"   [value defined {i - d} instructions earlier, region opened {i - r} earlier]", len(outside)))
+
+    for raw in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", raw.strip())
+        if m:
+            flush()
+            kernel, lines, addrs, targets = m.group(1), [], [], set()
+            kbase = int(raw.strip().split()[0], 16)
+            continue
+        t = raw.strip()
+        if t:
+            lines.append(t)
+            ma = re.search(r"//\s*([0-9A-Fa-f]+):", t)
+            addrs.append(int(ma.group(1), 16) if ma else -1)
+            mt = re.search(r"^s_c?branch\S*\s.*<[^>]*\+0x([0-9a-f]+)>", t)
+            if mt:
+                targets.add(int(mt.group(1), 16))
+    flush()
+    names = subprocess.run(["c++filt"], input="\n".join(b[0] for b in bad), capture_output=True, text=True).stdout.splitlines() if bad else []
+    for (k, ln, t, n), nm in zip(bad, names):
+        print(f"{label}: {nm[:70]}: line {ln}: {t}  (slot reloaded {n}x outside a masked region)")
+    return len(bad)
+
+
+def main():
+    n = 0
+    if len(sys.argv) > 1:
+        for f in sys.argv[1:]:
+            n += scan(open(f).read(), os.path.basename(f))
+    else:
+        obj = os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "build")
+        tmp = os.path.join(ROOT, "build_tmp", "isa_scan")
+        os.makedirs(tmp, exist_ok=True)
+        for f in sorted(os.listdir(obj)):
+            if f.endswith(".o"):
+                k = scan(disassemble(os.path.join(obj, f), tmp), f)
+                print(f"{f}: {k} masked spill store(s) with outside reloads")
+                n += k
+    sys.exit(1 if n else 0)
+
+
+if __name__ == "__main__":
+    main()
