@@ -3,8 +3,9 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
 git-ignored but travels with the repo snapshot to the GPU box.
 
-Translation units (compiled in parallel; objects cached under csrc/build/, each with the digest of the
-files it was compiled from — taken from the compiler's own dependency list — so that a change to the host
+Translation units (compiled in parallel; objects cached OUTSIDE the repository — `$AHMC_BUILD_CACHE`, else
+`$XDG_CACHE_HOME/ahmc_build`, else `~/.cache/ahmc_build` — so that nothing but the linked .so and its two digest stamps
+ever lands in the tree that `gpurun` snapshots; each object carries the digest of the files it was compiled from — taken from the compiler's own dependency list — so that a change to the host
 side or to the dense engine does not recompile the eight log-density instantiations):
   ahmc_api.hip                      host side of the C ABI + the target-independent kernels
   ahmc_inst.hip  × {f32,f64} × {iso,diag,funnel,hier}
@@ -19,9 +20,24 @@ import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
+try:
+    from . import isa_check
+except ImportError:  # run as a plain script / imported by path
+    import isa_check
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-OBJ = os.path.join(CSRC, "build")
+
+
+def _cache_dir() -> str:
+    """object cache outside the repository (the tree that travels to the GPU box holds sources, the .so and its stamps only)"""
+    base = os.environ.get("AHMC_BUILD_CACHE")
+    if not base:
+        base = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "ahmc_build")
+    return base
+
+
+OBJ = _cache_dir()
 OUT = os.path.join(CSRC, "libahmc_hip.so")
 INCLUDE = os.path.join(_HERE, "..", "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
@@ -64,7 +80,7 @@ def kernel_digest() -> str:
 
 def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     digest = _sources_digest()
-    stamp = OUT + ".digest"  # next to the .so (csrc/build/ holds only objects and does not travel to the GPU box)
+    stamp = OUT + ".digest"  # next to the .so (the object cache is outside the repo and does not travel to the GPU box)
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == digest:
         if not os.path.exists(OUT + ".kdigest"):
             with open(OUT + ".kdigest", "w") as f:
@@ -107,6 +123,15 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed on {name}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        # static check of the code object just made: a VGPR spill stored only under a narrowed exec mask and reloaded
+        # under the full one is a register-allocation artefact that returns wrong results on the device (isa_check.py,
+        # DESIGN §7.3).  The build fails on it — it is not a skippable test.
+        if isa_check.available() and not os.environ.get("AHMC_SKIP_ISA_CHECK"):
+            nbad = isa_check.check_object(obj, name)
+            if nbad:
+                os.remove(obj)
+                raise RuntimeError(f"{name}: {nbad} spill store(s) under a narrowed exec mask with outside reloads (see above); "
+                                   "the object was discarded")
         d = unit_digest(dep, defs)
         if d is not None:
             with open(dig, "w") as f:

@@ -5,8 +5,11 @@ a later full-wave reload hands the other lanes stale memory.  This is what made 
 k_nuts return wrong candidates / fault when its leaf used the single-value reduction: the lane-0-only block
 of the cross-wave exchange (`if ((threadIdx.x & 63) == 0) b[w] = v;`) received the spill of a wave-uniform 64-bit index.
 
-    python scripts/isa_masked_spills.py            # every unit of the shipped build (csrc/build/*.o)
-    python scripts/isa_masked_spills.py file.s ...  # disassembly files (llvm-objdump -d --no-show-raw-insn)
+`build.py` runs `check_object` on every translation unit it compiles and FAILS THE BUILD when one has the pattern (the
+disassembly goes through a temporary directory outside the repository and is deleted).  By hand:
+
+    python -m ahmc_amd.isa_check                 # every unit in the object cache of the build
+    python advancedhmc.jl_amd/isa_check.py file.s ...  # disassembly files (llvm-objdump -d --no-show-raw-insn)
 
 Exit status 1 if any kernel has such a store."""
 import os
@@ -14,8 +17,20 @@ import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import tempfile
+
 LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def available() -> bool:
+    return os.path.exists(f"{LLVM}/llvm-objdump")
+
+
+def check_object(obj, label=None, quiet=False) -> int:
+    """number of masked-spill findings in one object file (disassembled in a throw-away directory under $TMPDIR)"""
+    with tempfile.TemporaryDirectory(prefix="ahmc_isa_") as tmp:
+        text = disassemble(obj, tmp)
+    return scan(text, label or os.path.basename(obj), quiet=quiet)
 
 
 def disassemble(obj, tmp):
@@ -28,7 +43,7 @@ def disassemble(obj, tmp):
     return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
 
 
-def scan(text, label):
+def scan(text, label, quiet=False):
     bad = []
     kernel, lines, addrs, targets, kbase = None, [], [], set(), 0
 
@@ -110,6 +125,8 @@ def scan(text, label):
     flush()
     names = subprocess.run(["c++filt"], input="\n".join(b[0] for b in bad), capture_output=True, text=True).stdout.splitlines() if bad else []
     for (k, ln, t, n), nm in zip(bad, names):
+        if quiet:
+            continue
         print(f"{label}: {nm[:70]}: line {ln}: {t}  (slot reloaded {n}x outside a masked region)")
     return len(bad)
 
@@ -120,12 +137,13 @@ def main():
         for f in sys.argv[1:]:
             n += scan(open(f).read(), os.path.basename(f))
     else:
-        obj = os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "build")
-        tmp = os.path.join(ROOT, "build_tmp", "isa_scan")
-        os.makedirs(tmp, exist_ok=True)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import build as B  # the object cache lives outside the repository
+
+        obj = B.OBJ
         for f in sorted(os.listdir(obj)):
             if f.endswith(".o"):
-                k = scan(disassemble(os.path.join(obj, f), tmp), f)
+                k = check_object(os.path.join(obj, f), f)
                 print(f"{f}: {k} masked spill store(s) with outside reloads")
                 n += k
     sys.exit(1 if n else 0)

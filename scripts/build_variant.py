@@ -4,7 +4,7 @@
     python scripts/build_variant.py mfma -DAHMC_MFMA_REDUCE=1
     AHMC_HIP_LIB=advancedhmc.jl_amd/csrc/variants/libahmc_hip_mfma.so python bench.py ...
 
-Same sources, extra -D flags; objects under csrc/build/variants/<name>/ (do not travel), the .so under csrc/variants/
+Same sources, extra -D flags; objects under <object cache>/variants/<name>/ (outside the repository), the .so under csrc/variants/
 (travels: *.so is git-ignored, not gpurun-ignored).  The shipped library is never touched."""
 import os
 import subprocess

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel ISA digests of the built HIP engine (advancedhmc.jl_amd/csrc/build/*.o).
+"""Per-kernel ISA digests of the built HIP engine (the object cache of build.py, outside the repository).
 
     python scripts/isa_digest.py out.json            # write {unit: {kernel: sha1 of its gfx950 instructions}}
     python scripts/isa_digest.py out.json base.json  # ... and report kernels whose code differs from base.json
@@ -14,7 +14,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJ = os.environ.get("AHMC_OBJ_DIR") or os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "build")  # AHMC_OBJ_DIR: another build's objects
+sys.path.insert(0, ROOT)
+from ahmc_amd import build as _B  # noqa: E402
+
+OBJ = os.environ.get("AHMC_OBJ_DIR") or _B.OBJ  # the build's object cache (outside the repository); AHMC_OBJ_DIR: another build's objects
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
