@@ -266,11 +266,13 @@ def test_nuts_geometries_and_targets(hip, oracle, rng, D, target):
         assert n_div > 0, "the funnel at eps=0.5 must produce divergent transitions (Δ_max test, :500-507)"
 
 
-@pytest.mark.parametrize("D,target", [(400, "iso"), (600, "hier"), (1000, "iso"), (2048, "iso"), (2048, "funnel"), (3000, "diag")])
+@pytest.mark.parametrize("D,target", [(400, "iso"), (600, "hier"), (1000, "iso"), (2048, "iso"), (2048, "funnel"), (2048, "hier"), (3000, "diag")])
 def test_multiwave_chains(hip, oracle, rng, D, target):
     """D > 512: a chain spans 2-8 wavefronts of one workgroup (cross-wave reductions through LDS).
-    Every transition kind on those geometries — BASELINE.json configs[4] is D = 2048."""
-    N = 24
+    Every transition kind on those geometries — BASELINE.json configs[4] is D = 2048 hierarchical Gaussian: that
+    very pair runs with 64 chains (every chain must agree: 0.999 × 64 > 63)."""
+    N = 64 if (D, target) == (2048, "hier") else 24
+    bar = 0.999 if N == 64 else 0.95
     dtype = np.float64
     h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), make_target(target, D, rng))
     eps = 0.3 * D ** -0.25
@@ -299,7 +301,7 @@ def test_multiwave_chains(hip, oracle, rng, D, target):
             sg = g.stats()
             if dbg: print("[trace]   hip stats done", file=sys.stderr, flush=True)
             so = o.stats()
-            same = compare_transition_stats(sg, so, dtype, 0.95)
+            same = compare_transition_stats(sg, so, dtype, bar)
             if dbg: print(f"[trace]   same {same.mean()}", file=sys.stderr, flush=True)
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
@@ -890,23 +892,25 @@ def test_cfg2_pipeline_against_oracle(hip, oracle):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("offset", [0, 30000, 65536 - 256])
-def test_full_size_slice_against_oracle(hip, oracle, offset):
-    """cfg2 at FULL size on the HIP engine (65 536 chains × D = 128, per-chain M⁻¹ and ϵ, dispatch order by step size,
-    batched launches) — and 256 of its chains replayed by the oracle with the same global Philox stream
-    (chain_offset): the chains of a full launch must be the chains of a small one, bit-for-decision."""
-    D, N, n = 128, 65536, 256
+@pytest.mark.parametrize("cfg,offset", [("cfg2", 0), ("cfg2", 30000), ("cfg2", 65536 - 256), ("cfg3", 0), ("cfg3", 41000), ("cfg3", 65536 - 256)])
+def test_full_size_slice_against_oracle(hip, oracle, cfg, offset):
+    """cfg2 (65 536 chains × D = 128 iso Gaussian) and cfg3 (65 536 × D = 32 Neal's funnel, 4 chains per wave in lockstep,
+    divergent paths) at FULL size on the HIP engine — per-chain M⁻¹ and ϵ, dispatch order by step size, batched launches —
+    and 256 of its chains replayed by the oracle with the same global Philox stream (chain_offset): the chains of a full
+    launch must be the chains of a small one, bit-for-decision."""
+    N, n = 65536, 256
+    D, target = (128, A.IsoGaussian(128)) if cfg == "cfg2" else (32, A.Funnel(32))
     rs = np.random.default_rng(11)
     minv = np.asfortranarray(0.5 + rs.random((D, N)))
-    eps = 0.25 * (0.6 + 0.8 * rs.random(N))
+    eps = (0.25 if cfg == "cfg2" else 0.35) * (0.6 + 0.8 * rs.random(N))
     th0 = np.asfortranarray(rs.normal(size=(D, N)))
-    k_of = lambda e: A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(e), A.GeneralisedNoUTurn()))  # noqa: E731
-    g = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(minv), A.IsoGaussian(D)), N, rng=A.PhiloxRNG(42), lib=hip)
+    k_of = lambda e: A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(e), A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))  # noqa: E731
+    g = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(minv), target), N, rng=A.PhiloxRNG(42), lib=hip)
     g.set_integrator(A.Leapfrog(eps))
     g.set_position(th0)
     g.run(k_of(eps), 4)           # 4 transitions in ONE launch, chains dispatched in ascending-ϵ order
     sl = slice(offset, offset + n)
-    o = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(np.asfortranarray(minv[:, sl])), A.IsoGaussian(D)), n,
+    o = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(np.asfortranarray(minv[:, sl])), target), n,
                  rng=A.PhiloxRNG(42, chain_offset=offset), lib=oracle)
     o.set_integrator(A.Leapfrog(eps[sl]))
     o.set_position(th0[:, sl])
@@ -919,9 +923,85 @@ def test_full_size_slice_against_oracle(hip, oracle, offset):
     assert (same | ~on).all()
     np.testing.assert_allclose(sg["hamiltonian_energy"][sl][on], so["hamiltonian_energy"][on], rtol=1e-9)
     np.testing.assert_allclose(sg["acceptance_rate"][sl][on], so["acceptance_rate"][on], rtol=1e-8, atol=1e-10)
+    np.testing.assert_array_equal(sg["numerical_error"][sl][on], so["numerical_error"][on])
     ag, ao = g.accum(), o.accum()
     np.testing.assert_allclose(ag["sum_theta"][:, sl][:, on], ao["sum_theta"][:, on], rtol=1e-8, atol=1e-8)
+    if cfg == "cfg3":
+        assert ao["n_divergent"] > 0, "the funnel slice must contain divergent transitions"
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("metric", ["identity", "spd"])
+def test_cfg4_shape_against_oracle(hip, oracle, metric):
+    """BASELINE configs[3] at its own shape: D = 512, Σᵢⱼ = 0.9^|i−j| as a dense Gaussian target (ℓπ = −½θᵀΣ⁻¹θ, the gradient
+    a GEMM), shared DenseEuclideanMetric (`identity` = cfg4's initial M⁻¹ = I; `spd` = a well-conditioned full matrix, so the
+    second product (M⁻¹P)θ′ and the momentum solve U⁻¹z are not trivial), NUTS(0.8) + StepSizeAdaptor — on 2 304 chains, so
+    the engine runs what the bench runs: the 64×64-tile `k_dgemm` (both products in one launch, 16 × 18 workgroups per
+    half), the two chain pipelines on two streams, compaction, `k_d_tree<T,256>`.  The oracle replays the FIRST and the LAST
+    64 chains (one in each pipeline) through `chain_offset` (src/hamiltonian.jl:60-68,179-184, src/metric.jl:311-320,
+    src/trajectory.jl:626-742 per chain).  Every iteration (transition + adapt!) starts from the oracle's state for those
+    chains and is held to the bar: identical discrete decisions on ≥ 99.9 % of them (i.e. all 128), 1e-8 on θ, r, ∇ℓπ."""
+    D, N, n = 512, 2304, 64
+    idx = np.arange(D)
+    Sigma = 0.9 ** np.abs(idx[:, None] - idx[None, :])
+    P = np.asfortranarray(np.linalg.inv(Sigma))
+    rs = np.random.default_rng(2024)
+    if metric == "identity":
+        Minv = np.eye(D, order="F")
+    else:
+        Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+        Minv = (Q * np.linspace(0.6, 2.0, D)) @ Q.T
+        Minv = np.asfortranarray((Minv + Minv.T) / 2)
+    target = A.DenseGaussian(P)
+    th0 = np.asfortranarray(rs.normal(size=(D, N)))
+    eps0 = 0.12 * (0.7 + 0.6 * rs.random(N))
+    lf = A.Leapfrog(eps0)
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+    g = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), target), N, rng=A.PhiloxRNG(77), lib=hip)
+    g.set_integrator(lf)
+    g.set_position(th0)
+    g.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+    offsets = (0, N - n)
+    os_ = []
+    for off in offsets:
+        o = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), target), n, rng=A.PhiloxRNG(77, chain_offset=off), lib=oracle)
+        o.set_integrator(A.Leapfrog(eps0[off:off + n]))
+        o.set_position(th0[:, off:off + n])
+        o.adaptor_init(A.StepSizeAdaptor(0.8, A.Leapfrog(eps0[off:off + n])))
+        os_.append(o)
+    n_adapts, n_iter = 3, 4            # three adapting iterations and one draw after finalize!
+    depth_seen = 0
+    for i in range(1, n_iter + 1):
+        # start the iteration from the oracle's state on the replayed chains (θ, r, caches, ϵ, DAState)
+        sg = g.get_state()
+        for off, o in zip(offsets, os_):
+            so = o.get_state()
+            sl = slice(off, off + n)
+            for key in ("theta", "r", "grad"):
+                sg[key][:, sl] = so[key]
+            sg["lp"][sl] = so["lp"]
+            sg["stepsize"][sl] = so["stepsize"]
+            if sg["da"] is not None:
+                sg["da"][:, sl] = so["da"]
+            assert sg["adaptor"] == so["adaptor"]
+        g.set_state(sg)
+        g.run(k, i, n_adapts, i_first=i)
+        st_g, zg, eg = g.stats(), g.phasepoint(), g.get_stepsize()
+        for off, o in zip(offsets, os_):
+            o.run(k, i, n_adapts, i_first=i)
+            sl = slice(off, off + n)
+            st_o, zo = o.stats(), o.phasepoint()
+            sub = {key: v[sl] for key, v in st_g.items()}
+            same = compare_transition_stats(sub, st_o, np.float64, 0.999)
+            np.testing.assert_allclose(zg.theta[:, sl][:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(zg.r[:, sl][:, same], zo.r[:, same], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(zg.lp.gradient[:, sl][:, same], zo.lp.gradient[:, same], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(eg[sl][same], o.get_stepsize()[same], rtol=1e-9, err_msg=f"ϵ after adapt! {i}")
+            depth_seen = max(depth_seen, int(st_o["tree_depth"].max()))
+    assert depth_seen >= 5, depth_seen   # trees of 32+ leaves: merges on several pending levels, compaction of finished chains
+    g.close()
+    for o in os_:
+        o.close()
 
 
 def test_fixed_integration_time_hmcda(hip, oracle, rng):
