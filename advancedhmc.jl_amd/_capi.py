@@ -14,12 +14,13 @@ import os
 import numpy as np
 
 # --- enums (mirror include/ahmc_hip.h) --------------------------------------------------------
-AHMC_ABI_VERSION = 3
+AHMC_ABI_VERSION = 4
 OK, ERR_ARGUMENT, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_STATE = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
 (TARGET_ISO_GAUSS, TARGET_DIAG_GAUSS, TARGET_FUNNEL, TARGET_HIER_GAUSS, TARGET_DENSE_GAUSS,
- TARGET_EXTERNAL) = range(6)
+ TARGET_EXTERNAL, TARGET_PLUGIN, TARGET_KERNEL) = range(8)
+KERNEL_HIP_FUNCTION, KERNEL_HIP_SYMBOL, KERNEL_HOST = 0, 1, 2
 INTEGRATOR_LEAPFROG, INTEGRATOR_JITTERED, INTEGRATOR_TEMPERED = 0, 1, 2
 TS_ENDPOINT, TS_MULTINOMIAL, TS_SLICE = 0, 1, 2
 TC_CLASSIC, TC_GENERALISED, TC_STRICT = 0, 1, 2
@@ -105,6 +106,8 @@ SIGNATURES = {
     "ahmc_sync": (_i32, [_vp]),
     "ahmc_stream": (_vp, [_vp]),
     "ahmc_set_target": (_i32, [_vp, _i32, _vp, _i64]),
+    "ahmc_set_target_plugin": (_i32, [_vp, C.c_char_p, _vp, _i64]),
+    "ahmc_set_target_kernel": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
     "ahmc_set_metric": (_i32, [_vp, _i32, _vp, _i64]),
     "ahmc_get_metric": (_i32, [_vp, _vp, _i64]),
     "ahmc_set_stepsize": (_i32, [_vp, _vp, _i64]),
@@ -133,6 +136,8 @@ SIGNATURES = {
     "ahmc_sample_from": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i64, _i32, _vp]),
     "ahmc_get_accum": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
     "ahmc_reset_accum": (_i32, [_vp]),
+    "ahmc_get_accum_state": (_i32, [_vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
+    "ahmc_set_accum_state": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ahmc_get_info": (_i32, [_vp, _i32, C.POINTER(_i64)]),
     "ahmc_ext_begin": (_i32, [_vp, C.POINTER(KernelCfg), _i32]),
     "ahmc_ext_find_good_stepsize_begin": (_i32, [_vp, _f64, _i32]),

@@ -198,6 +198,36 @@ class ExternalTarget:
 
 
 @dataclass
+class PluginTarget:
+    """User log-density as a HIP DEVICE FUNCTION compiled INTO the engine's trajectory kernels (include/ahmc_user_target.h
+    has the contract; ahmc_set_target_plugin): `source` is the path of a header defining
+    `ahmc_user::logdensity<T, G, E>(params, D, theta, grad_neg, lane, d0)`.  The engine compiles it (hipcc, cached by content)
+    for the context's element type and thread geometry the first time it is bound; from then on the density runs inside the
+    same fused kernels as a built-in family — no host round trip.  HIP engine only (the CPU checker takes the same density
+    as an ExternalTarget callback or a host KernelTarget)."""
+    D: int
+    source: str
+    params: Optional[np.ndarray] = None
+    kind: int = capi.TARGET_PLUGIN
+
+
+@dataclass
+class KernelTarget:
+    """User log-density as a device KERNEL the engine launches itself (ahmc_set_target_kernel): `handle` is a hipFunction_t
+    (handle_kind = capi.KERNEL_HIP_FUNCTION; what hipModuleGetFunction returns / AMDGPU.jl compiles a Julia kernel to), the
+    host address of a __global__ symbol (KERNEL_HIP_SYMBOL), or — CPU checker only — a ctypes callback with the kernel's
+    signature (KERNEL_HOST):  f(theta, lp, grad_neg, cols, n_cols, D, N, user)."""
+    D: int
+    handle: object
+    handle_kind: int = capi.KERNEL_HIP_FUNCTION
+    block_threads: int = 256
+    chains_per_block: int = 1
+    user: object = None
+    kind: int = capi.TARGET_KERNEL
+    params: Optional[np.ndarray] = None
+
+
+@dataclass
 class Hamiltonian:
     """src/hamiltonian.jl:1-20 (GaussianKinetic only, :18-20)"""
     metric: AbstractMetric
@@ -498,6 +528,19 @@ class Engine:
     # -- configuration --
     def set_target(self, target):
         p = None if target.params is None else np.ascontiguousarray(target.params, dtype=self.dtype)
+        if isinstance(target, PluginTarget):
+            from .build import build_target_plugin
+
+            so = build_target_plugin(target.source, self.dtype, self.info("group_lanes"), self.info("elems_per_lane"))
+            self._call("ahmc_set_target_plugin", so.encode(), capi.as_ptr(p), 0 if p is None else p.size)
+            return
+        if isinstance(target, KernelTarget):
+            h = target.handle
+            self._kernel_keepalive = (h, target.user)  # (a ctypes callback must outlive the context's use of it)
+            hp = C.cast(h, C.c_void_p) if not isinstance(h, (int, C.c_void_p)) else (C.c_void_p(h) if isinstance(h, int) else h)
+            up = target.user if isinstance(target.user, C.c_void_p) else C.c_void_p(target.user)
+            self._call("ahmc_set_target_kernel", int(target.handle_kind), hp, int(target.block_threads), int(target.chains_per_block), up)
+            return
         self._call("ahmc_set_target", target.kind, capi.as_ptr(p), 0 if p is None else p.size)
 
     def set_metric(self, metric):
@@ -704,9 +747,16 @@ class Engine:
             self._vector_mode = False
             z = self.phasepoint()
             self._vector_mode = True
+        ntr = C.c_int64()
+        acc = {"n_steps": np.empty(self.N, dtype=np.int64), "n_divergent": np.empty(self.N, dtype=np.int64),
+               "sum_theta": np.empty((self.N, self.D), dtype=self.dtype), "sumsq_theta": np.empty((self.N, self.D), dtype=self.dtype),
+               "energy_sums": np.empty((5, self.N), dtype=self.dtype)}
+        self._call("ahmc_get_accum_state", C.byref(ntr), capi.as_ptr(acc["n_steps"]), capi.as_ptr(acc["n_divergent"]), capi.as_ptr(acc["sum_theta"]),
+                   capi.as_ptr(acc["sumsq_theta"]), capi.as_ptr(acc["energy_sums"]))
+        acc["n_transitions"] = ntr.value
         return {"adaptor": {k: getattr(st, k) for k, _ in capi.AdaptorState._fields_}, "da": da, "welford": wv,
                 "theta": z.theta, "r": z.r, "lp": z.lp.value, "grad": z.lp.gradient,
-                "metric": self.get_metric(), "metric_kind": self.metric_kind, "stepsize": self.get_stepsize()}
+                "metric": self.get_metric(), "metric_kind": self.metric_kind, "stepsize": self.get_stepsize(), "accum": acc}
 
     def set_state(self, state: dict):
         if state["metric"] is not None:
@@ -719,6 +769,12 @@ class Engine:
         self._call("ahmc_set_phasepoint", capi.as_ptr(th), capi.as_ptr(r), capi.as_ptr(lp), capi.as_ptr(g))
         st = capi.AdaptorState(**state["adaptor"])
         self._call("ahmc_set_adaptor_state", C.byref(st), capi.as_ptr(state["da"]), capi.as_ptr(state["welford"]))
+        acc = state.get("accum")
+        if acc is not None:  # the running accumulators (Σθ, Σθ², Σ n_steps, the energy sums of EBFMI) are part of the checkpoint
+            cont = lambda a, dt: np.ascontiguousarray(a, dtype=dt)  # noqa: E731
+            self._call("ahmc_set_accum_state", int(acc["n_transitions"]), capi.as_ptr(cont(acc["n_steps"], np.int64)),
+                       capi.as_ptr(cont(acc["n_divergent"], np.int64)), capi.as_ptr(cont(acc["sum_theta"], self.dtype)),
+                       capi.as_ptr(cont(acc["sumsq_theta"], self.dtype)), capi.as_ptr(cont(acc["energy_sums"], self.dtype)))
 
     # -- multi-GPU: the final gather through the C ABI (RCCL inside) --
     def comm_unique_id(self) -> bytes:

@@ -66,15 +66,34 @@ def _sources_digest() -> str:
 KERNEL_SOURCES = ("ahmc_device.hpp", "ahmc_kernels.hpp", "ahmc_nuts.hpp", "ahmc_inst.hpp", "ahmc_inst.hip")
 
 
-def kernel_digest() -> str:
-    """sha256 over the DEVICE code of the trajectory kernels (k_nuts, k_hmc, k_leapfrog, …) and the compiler flags: what
-    decides their instruction counts.  bench.py matches it against profiles/counters_at_head.json — host-side edits
-    (ahmc_api.hip …) do not invalidate PMC counters taken on the same kernels."""
+def source_digest() -> str:
+    """sha256 over the SOURCES of the trajectory kernels and the compiler flags (what a target plugin is keyed on)"""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def kernel_digest() -> str:
+    """Digest of the DEVICE CODE of the trajectory kernels as built: sha256 over the gfx950 instructions of the eight
+    log-density units (k_nuts, k_hmc, k_leapfrog, … of every geometry), taken from the disassembly the build's ISA scan
+    makes anyway (`<unit>.o.isa` in the object cache).  It is what decides the kernels' instruction counts — so it is what
+    profiles/counters_at_head.json is keyed on: comments, host-side edits and unrelated templates do not invalidate PMC
+    counters, a different compiler or ROCm does.  Falls back to the stamp next to the .so (the GPU box has no object cache)."""
+    h = hashlib.sha256()
+    for name, _, _ in _units():
+        if not name.startswith("inst_"):
+            continue
+        f = os.path.join(OBJ, name + ".o.isa")
+        if not os.path.exists(f):
+            try:
+                return open(OUT + ".kdigest").read().strip()
+            except OSError:
+                return source_digest()
+        h.update(name.encode())
+        h.update(open(f).read().strip().encode())
     return h.hexdigest()
 
 
@@ -113,7 +132,7 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
         name, src, defs = unit
         obj = os.path.join(OBJ, name + ".o")
         dep, dig = obj + ".d", obj + ".digest"
-        if not force and os.path.exists(obj) and os.path.exists(dig):
+        if not force and os.path.exists(obj) and os.path.exists(dig) and (os.path.exists(obj + ".isa") or not isa_check.available()):
             d = unit_digest(dep, defs)
             if d is not None and d == open(dig).read():
                 if verbose:
@@ -127,7 +146,9 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
         # under the full one is a register-allocation artefact that returns wrong results on the device (isa_check.py,
         # DESIGN §7.3).  The build fails on it — it is not a skippable test.
         if isa_check.available() and not os.environ.get("AHMC_SKIP_ISA_CHECK"):
-            nbad = isa_check.check_object(obj, name)
+            nbad, code = isa_check.analyse_object(obj, name)
+            with open(obj + ".isa", "w") as f:  # digest of the unit's device code (kernel_digest)
+                f.write(code)
             if nbad:
                 os.remove(obj)
                 raise RuntimeError(f"{name}: {nbad} spill store(s) under a narrowed exec mask with outside reloads (see above); "
@@ -157,3 +178,63 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print("linked", OUT)
     return OUT
+
+
+def build_target_plugin(source: str, dtype, G: int, E: int, n_params: int = -1, force: bool = False, verbose: bool = False) -> str:
+    """Compile a user log-density (a header defining `ahmc_user::logdensity<T, G, E>`, contract in include/ahmc_user_target.h)
+    INTO the engine's trajectory kernels for one element type and one thread geometry: ahmc_inst.hip with TK = 4 → a shared
+    object that `ahmc_set_target_plugin` binds.  Cached outside the repository under <object cache>/plugins/, keyed on the
+    header's content, the engine's kernel sources, the flags, dtype and geometry; scanned by isa_check like every unit of
+    the engine.  ≈ 20–60 s the first time (one geometry, all kernel families and NUTS modes)."""
+    import numpy as np
+
+    source = os.path.abspath(source)
+    if not os.path.exists(source):
+        raise FileNotFoundError(source)
+    tname = {"float32": "float", "float64": "double"}[np.dtype(dtype).name]
+    kd = source_digest()
+    h = hashlib.sha256()
+    for part in (open(source, "rb").read(), kd.encode(), tname.encode(), f"{G},{E},{n_params}".encode(), " ".join(FLAGS).encode(),
+                 open(os.path.join(CSRC, "ahmc_kernels.hpp"), "rb").read(), open(os.path.join(CSRC, "ahmc_inst.hpp"), "rb").read()):
+        h.update(part)
+    out_dir = os.path.join(OBJ, "plugins")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"libahmc_target_{h.hexdigest()[:20]}.so")
+    if os.path.exists(out) and not force:
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: a target plugin is compiled from the engine's kernel sources")
+    tmp = out + f".tmp{os.getpid()}"
+    cmd = [hipcc, *FLAGS, "-shared", f"-DAHMC_INST_T={tname}", "-DAHMC_INST_TK=4", f"-DAHMC_PLUGIN_G={int(G)}", f"-DAHMC_PLUGIN_E={int(E)}",
+           f"-DAHMC_PLUGIN_NPARAMS={int(n_params)}", f'-DAHMC_USER_TARGET_HEADER="{source}"', f'-DAHMC_SOURCES_DIGEST="{kd}"',
+           "-I", INCLUDE, os.path.join(CSRC, "ahmc_inst.hip"), "-o", tmp]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed on the target plugin {source}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    if isa_check.available() and not os.environ.get("AHMC_SKIP_ISA_CHECK"):
+        if isa_check.check_object(tmp, os.path.basename(source)):
+            os.remove(tmp)
+            raise RuntimeError(f"{source}: the compiled plugin holds a spill stored under a narrowed exec mask (isa_check.py); discarded")
+    os.replace(tmp, out)
+    if verbose:
+        print("built target plugin", out)
+    return out
+
+
+def build_code_object(source: str, force: bool = False) -> str:
+    """hipcc --genco of a file of user KERNELS (ahmc_set_target_kernel) → a gfx950 code object for hipModuleLoad; cached
+    outside the repository by content."""
+    source = os.path.abspath(source)
+    h = hashlib.sha256(open(source, "rb").read()).hexdigest()[:20]
+    out_dir = os.path.join(OBJ, "kernels")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"{os.path.splitext(os.path.basename(source))[0]}_{h}.hsaco")
+    if os.path.exists(out) and not force:
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "--genco", source, "-o", out + ".tmp"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc --genco failed on {source}:\n{res.stdout}\n{res.stderr}")
+    os.replace(out + ".tmp", out)
+    return out

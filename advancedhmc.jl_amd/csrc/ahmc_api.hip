@@ -102,6 +102,14 @@ struct Ctx : CtxBase {
   // target
   int target_kind = AHMC_TARGET_ISO_GAUSS;
   T* tparams = nullptr;
+  // AHMC_TARGET_PLUGIN: the user's log-density compiled into the trajectory kernels (a dlopen'ed Inst<T, 4>)
+  void* plugin_dl = nullptr;
+  const TargetOps<T>* plugin_ops = nullptr;
+  // AHMC_TARGET_KERNEL: the user's log-density as a device kernel the step-synchronous engine launches itself
+  int uk_kind = -1;           // AHMC_KERNEL_HIP_FUNCTION / AHMC_KERNEL_HIP_SYMBOL
+  void* uk_handle = nullptr;
+  int uk_block = 256, uk_cpb = 1;
+  void* uk_user = nullptr;
   // metric
   int metric_kind = AHMC_METRIC_UNIT;
   bool minv_per_chain = false;
@@ -212,6 +220,7 @@ struct Ctx : CtxBase {
     for (auto* v : {&ev_pool, &ev_pending, &ev_pending_warm})
       for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (plugin_dl) (void)dlclose(plugin_dl);
   }
 };
 
@@ -294,8 +303,18 @@ unsigned group_grid(Ctx<T>* c) {  // blocks of 256 threads covering N groups of 
   return (unsigned)((threads + 255) / 256);
 }
 
+// the launch table of the context's log-density family: a built-in one, or the plugin's
+template <class T>
+const TargetOps<T>* ops_for(const Ctx<T>* c) {
+  static const TargetOps<T> builtin[AHMC_N_TARGETS] = {make_target_ops<T, 0>(), make_target_ops<T, 1>(), make_target_ops<T, 2>(), make_target_ops<T, 3>()};
+  if (c->target_kind == AHMC_TARGET_PLUGIN) return c->plugin_ops;
+  if (c->target_kind >= 0 && c->target_kind < AHMC_N_TARGETS) return &builtin[c->target_kind];
+  return nullptr;
+}
+
 template <class T>
 int check_builtin(Ctx<T>* c, const char* what) {
+  if (c->target_kind == AHMC_TARGET_PLUGIN && !c->plugin_ops) return fail(c, AHMC_ERR_STATE, std::string(what) + ": no target plugin is bound");
   if (c->target_kind == AHMC_TARGET_EXTERNAL)
     return fail(c, AHMC_ERR_STATE, std::string(what) + " needs a built-in target; with AHMC_TARGET_EXTERNAL the caller evaluates the log-density: "
                                    "ahmc_ext_* (whole transitions, find_good_stepsize) or ahmc_lf_pre / ahmc_lf_post (single leapfrogs)");
@@ -308,7 +327,7 @@ template <class T>
 int launch_fill_caches_builtin(Ctx<T>* c) {
   KP<T> p = make_kp(c);
   p.no_lk = c->metric_kind == AHMC_METRIC_DENSE ? 1 : 0;  // ℓκ = −½ rᵀM⁻¹r comes from the dense engine
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::fill_caches(c->G, c->E, group_grid(c), c->stream, p); });
+  if (const TargetOps<T>* o = ops_for(c)) o->fill_caches(c->G, c->E, group_grid(c), c->stream, p);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -390,7 +409,9 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   const size_t scalar_bytes = (size_t)(NUTS_NSC * NLEV + NUTS_NAT) * CPW * sizeof(T) + (size_t)(NUTS_NSI * NLEV + NUTS_NAI) * CPW * sizeof(int);
   const int64_t n_chunks = (c->N + CPW - 1) / CPW;
   int occ = 0;  // single-wave workgroups per CU
-  with_target(c->target_kind, [&](auto tk) { occ = Inst<T, decltype(tk)::value>::nuts_occupancy(c->G, c->E, MODE, scalar_bytes * NW); });
+  const TargetOps<T>* o = ops_for(c);
+  if (!o) return fail(c, AHMC_ERR_STATE, "k_nuts: the context's target has no fused kernels");
+  occ = o->nuts_occupancy(c->G, c->E, MODE, scalar_bytes * NW);
   occ *= NW;
   if (occ < 1) occ = 4;
   if (occ > 32) occ = 32;
@@ -406,14 +427,14 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   smem = (size_t)n_lds_slots * slot_bytes + scalar_bytes;
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] k_nuts<%s,%d,%d,mode=%d>: occupancy %d waves/CU, %d/%d vector slots in LDS, %zu B LDS/wave, %lld waves\n", sizeof(T) == 8 ? "f64" : "f32", c->G, c->E, MODE, occ, n_lds_slots, n_slots, smem, (long long)n_chunks);
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, MODE, smem); });
+  o->nuts_set_smem(c->G, c->E, MODE, smem);
   // waves per workgroup (AHMC_NUTS_WPB): measured on cfg2, leapfrog/s for 1 / 2 / 4 waves per workgroup =
   // 8.4e8 / 7.0e8 / 5.6e8 — a workgroup holds its LDS and registers until its slowest wave ends
   static const int wpb_env = getenv("AHMC_NUTS_WPB") ? atoi(getenv("AHMC_NUTS_WPB")) : 1;
   wpb = NW > 1 ? NW : std::max(1, std::min(4, wpb_env));
   blocks = NW > 1 ? (int)n_chunks : (int)((n_chunks + wpb - 1) / wpb);
   smem *= (size_t)wpb;
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts_set_smem(c->G, c->E, MODE, smem); });
+  o->nuts_set_smem(c->G, c->E, MODE, smem);
   size_t need = (size_t)blocks * wpb * (size_t)(n_slots - n_lds_slots) * slot_bytes + 256;
   if (need > c->scratch_bytes) {
     if (c->scratch) {
@@ -436,7 +457,7 @@ int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
   if (rc) return rc;
   p.scratch = c->scratch;
   p.n_lds_levels = n_lds_slots;
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::nuts(c->G, c->E, MODE, (unsigned)blocks, wpb, smem, c->stream, p); });
+  if (const TargetOps<T>* o = ops_for(c)) o->nuts(c->G, c->E, MODE, (unsigned)blocks, wpb, smem, c->stream, p);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -609,7 +630,16 @@ int64_t nuts_batch(Ctx<T>* c) {
     // is better; three (batch, D, N) arrays (normals, momenta, M⁻¹·momenta) kept under 8 GiB
     // (round 2: 64 under 8 GiB -> 256 under 48 GiB of the 288: the end of a batch, where only the chains with the
     // longest trees are left, is the part of it that runs below full occupancy)
-    const int64_t capd = (int64_t)(48ull << 30) / (int64_t)(3 * sizeof(T) * c->D * c->N);
+    // ... and under a quarter of what is free on THIS device now (several contexts on one GPU, a user log-density at large
+    // D·N, a part with less than 288 GB): the buffers already held by this context (dn_batch_elems) count as free
+    size_t free_b = 0, total_b = 0;
+    size_t budget = 48ull << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t held = c->dn_batch_elems * 2 * sizeof(T) + c->znorm_elems * sizeof(T);
+      budget = std::min<size_t>(budget, (free_b + held) / 4);
+    }
+    (void)hipGetLastError();
+    const int64_t capd = (int64_t)budget / (int64_t)(3 * sizeof(T) * c->D * c->N);
     return std::max<int64_t>(1, std::min<int64_t>(256, capd));
   }
   // Round 2: 32 -> 128 under an 8 GiB cap.  A launch cannot end before its slowest chain, and in the warm-up (step sizes
@@ -664,7 +694,7 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refr
   p.sampler = sampler;
   p.refresh_alpha = (T)refresh_alpha;
   p.accum = accum ? 1 : 0;
-  with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::hmc(c->G, c->E, group_grid(c), c->stream, p); });
+  if (const TargetOps<T>* o = ops_for(c)) o->hmc(c->G, c->E, group_grid(c), c->stream, p);
   HIPCHK(hipGetLastError());
   c->iteration += 1;
   return AHMC_OK;
@@ -1104,7 +1134,63 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
       HIPCHK(hipMemcpyAsync(c->tparams, params, sizeof(T) * need, hipMemcpyDefault, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
     }
+    if (kind == AHMC_TARGET_PLUGIN || kind == AHMC_TARGET_KERNEL)
+      return fail(c, AHMC_ERR_ARGUMENT, "set_target: use ahmc_set_target_plugin / ahmc_set_target_kernel");
     c->target_kind = kind;
+    c->have_point = false;
+    return dn_refresh_fused(c);
+  });
+}
+
+int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void* params, int64_t n_params) {
+  FOR_CTX_MUT(ctx, {
+    if (!plugin_so) return fail(c, AHMC_ERR_ARGUMENT, "set_target_plugin: path is NULL");
+    if (n_params < 0 || (n_params > 0 && !params)) return fail(c, AHMC_ERR_ARGUMENT, "set_target_plugin: bad parameter array");
+    void* dl = dlopen(plugin_so, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return fail(c, AHMC_ERR_ARGUMENT, std::string("set_target_plugin: cannot load ") + plugin_so + ": " + dlerror());
+    const TargetPluginDesc* d = static_cast<const TargetPluginDesc*>(dlsym(dl, "ahmc_target_plugin_v1"));
+    auto reject = [&](const std::string& why) {
+      dlclose(dl);
+      return fail(c, AHMC_ERR_ARGUMENT, std::string("set_target_plugin: ") + plugin_so + ": " + why);
+    };
+    if (!d) return reject("no symbol ahmc_target_plugin_v1 (not a target plugin)");
+    if (d->plugin_abi != AHMC_PLUGIN_ABI || d->struct_bytes != (int32_t)sizeof(TargetPluginDesc) || d->kp_bytes != (int32_t)sizeof(KP<T>))
+      return reject("built against another version of the engine's kernel sources: rebuild it (build_target_plugin)");
+    if (d->dtype != (sizeof(T) == 4 ? AHMC_F32 : AHMC_F64)) return reject("built for the other element type");
+    if (d->G != c->G || d->E != c->E)
+      return reject("built for thread geometry (" + std::to_string(d->G) + "," + std::to_string(d->E) + "), the context uses (" + std::to_string(c->G) + "," +
+                    std::to_string(c->E) + ")");
+    if (d->n_params >= 0 && d->n_params != n_params) return reject("expects " + std::to_string(d->n_params) + " parameters");
+    if (c->tparams) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tparams)); c->tparams = nullptr; }
+    if (n_params > 0) {
+      int rc = dev_alloc(c, &c->tparams, (size_t)n_params);
+      if (rc) { dlclose(dl); return rc; }
+      HIPCHK(hipMemcpyAsync(c->tparams, params, sizeof(T) * n_params, hipMemcpyDefault, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (c->plugin_dl) { HIPCHK(hipStreamSynchronize(c->stream)); dlclose(c->plugin_dl); }
+    c->plugin_dl = dl;
+    c->plugin_ops = static_cast<const TargetOps<T>*>(d->ops);
+    c->target_kind = AHMC_TARGET_PLUGIN;
+    c->have_point = false;
+    c->order_valid = false;
+    return dn_refresh_fused(c);
+  });
+}
+
+int32_t ahmc_set_target_kernel(ahmc_ctx* ctx, int32_t handle_kind, void* handle, int32_t block_threads, int32_t chains_per_block, void* user) {
+  FOR_CTX_MUT(ctx, {
+    if (handle_kind == AHMC_KERNEL_HOST) return fail(c, AHMC_ERR_UNSUPPORTED, "set_target_kernel: a host function is the CPU checker's form; the HIP engine takes device kernels");
+    if (handle_kind != AHMC_KERNEL_HIP_FUNCTION && handle_kind != AHMC_KERNEL_HIP_SYMBOL) return fail(c, AHMC_ERR_ARGUMENT, "set_target_kernel: unknown handle kind");
+    if (!handle) return fail(c, AHMC_ERR_ARGUMENT, "set_target_kernel: handle is NULL");
+    if (block_threads < 1 || block_threads > 1024 || chains_per_block < 1) return fail(c, AHMC_ERR_ARGUMENT, "set_target_kernel: block_threads in 1..1024, chains_per_block >= 1");
+    if (c->tparams) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tparams)); c->tparams = nullptr; }
+    c->uk_kind = handle_kind;
+    c->uk_handle = handle;
+    c->uk_block = block_threads;
+    c->uk_cpb = chains_per_block;
+    c->uk_user = user;
+    c->target_kind = AHMC_TARGET_KERNEL;
     c->have_point = false;
     return dn_refresh_fused(c);
   });
@@ -1222,7 +1308,7 @@ int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
     if (rc) return rc;
     KP<T> p = make_kp(c);
     p.refresh_alpha = (T)alpha;
-    with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::refresh(c->G, c->E, group_grid(c), c->stream, p); });
+    if (const TargetOps<T>* o = ops_for(c)) o->refresh(c->G, c->E, group_grid(c), c->stream, p);
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   });
@@ -1236,7 +1322,7 @@ int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
     if (rc) return rc;
     KP<T> p = make_kp(c);
     p.n_steps = n_steps;
-    with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::leapfrog(c->G, c->E, group_grid(c), c->stream, p); });
+    if (const TargetOps<T>* o = ops_for(c)) o->leapfrog(c->G, c->E, group_grid(c), c->stream, p);
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   });
@@ -1342,7 +1428,7 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
     p.init_eps = (T)initial_step_size;
     p.max_iters = max_n_iters;
     T* out = c->eps_cur;
-    with_target(c->target_kind, [&](auto tk) { Inst<T, decltype(tk)::value>::find_eps(c->G, c->E, group_grid(c), c->stream, p, out); });
+    if (const TargetOps<T>* o = ops_for(c)) o->find_eps(c->G, c->E, group_grid(c), c->stream, p, out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->eps_nom, c->eps_cur, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
     c->eps_scalar = false;
@@ -1407,8 +1493,16 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "sample before set_position");
     if (drop_warmup && c->adapt_kind == AHMC_ADAPT_NONE)
       return fail(c, AHMC_ERR_ARGUMENT, "Cannot drop warmup samples if there is no adaptation phase.");  // src/sampler.jl:172
+    // a resumed run must continue where the restored state stopped: a Stan adaptor counts its own calls (state.i,
+    // stan_adaptor.jl:137-159), so while it is adapting the absolute iteration is known and a mismatch is an error rather
+    // than a silently wrong window schedule
+    if (i_first > 1 && c->adapt_kind == AHMC_ADAPT_STAN && c->adapting && i_first <= n_adapts && c->stan_i != i_first - 1)
+      return fail(c, AHMC_ERR_STATE, "sample_from: i_first = " + std::to_string(i_first) + " but the adaptor has seen " + std::to_string(c->stan_i) +
+                                         " iterations (restore the checkpoint taken after iteration i_first - 1: ahmc_set_adaptor_state)");
     T* so = static_cast<T*>(samples_out);
-    bool reset_done = false;
+    // the accumulators are reset at the first kept transition — unless the run is being RESUMED beyond it (ahmc_sample_from):
+    // then they continue (a checkpoint carries them: ahmc_get/set_accum_state)
+    bool reset_done = i_first > (drop_warmup ? n_adapts + 1 : 1);
     const size_t nb = sizeof(T) * c->D * c->N;
     // can k_nuts write the kept draws itself?  (device buffer, or none requested)
     bool so_on_device = false;
@@ -1615,6 +1709,38 @@ int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transit
 
 int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
   FOR_CTX_MUT(ctx, { return reset_accum(c); });
+}
+
+int32_t ahmc_get_accum_state(ahmc_ctx* ctx, int64_t* n_transitions, int64_t* n_steps, int64_t* n_divergent, void* sum_theta, void* sumsq_theta,
+                             void* energy_sums) {
+  FOR_CTX(ctx, {
+    static_assert(sizeof(long long) == sizeof(int64_t), "accumulators are 64-bit");
+    const size_t nb = sizeof(T) * c->D * c->N;
+    if (n_transitions) *n_transitions = c->acc_ntrans;
+    if (n_steps) HIPCHK(hipMemcpyAsync(n_steps, c->acc_nsteps, sizeof(int64_t) * c->N, hipMemcpyDefault, c->stream));
+    if (n_divergent) HIPCHK(hipMemcpyAsync(n_divergent, c->acc_ndiv, sizeof(int64_t) * c->N, hipMemcpyDefault, c->stream));
+    if (sum_theta) HIPCHK(hipMemcpyAsync(sum_theta, c->acc_sum, nb, hipMemcpyDefault, c->stream));
+    if (sumsq_theta) HIPCHK(hipMemcpyAsync(sumsq_theta, c->acc_sumsq, nb, hipMemcpyDefault, c->stream));
+    if (energy_sums) HIPCHK(hipMemcpyAsync(energy_sums, c->acc_energy, sizeof(T) * 5 * c->N, hipMemcpyDefault, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_accum_state(ahmc_ctx* ctx, int64_t n_transitions, const int64_t* n_steps, const int64_t* n_divergent, const void* sum_theta,
+                             const void* sumsq_theta, const void* energy_sums) {
+  FOR_CTX_MUT(ctx, {
+    if (n_transitions < 0) return fail(c, AHMC_ERR_ARGUMENT, "set_accum_state: n_transitions < 0");
+    const size_t nb = sizeof(T) * c->D * c->N;
+    if (n_steps) HIPCHK(hipMemcpyAsync(c->acc_nsteps, n_steps, sizeof(int64_t) * c->N, hipMemcpyDefault, c->stream));
+    if (n_divergent) HIPCHK(hipMemcpyAsync(c->acc_ndiv, n_divergent, sizeof(int64_t) * c->N, hipMemcpyDefault, c->stream));
+    if (sum_theta) HIPCHK(hipMemcpyAsync(c->acc_sum, sum_theta, nb, hipMemcpyDefault, c->stream));
+    if (sumsq_theta) HIPCHK(hipMemcpyAsync(c->acc_sumsq, sumsq_theta, nb, hipMemcpyDefault, c->stream));
+    if (energy_sums) HIPCHK(hipMemcpyAsync(c->acc_energy, energy_sums, sizeof(T) * 5 * c->N, hipMemcpyDefault, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // (the sources may be pageable host buffers)
+    c->acc_ntrans = n_transitions;
+    return AHMC_OK;
+  });
 }
 
 // ---- adaptor checkpoint, multi-GPU gather, device diagnostics (ahmc_multi_host.hpp) ----

@@ -4,7 +4,47 @@
 
 template <class T>
 bool dense_engine(const Ctx<T>* c) {
-  return c->metric_kind == AHMC_METRIC_DENSE || c->target_kind == AHMC_TARGET_DENSE_GAUSS;
+  return c->metric_kind == AHMC_METRIC_DENSE || c->target_kind == AHMC_TARGET_DENSE_GAUSS || c->target_kind == AHMC_TARGET_KERNEL;
+}
+
+// lp[c] ← sanitize(lp[c]) for the listed chains (PhasePoint: a non-finite ℓπ → −Inf, src/hamiltonian.jl:95-104)
+template <class T>
+__global__ __launch_bounds__(256) void k_u_sanitize(T* __restrict__ lp, int64_t n, const int* __restrict__ list) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int64_t c = list ? (int64_t)list[j] : j;
+  lp[c] = sanitize(lp[c]);
+}
+
+// AHMC_TARGET_KERNEL: (ℓπ, g = −∇ℓπ) at θ of the listed chains by the user's device kernel, launched on the context's stream —
+// the `h.∂ℓπ∂θ(θ)` call of src/hamiltonian.jl:45-48 without leaving the device (signature: include/ahmc_hip.h)
+template <class T>
+int dn_user_target(Ctx<T>* c, const int* list, int64_t n) {
+  if (n <= 0) return AHMC_OK;
+  if (!c->uk_handle) return fail(c, AHMC_ERR_STATE, "AHMC_TARGET_KERNEL without a kernel (ahmc_set_target_kernel)");
+  const T* th = c->th;
+  T* lp = c->lp;
+  T* g = c->g;
+  const int32_t* cols = list;
+  int64_t n_cols = n, N = c->N;
+  int32_t D = (int32_t)c->D;
+  void* user = c->uk_user;
+  void* args[] = {&th, &lp, &g, &cols, &n_cols, &D, &N, &user};
+  const unsigned grid = (unsigned)((n + c->uk_cpb - 1) / c->uk_cpb);
+  if (c->uk_kind == AHMC_KERNEL_HIP_FUNCTION)
+    HIPCHK(hipModuleLaunchKernel(static_cast<hipFunction_t>(c->uk_handle), grid, 1, 1, (unsigned)c->uk_block, 1, 1, 0, c->stream, args, nullptr));
+  else
+    HIPCHK(hipLaunchKernel(c->uk_handle, dim3(grid), dim3((unsigned)c->uk_block), args, 0, c->stream));
+  hipLaunchKernelGGL((k_u_sanitize<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->lp, n, list);
+  HIPCHK(hipGetLastError());
+  return AHMC_OK;
+}
+
+// (ℓπ, g) of the listed chains for a target that is not the dense Gaussian: the user's kernel, or the built-in family's /
+// the plugin's group kernel (which has no chain list: it evaluates every chain)
+template <class T>
+int dn_other_target(Ctx<T>* c, const int* list, int64_t n) {
+  return c->target_kind == AHMC_TARGET_KERNEL ? dn_user_target(c, list, n) : launch_fill_caches_builtin(c);
 }
 
 template <class T>
@@ -115,8 +155,8 @@ int dn_target(Ctx<T>* c, const int* list = nullptr, int64_t n = -1) {
     HIPCHK(hipGetLastError());
     return AHMC_OK;
   }
-  // built-in family: the group kernel (it also writes a Unit/Diag ℓκ, overwritten by dn_velocity)
-  return launch_fill_caches_builtin(c);
+  // built-in family: the group kernel (it also writes a Unit/Diag ℓκ, overwritten by dn_velocity); or the user's kernel
+  return dn_other_target(c, list, n);
 }
 
 template <class T>
@@ -151,7 +191,7 @@ int dn_step(Ctx<T>* c, const int* list = nullptr, int64_t n = -1) {
   int rc;
   const bool dt = c->target_kind == AHMC_TARGET_DENSE_GAUSS;
   if (dt) rc = dn_gemm(c, c->tparams, c->th, c->g, n, list);  // g′ = Pθ′
-  else rc = launch_fill_caches_builtin(c);                    // built-in family: (ℓπ, g′) by the group kernel
+  else rc = dn_other_target(c, list, n);                      // built-in family: (ℓπ, g′) by the group kernel; or the user's kernel
   if (rc) return rc;
   if (dm) {
     rc = dn_gemm(c, c->dn_minv, c->g, W, n, list);  // w′ = M⁻¹g′
@@ -476,7 +516,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // A1 B1 …), every tree kernel on the second stream (A0 B0 A1 …), with an event per half in each direction (tree k
   // waits for GEMM k; the next GEMM of that half waits for its tree kernel).  Stream order then forces the phase shift:
   // GEMM B(s) can only run beside tree A(s), GEMM A(s+1) beside tree B(s).  Same kernels on the same data: bit-identical
-  // results.  (Not yet measured on the GPU — DESIGN §7.)
+  // results.  Measured in round 2 (profiles/r2_cfg4_timeline_split*.json): the phase shift happens as designed and both
+  // kernels slow down by the factor they now share the chip — 18.5–19.6 TFLOP/s against 24.0 for =1 and 22.2 for =0.  Kept as a switch.
   const int CHUNK = 16;
   const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
   const int split_env = getenv("AHMC_DENSE_SPLIT") ? atoi(getenv("AHMC_DENSE_SPLIT")) : 1;  // (read per call: the tests toggle it)
@@ -540,7 +581,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
           rc = dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list, c->dn_C, Wcur);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
           if (rc) return bail(rc);
         } else {
-          rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list) : launch_fill_caches_builtin(c);
+          rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list) : dn_other_target(c, h.list, h.n_list);
           if (rc) return bail(rc);
           if (dm) {
             rc = dn_gemm(c, c->dn_minv, c->g, Wcur, h.n_list, h.list);

@@ -193,7 +193,7 @@ int dn_hmc_multinomial(Ctx<T>* c, int64_t L, bool accum) {
   if (rc) return rc;
   const bool dt = c->target_kind == AHMC_TARGET_DENSE_GAUSS;
   while (c->mn.phase == MN_BWD || c->mn.phase == MN_FWD || c->mn.phase == MN_REINT) {
-    rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, c->N) : launch_fill_caches_builtin(c);  // g′ (and ℓπ for the built-in families)
+    rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, c->N) : dn_other_target(c, nullptr, c->N);  // g′ (and ℓπ for the built-in families)
     if (rc) return rc;
     rc = dn_post_all(c, dt);
     if (rc) return rc;

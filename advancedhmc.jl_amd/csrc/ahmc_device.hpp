@@ -179,8 +179,11 @@ template <bool UNIFORM>
 __device__ __forceinline__ double leaf_weight_exp(double x) {
   constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
 #if AHMC_LEAF_EXP == 2
-  const double dk = __builtin_rint(x * 92.33248261689366);                 // 64 / ln 2
-  double t = __builtin_fma(dk, -0x1.62e42fef00000p-7, x);                   // − k·ln2/64: high part (20 trailing zero bits: exact product)
+  // (clamped first: ℓw = −Inf is a routine input — every divergent leaf — and a float-to-int conversion of ±Inf is undefined
+  // behaviour, however the hardware's v_cvt_i32_f64 saturates; the final select still returns 0 below −1075)
+  const double xc = x < -1100.0 ? -1100.0 : x;
+  const double dk = __builtin_rint(xc * 92.33248261689366);                // 64 / ln 2
+  double t = __builtin_fma(dk, -0x1.62e42fef00000p-7, xc);                  // − k·ln2/64: high part (20 trailing zero bits: exact product)
   t = __builtin_fma(dk, -0x1.473de6af278edp-40, t);                         // low part
   int k = (int)dk;
   if constexpr (UNIFORM) k = __builtin_amdgcn_readfirstlane(k);             // a chain owns the wave: scalar table load
@@ -191,7 +194,7 @@ __device__ __forceinline__ double leaf_weight_exp(double x) {
   q = fma3(t, q, 1.0);
   q = q * t;                                                                // e^t − 1
   double z = __builtin_ldexp(__builtin_fma(tj, q, tj), k >> 6);
-  z = x < -1075.0 ? 0.0 : z;                                                // (and x = -Inf, where t is NaN)
+  z = x < -1075.0 ? 0.0 : z;                                                // (incl. x = −Inf; a NaN x fails the compare and propagates)
   return z;
 #else
   const double dn = __builtin_rint(x * C(0x3ff71547652b82feULL));                 // x·log2(e)
@@ -529,6 +532,16 @@ struct TargetP {
 
 #define AHMC_LOG2PI 1.8378770664093454835606594728112
 
+#ifdef AHMC_USER_TARGET_HEADER
+// A target plugin: the user's log-density as a device function, compiled into every trajectory kernel (TK = 4).  The header
+// defines, in namespace ahmc_user (contract and helpers: include/ahmc_user_target.h):
+//   template <class T, int G, int E>
+//   __device__ T logdensity(const T* params, int D, const T (&theta)[E], T (&grad_neg)[E], int lane, int d0);
+}  // namespace ahmc
+#include AHMC_USER_TARGET_HEADER
+namespace ahmc {
+#endif
+
 template <class T, int G, int E, int TK>
 __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E], T (&grad)[E], int lane, int d0) {
   const T log2pi = (T)AHMC_LOG2PI;
@@ -581,6 +594,9 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
       }
 
     }
+#ifdef AHMC_USER_TARGET_HEADER
+    if constexpr (TK == 4) part = ::ahmc_user::logdensity<T, G, E>(tp.params, D, th, grad, lane, d0);  // target plugin
+#endif
     if constexpr (TK == 3) {  // AHMC_TARGET_HIER_GAUSS: θ = (μ, log τ, x...)
       T mu = group_bcast<G>(th[0], 0);
       T lt = (E >= 2) ? group_bcast<G>(th[E >= 2 ? 1 : 0], 0) : group_bcast<G>(th[0], 1);
@@ -609,7 +625,12 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
       }
 
     }
-    if constexpr (TK < 0 || TK > 3) {
+#ifdef AHMC_USER_TARGET_HEADER
+    constexpr int TK_MAX = 4;
+#else
+    constexpr int TK_MAX = 3;
+#endif
+    if constexpr (TK < 0 || TK > TK_MAX) {
 #pragma unroll
       for (int e = 0; e < E; ++e) grad[e] = Lim<T>::nan();
       part = Lim<T>::nan();

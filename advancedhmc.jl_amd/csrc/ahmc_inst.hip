@@ -6,7 +6,7 @@
 #include "ahmc_nuts.hpp"
 
 #ifndef AHMC_INST_T
-#error "compile with -DAHMC_INST_T=float|double -DAHMC_INST_TK=0..3"
+#error "compile with -DAHMC_INST_T=float|double -DAHMC_INST_TK=0..3 (4 = a target plugin: -DAHMC_USER_TARGET_HEADER=... -DAHMC_PLUGIN_G= -DAHMC_PLUGIN_E=)"
 #endif
 
 namespace ahmc {
@@ -71,5 +71,22 @@ void Inst<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t sm
 }
 
 template struct Inst<AHMC_INST_T, AHMC_INST_TK>;
+
+#if AHMC_INST_TK == 4
+// ---- target plugin: the user's log-density (AHMC_USER_TARGET_HEADER, see include/ahmc_user_target.h) compiled into every
+// trajectory kernel of ONE element type and ONE thread geometry; the engine binds this table with dlopen ----
+#ifndef AHMC_PLUGIN_NPARAMS
+#define AHMC_PLUGIN_NPARAMS -1
+#endif
+#ifndef AHMC_SOURCES_DIGEST
+#define AHMC_SOURCES_DIGEST ""
+#endif
+static const TargetOps<AHMC_INST_T> plugin_ops = make_target_ops<AHMC_INST_T, 4>();
+}  // namespace ahmc
+extern "C" __attribute__((visibility("default"))) const ahmc::TargetPluginDesc ahmc_target_plugin_v1 = {
+    ahmc::AHMC_PLUGIN_ABI, (int32_t)sizeof(ahmc::TargetPluginDesc), (int32_t)sizeof(ahmc::KP<AHMC_INST_T>), (int32_t)(sizeof(AHMC_INST_T) == 4 ? 0 : 1),
+    AHMC_PLUGIN_G, AHMC_PLUGIN_E, (int64_t)(AHMC_PLUGIN_NPARAMS), &ahmc::plugin_ops, AHMC_SOURCES_DIGEST};
+namespace ahmc {
+#endif
 
 }  // namespace ahmc

@@ -11,9 +11,14 @@
 namespace ahmc {
 
 // Thread geometries (G lanes per chain, E elements per lane) with compiled kernels.
+#if defined(AHMC_PLUGIN_G) && defined(AHMC_PLUGIN_E)
+// a target plugin (ahmc_set_target_plugin) is compiled for the ONE geometry of the context it serves
+#define AHMC_GEOMETRIES(X) X(AHMC_PLUGIN_G, AHMC_PLUGIN_E)
+#else
 #define AHMC_GEOMETRIES(X) \
   X(4, 1) X(8, 1) X(16, 1) X(32, 1) X(64, 1) X(4, 2) X(8, 2) X(16, 2) X(32, 2) X(64, 2) X(32, 4) X(64, 4) X(64, 8) \
   X(128, 4) X(256, 4) X(512, 4) X(128, 8) X(256, 8) X(512, 8)
+#endif
 
 // call f(std::integral_constant<int,G>{}, std::integral_constant<int,E>{}) for a run-time geometry
 template <class F>
@@ -36,6 +41,40 @@ struct Inst {
   static int nuts_occupancy(int G, int E, int mode, size_t smem);  // single-wave workgroups per CU
   static void nuts_set_smem(int G, int E, int mode, size_t smem);
   static void nuts(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
+};
+
+// The launch table of one Inst<T, TK> as plain function pointers: what the host API calls.  The four built-in families
+// fill it from the instantiations linked into the library; a user log-density compiled INTO the trajectory kernels
+// (TK = AHMC_TK_PLUGIN, `ahmc_set_target_plugin`) fills it from the plugin .so's own Inst<T, 4> behind dlopen.
+template <class T>
+struct TargetOps {
+  void (*fill_caches)(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  void (*refresh)(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  void (*leapfrog)(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  void (*hmc)(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p);
+  void (*find_eps)(int G, int E, unsigned grid, hipStream_t s, const KP<T>& p, T* eps_out);
+  int (*nuts_occupancy)(int G, int E, int mode, size_t smem);
+  void (*nuts_set_smem)(int G, int E, int mode, size_t smem);
+  void (*nuts)(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
+};
+template <class T, int TK>
+inline TargetOps<T> make_target_ops() {
+  return TargetOps<T>{&Inst<T, TK>::fill_caches, &Inst<T, TK>::refresh, &Inst<T, TK>::leapfrog, &Inst<T, TK>::hmc, &Inst<T, TK>::find_eps,
+                      &Inst<T, TK>::nuts_occupancy, &Inst<T, TK>::nuts_set_smem, &Inst<T, TK>::nuts};
+}
+
+constexpr int AHMC_PLUGIN_ABI = 1;  // bump when KP<T>, TargetP<T> or TargetOps<T> change meaning without changing size
+constexpr int AHMC_TK_PLUGIN = 4;  // the TK of a plugin's instantiation (not an AHMC_TARGET_* code: the API kind is AHMC_TARGET_PLUGIN)
+// what a plugin .so exports under the C name `ahmc_target_plugin_v1` (built by advancedhmc.jl_amd/build.py: build_target_plugin)
+struct TargetPluginDesc {
+  int32_t plugin_abi;     // AHMC_PLUGIN_ABI of the headers it was compiled against
+  int32_t struct_bytes;   // sizeof(TargetPluginDesc): layout check
+  int32_t kp_bytes;       // sizeof(KP<T>): the plugin and the engine must agree on the kernel-argument struct
+  int32_t dtype;          // AHMC_F32 = 0 / AHMC_F64 = 1 (ahmc_hip.h)
+  int32_t G, E;           // the one thread geometry it was compiled for
+  int64_t n_params;       // parameters its log-density reads (tp.params), −1 = any
+  const void* ops;        // const TargetOps<T>*
+  const char* sources_digest;  // kernel-source digest of the engine headers it was compiled against (informational; the build helper keys its cache on it)
 };
 
 #define AHMC_DECLARE_INST(T) \

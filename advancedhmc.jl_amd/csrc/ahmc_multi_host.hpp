@@ -189,6 +189,16 @@ int gather_state(Ctx<T>* c, void* theta_all) {
   if (!theta_all) return fail(c, AHMC_ERR_ARGUMENT, "gather_state: theta_all is NULL");
   const size_t n = (size_t)c->D * (size_t)c->N;
   if (c->comm && c->comm_ranks > 1) {
+    // every rank must contribute the same count (ncclAllGather with unequal counts hangs or corrupts): one all-reduce of
+    // (N, −N) with max tells every rank the largest and the smallest N of the communicator
+    int rc = red_buf(c, 2);
+    if (rc) return rc;
+    double nn[2] = {(double)c->N, -(double)c->N};
+    HIPCHK(hipMemcpyAsync(c->red, nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(rccl_api().AllReduce(c->red, c->red, 2, ncclDouble, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream));
+    HIPCHK(hipMemcpyAsync(nn, c->red, sizeof(nn), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nn[0] != -nn[1]) return fail(c, AHMC_ERR_ARGUMENT, "gather_state: the ranks hold different numbers of chains (all ranks must hold the same N)");
     NCCLCHK(rccl_api().AllGather(c->th, theta_all, n, sizeof(T) == 8 ? ncclDouble : ncclFloat, static_cast<ncclComm_t>(c->comm), c->stream));
   } else {
     HIPCHK(hipMemcpyAsync(theta_all, c->th, n * sizeof(T), hipMemcpyDefault, c->stream));
@@ -329,6 +339,9 @@ int set_adaptor_state(Ctx<T>* c, const ahmc_adaptor_state* s, const void* da_in,
   // the constructor path allocates and shapes everything (incl. the promotion of a shared M⁻¹ to per-chain); the saved
   // values then overwrite what it initialised.  The metric and the step sizes are the caller's to restore first
   // (ahmc_set_metric / ahmc_set_stepsize), as they are fields of h and κ, not of the adaptor (src/abstractmcmc.jl:11-27).
+  if (s->var_estimator != AHMC_VAR_WELFORD && s->var_estimator != AHMC_VAR_NUTPIE && s->var_estimator != AHMC_VAR_POOLED)
+    return fail(c, AHMC_ERR_ARGUMENT, "set_adaptor_state: unknown variance estimator");
+  if (s->iteration < 0 || s->stan_i < 0 || s->wv_n < 0 || s->n_adapts < 0) return fail(c, AHMC_ERR_ARGUMENT, "set_adaptor_state: negative counter");
   c->var_estimator = s->var_estimator;
   int rc = adaptor_init(c, s->kind, s->delta, s->init_buffer, s->term_buffer, s->window_size);
   if (rc) return rc;

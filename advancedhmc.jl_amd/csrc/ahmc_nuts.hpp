@@ -23,6 +23,9 @@
 // start at the end (vector work only, no reductions, no RNG), which halves the pending state and
 // removes every candidate copy from the merge path.
 #pragma once
+#ifndef AHMC_SCALAR_ANY
+#define AHMC_SCALAR_ANY 1      // loop-control predicates of a wave-owning chain are tested directly instead of through a ballot (0: ballot)
+#endif
 
 #include <type_traits>
 
@@ -173,6 +176,14 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   // construction) turns the exec-mask save/restore of divergent branches into scalar branches and keeps the
   // predicates in SGPRs instead of VGPR 0/1 values.
 #define AHMC_UNI(b) (CPW == 1 ? (__builtin_amdgcn_ballot_w64(b) != 0) : (b))
+  // any lane of the wave?  For a chain that owns the wave the predicate is already wave-uniform (built from AHMC_UNI values):
+  // testing it directly is a scalar branch, a ballot of it would re-materialise the lane mask (v_cndmask + v_cmp).
+  // Measured (round 3, cfg2, A/B on one box, two runs each): whole loop 2.36e9 -> 2.43e9, warm-up 1.97e9 -> 2.06e9.
+#if AHMC_SCALAR_ANY
+#define AHMC_ANY(b) (CPW == 1 ? (bool)(b) : (__builtin_amdgcn_ballot_w64(b) != 0))
+#else
+#define AHMC_ANY(b) (__builtin_amdgcn_ballot_w64(b) != 0)
+#endif
   constexpr int NCH = Chunking<T, E>::NCH, CH = Chunking<T, E>::CH;
   constexpr int SLOT_ELEMS = NCH * 64 * CH;  // elements per vector slot (= 64 * E)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -247,7 +258,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   // redo pass: only the chains flagged by the linear-domain pass, from the transition they bailed at
   const int kt0 = p.redo_only ? p.redo[cc] - 1 : 0;
   bool active = c < p.N && kt0 >= 0;
-  if (__builtin_amdgcn_ballot_w64(active) == 0) return;  // (redo pass: the common case)
+  if (!AHMC_ANY(active)) return;  // (redo pass: the common case)
   T minv[E];
   load_minv<T, E>(p, cc, d0, minv);
   T th_cur[E];  // the chain's position, carried in registers from one transition to the next
@@ -298,7 +309,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     // stays live through the whole tree (measured: +50 VGPRs, one wave per SIMD less).
     asm volatile("" : "+v"(cc), "+v"(d0), "+v"(lane), "+v"(gi), "+v"(sl.lane_off));
     const bool on = AHMC_UNI(active && kt >= kt0);
-    if (__builtin_amdgcn_ballot_w64(on) == 0) continue;
+    if (!AHMC_ANY(on)) continue;
     // ---- transition prologue (src/sampler.jl:54-57): jitter, fresh momentum, caches.  The standard
     // normals come from k_normals (same Philox stream): keeping the f64 Box–Muller out of this
     // kernel saves ~25 VGPRs at its register peak ----
@@ -340,13 +351,13 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     bool done = !on;
 
     for (int jw = 0; jw < p.max_depth; ++jw) {  // doubling loop (:691-723), wave-uniform
-      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+      if (!AHMC_ANY(!done)) break;
       // ---- direction (:693) and edge selection ----
       bool vleft = false;
       if (!done) vleft = AHMC_UNI(ds.boolean());
       const int v = vleft ? -1 : 1;
       const bool need_swap = AHMC_UNI(!done && (vleft != cur_is_left));
-      if (__builtin_amdgcn_ballot_w64(need_swap) != 0) {
+      if (AHMC_ANY(need_swap)) {
         if (need_swap) {
           if (jw > 0) {  // at jw == 0 both edges are z0
             Point<T, E> t;
@@ -364,7 +375,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           cur_is_left = vleft;
         }
       }
-      if (strict && __builtin_amdgcn_ballot_w64(!done) != 0) {
+      if (strict && AHMC_ANY(!done)) {
         if (!done) sl.store(DORM + SL_START_R, cur.r);  // r of the edge the subtree grows from
       }
       // ---- build the subtree of 2^jw leaves (:626-675) ----
@@ -375,7 +386,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       T w_c = 0, sa_c = 0, dh_c = 0;
       int na_c = 0, ck_c = 0;
       for (uint32_t leaf = 1; leaf <= nleaf; ++leaf) {
-        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+        if (!AHMC_ANY(alive)) break;
         int merged = 0;
         // merges after this leaf: one per trailing zero bit of `leaf` (:649-673); the count is wave-uniform
         const int nm = __builtin_ctz(leaf);
@@ -401,9 +412,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               }
             });
           } else if constexpr (G > 64) {
-            // multi-wave chains keep the (ℓπ, ℓκ) pair reduction: with the single-value form the (128,8) instantiation of
-            // the linear-domain kernel returned wrong candidates on the MI355X (energies and tree sizes right; the
-            // log-domain instantiation and (256,4) fine) — not understood, so not shipped for G > 64
+            // multi-wave chains keep the (ℓπ, ℓκ) pair reduction.  Round 2: with the single-value form the (128,8) instantiation
+            // returned wrong candidates — a register-allocation artefact (a spill stored under the lane-0 mask of the cross-wave
+            // exchange; the build now scans for it).  Round 3 measured the single-value leaf with an exchange that has
+            // no narrowed block (every lane stores): parity-green, but cfg5 5.92e7 -> 4.70e7 leapfrog/s (the all-lane store alone:
+            // 5.36e7) — more scratch traffic in the leaf loop than the barrier pair it saves.  Not taken.
             leapfrog_step<T, G, E, TK, false>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
             ne_leaf = cur.lp + cur.lk;
           } else {
@@ -529,18 +542,18 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         if constexpr (GENERAL) {
           for (int lvl = 0; lvl < nm; ++lvl) {
             const bool m = AHMC_UNI(alive && !sub_term);
-            if (__builtin_amdgcn_ballot_w64(m) == 0) break;
+            if (!AHMC_ANY(m)) break;
             if (m) merge_level(lvl, A_c, RF_c, std::false_type{});
           }
         } else if (nm > 0) {
           // first merge peeled: the completed half is the single leaf `cur` (its vector work was done with the leaf);
           // later merges carry A_c / RF_c
           bool m = AHMC_UNI(alive && !sub_term);
-          if (__builtin_amdgcn_ballot_w64(m) != 0) {
+          if (AHMC_ANY(m)) {
             if (m) merge_level(0, cur.r, cur.r, std::bool_constant<FUSE_M0>{});
             for (int lvl = 1; lvl < nm; ++lvl) {
               m = AHMC_UNI(alive && !sub_term);
-              if (__builtin_amdgcn_ballot_w64(m) == 0) break;
+              if (!AHMC_ANY(m)) break;
               if (m) merge_level(lvl, A_c, RF_c, std::false_type{});
             }
           }
@@ -668,7 +681,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       const T es = ck_tree < 0 ? -eps : eps;
       for (int s = 0;; ++s) {
         const bool go = AHMC_UNI(s < steps);
-        if (__builtin_amdgcn_ballot_w64(go) == 0) break;
+        if (!AHMC_ANY(go)) break;
         if (go) leapfrog_core<T, G, E, TK, GENERAL>(zc, minv, es, p.tp, p.lf, lane, d0);
       }
       if (on && redo) {

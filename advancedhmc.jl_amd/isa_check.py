@@ -28,9 +28,29 @@ def available() -> bool:
 
 def check_object(obj, label=None, quiet=False) -> int:
     """number of masked-spill findings in one object file (disassembled in a throw-away directory under $TMPDIR)"""
+    return analyse_object(obj, label, quiet)[0]
+
+
+def code_digest(text) -> str:
+    """sha256 over the gfx950 INSTRUCTIONS of a disassembly (addresses, encodings and comments stripped): equal digests =
+    the same device code, whatever was edited in comments, host code or unrelated templates, and whichever compiler made it"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for line in text.splitlines():
+        t = line.strip()
+        if not t or t == "...":
+            continue
+        h.update(re.sub(r"\s*//.*$", "", t).encode())
+        h.update(b"\n")
+    return h.hexdigest()
+
+
+def analyse_object(obj, label=None, quiet=False):
+    """(number of masked-spill findings, digest of the device code) of one object file — one disassembly for both"""
     with tempfile.TemporaryDirectory(prefix="ahmc_isa_") as tmp:
         text = disassemble(obj, tmp)
-    return scan(text, label or os.path.basename(obj), quiet=quiet)
+    return scan(text, label or os.path.basename(obj), quiet=quiet), code_digest(text)
 
 
 def disassemble(obj, tmp):

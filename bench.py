@@ -21,7 +21,10 @@ round-1 headline) and the warm-up rate are sub-fields of `config`.
 registers, so SURVEY §8d's state-through-memory byte model is not a roof for it (a fraction > 1 in round 1); it is
 still reported as `hbm_model_frac`.  VALU roof: wave-instructions per leapfrog of the shipped kernel × leapfrogs of
 the launches ÷ their duration (HIP events recorded by the engine around every launch of the kernel on its stream)
-÷ (1024 SIMDs × 2.4 GHz ÷ 4 cycles per wave64 instruction).  Instructions per leapfrog and HBM bytes come from
+÷ the MIX-WEIGHTED issue peak of that kernel: the measured issue rate of every instruction class on this chip
+(scripts/probe/valu_rate.hip → profiles/r3_valu_rate.json: f64 arithmetic, DPP moves, multiplies ≈ 450–590 G wave-instr/s,
+32-bit add / xor / mov ≈ 1 000, permlane swaps ≈ 300) weighted by the kernel's dynamic instruction mix
+(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / INT32 / INT64 / CVT per leapfrog; scripts/valu_mix.py).  Instructions per leapfrog and HBM bytes come from
 rocprofv3 PMC passes over THIS command, committed as profiles/counters_at_head.json together with the digest of the
 kernel sources they were taken on: if the digest does not match the library in use the counters are stale and
 `frac`, `traffic` are null (never rescaled from an old measurement).
@@ -32,6 +35,7 @@ collective (weak scaling, Philox chain offset = rank·chains); the only collecti
 final gather of per-dimension moments, which goes through the C ABI (ahmc_gather_moments over RCCL).
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -124,10 +128,12 @@ def build_engine(A, lib, cfg, N, seed, chain_offset, stream=0, device=0, dtype=n
     return eng, kernel
 
 
-def sample_loop(eng, kernel, n_adapts, n_draws, sync):
+def sample_loop(eng, kernel, n_adapts, n_draws, sync, draws_ptr=None):
     """the timed region: sample(…, n_adapts + n_draws, adaptor, n_adapts).  Two ahmc_sample calls — the adapting
     transitions, then the draws — so that each phase's Σ n_steps can be read; the iteration counter, the adaptor
-    and the state carry over, i.e. it is the one loop of src/sampler.jl:182-228."""
+    and the state carry over, i.e. it is the one loop of src/sampler.jl:182-228.  `draws_ptr`: the (D, N, n_draws) device
+    buffer that receives θ after EVERY post-warm-up transition — what the reference's `sample` returns
+    (src/sampler.jl:224-227, drop_warmup) — written inside the timed region by the trajectory kernel itself."""
     info0 = {k: eng.info(k) for k in ("nuts_launches", "nuts_kernel_ns", "nuts_warm_launches", "nuts_warm_kernel_ns")}
     sync()
     t0 = time.perf_counter()
@@ -136,7 +142,7 @@ def sample_loop(eng, kernel, n_adapts, n_draws, sync):
     eng.sync()
     t1 = time.perf_counter()
     acc_a = eng.accum(moments=False) if n_adapts > 0 else {"total_n_steps": 0, "n_divergent": 0}
-    eng.run(kernel, n_draws, 0)
+    eng.run(kernel, n_draws, 0, samples_out=draws_ptr)
     sync()
     t2 = time.perf_counter()
     acc_d = eng.accum(moments=True)
@@ -222,8 +228,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64", help="f64 = the reference default and the headline; f32 = what the "
                     "reference's CUDA smoke test uses (test/CUDA/cuda.jl:18), reported for information")
-    ap.add_argument("--ess", type=int, default=-1, help="after the timed region: this many more draws kept in HBM for the ESS estimate "
-                    "(-1 = 500 for cfg2/cfg3, 0 for the large-D configs; 0 = skip)")
+    ap.add_argument("--ess", type=int, default=-1, help="ESS of the TIMED run's draws (every chain, every dimension; device reduction through ahmc_ess): "
+                    "-1 = on for D <= 256, 0 = off, 1 = on")
+    ap.add_argument("--no-draws-out", action="store_true", help="do not materialise the draws in the timed region (A/B of its cost; the reported line always does)")
     ap.add_argument("--launch-check", action="store_true", help="spawn/rendezvous check only (gloo, no GPU, no compute)")
     args = ap.parse_args()
 
@@ -277,12 +284,22 @@ def main():
                 dist.barrier()
         return f
 
-    # W untimed warm-up steps of the same loop (code objects, allocator, clocks) on a throw-away engine
+    # the draws of the timed region: θ after every post-warm-up transition of every chain, (D, N, n_draws) in HBM — what the
+    # reference's `sample` returns (src/sampler.jl:224-227); written by the trajectory kernel inside the timed region
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    draws = None if args.no_draws_out else torch.empty((n_draws, N, D), dtype=tdt, device=dev)
+
+    # W untimed warm-up steps of the same loop (code objects, allocator, clocks, first touch of the draws buffer) on a throw-away engine
     if args.warmup > 0:
         eng, kernel = make()
         nw = args.warmup * T
-        sample_loop(eng, kernel, int(round(nw * args.adapt_fraction)), max(1, nw - int(round(nw * args.adapt_fraction))), barrier_for(eng))
+        nwa = int(round(nw * args.adapt_fraction))
+        nwd = max(1, nw - nwa)
+        sample_loop(eng, kernel, nwa, nwd, barrier_for(eng), draws_ptr=draws.data_ptr() if (draws is not None and nwd <= n_draws) else None)
         eng.close()
+
+    want_ess = draws is not None and (args.ess > 0 or (args.ess < 0 and D <= 256)) and n_draws >= 8
+    ess_buf = torch.empty((N, D), dtype=tdt, device=dev) if want_ess else None
 
     runs = []
     eng = None
@@ -290,15 +307,22 @@ def main():
         if eng is not None:
             eng.close()
         eng, kernel = make()                      # untimed setup: create, θ0, find_good_stepsize, adaptor
-        r = sample_loop(eng, kernel, n_adapts, n_draws, barrier_for(eng))
+        r = sample_loop(eng, kernel, n_adapts, n_draws, barrier_for(eng), draws_ptr=draws.data_ptr() if draws is not None else None)
+        if want_ess:
+            # ESS of THIS run's draws (all chains, all dimensions), reduced on the device through the C ABI (ahmc_ess):
+            # per (dimension, chain) series Geyer's initial monotone sequence; per dimension the mean over chains; min over dimensions
+            eng._call("ahmc_ess", ctypes.c_void_p(draws.data_ptr()), int(n_draws), ctypes.c_void_p(ess_buf.data_ptr()))
+            eng.sync()
+            r["ess_per_draw"] = float(ess_buf.mean(dim=0).min().item()) / n_draws
         tt = torch.tensor([r["dt"], r["dt_adapt"], r["dt_draw"]], dtype=torch.float64, device=dev)
-        tn = torch.tensor([float(r["leap_adapt"]), float(r["leap_draw"]), float(r["acc"]["n_divergent"]), float(r["div_adapt"])],
+        tn = torch.tensor([float(r["leap_adapt"]), float(r["leap_draw"]), float(r["acc"]["n_divergent"]), float(r["div_adapt"]), r.get("ess_per_draw", 0.0)],
                           dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(tn, op=dist.ReduceOp.SUM)
         r["dt_max"], r["dt_adapt_max"], r["dt_draw_max"] = (float(x) for x in tt.tolist())
-        r["leap_adapt_all"], r["leap_draw_all"], r["div_all"], r["div_adapt_all"] = (float(x) for x in tn.tolist())
+        r["leap_adapt_all"], r["leap_draw_all"], r["div_all"], r["div_adapt_all"], ess_sum = (float(x) for x in tn.tolist())
+        r["ess_per_draw_all"] = ess_sum / world
         r["value"] = (r["leap_adapt_all"] + r["leap_draw_all"]) / r["dt_max"]
         runs.append(r)
         spent = sum(x["dt_max"] for x in runs)
@@ -309,7 +333,7 @@ def main():
         if len(runs) >= 50:
             break
     order = sorted(range(len(runs)), key=lambda i: runs[i]["value"])
-    med = runs[order[len(order) // 2]]   # median run (the engine of the LAST run is still open for the ESS leg / the gather)
+    med = runs[order[len(order) // 2]]   # median run (the engine of the LAST run is still open for the gather)
 
     # final gather of the pooled per-dimension moments of the last run's draws through the C ABI (RCCL all-reduce inside)
     acc = runs[-1]["acc"]
@@ -319,33 +343,17 @@ def main():
     g = comm.gather_moments()
     mean, var = g["mean"], g["var"]
 
-    ess_n = args.ess if args.ess >= 0 else (500 if D <= 256 else 0)
     ess_info = None
-    if ess_n > 0:
-        # ESS/sec (BASELINE.json's secondary metric): `ess_n` more draws of the adapted chains written by k_nuts straight
-        # into HBM; ESS per draw (Geyer, per chain and dimension, min over dimensions of the mean over a 256-chain subset)
-        # × the draws/s of the timed run (whole loop incl. warm-up in the denominator)
-        from ahmc_amd.diagnostics import ess as ess_fn
-
-        draws = torch.empty((ess_n, N, D), dtype=torch.float64 if args.dtype == "f64" else torch.float32, device=dev)
-        torch.cuda.synchronize()
-        eng.run(kernel, ess_n, 0, samples_out=draws.data_ptr())
-        eng.sync()
-        sub = draws[:, :256, :].cpu().numpy()                      # (K, 256 chains, D)
-        per_dim = ess_fn(sub, axis=0).mean(axis=0)                 # mean over the subset, per dimension
-        ess_per_draw = float(per_dim.min()) / ess_n
-        te = torch.tensor([ess_per_draw], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(te, op=dist.ReduceOp.SUM)
-            te /= world
-        ess_per_draw = float(te.item())
-        ess_info = {"ess_per_sec": ess_per_draw * n_draws * N * world / med["dt_max"],
-                    "ess_per_sec_sampling_phase_only": ess_per_draw * n_draws * N * world / med["dt_draw_max"],
-                    "ess_per_draw_min_over_dims": ess_per_draw, "estimated_on_draws_per_chain": ess_n,
-                    "estimator": "Geyer initial monotone sequence on FFT autocorrelation per chain and dimension (256-chain subset per rank); "
+    if want_ess:
+        e1 = med["ess_per_draw_all"]
+        ess_info = {"ess_per_sec": e1 * n_draws * N * world / med["dt_max"],
+                    "ess_per_sec_sampling_phase_only": e1 * n_draws * N * world / med["dt_draw_max"],
+                    "ess_per_draw_min_over_dims": e1, "estimated_on_draws_per_chain": n_draws, "chains_used": N * world,
+                    "estimator": "Geyer initial monotone sequence on the autocovariances of every (dimension, chain) series (ahmc_ess, device "
+                                 "reduction over ALL chains); per dimension the mean over chains, then the min over dimensions; "
                                  "the reference computes no ESS (MCMCChains.jl does): parity unpinned",
-                    "definition": "ESS of the timed run's post-warm-up draws (all chains) / wall time of its whole sample loop"}
-        del draws
+                    "definition": "ESS of the timed run's own post-warm-up draws (the buffer the timed region filled) / wall time of its whole sample loop"}
+    del draws
 
     if rank == 0:
         B_lf = algorithmic_bytes_per_leapfrog(D, cfg["metric"], itemsize)
@@ -367,7 +375,11 @@ def main():
             if c:
                 o["valu_instructions_per_leapfrog"] = c["valu_per_leapfrog"]
                 o["achieved"] = lf_per_s * c["valu_per_leapfrog"] / 1e9
-                o["frac"] = o["achieved"] / VALU_PEAK_GINSTR
+                o["peak"] = c.get("valu_peak_mix_gwave_instr_per_s") or VALU_PEAK_GINSTR
+                o["peak_is_mix_weighted"] = bool(c.get("valu_peak_mix_gwave_instr_per_s"))
+                o["frac"] = o["achieved"] / o["peak"]
+                o["frac_of_uniform_4_cycle_peak"] = o["achieved"] / VALU_PEAK_GINSTR
+                o["valu_mix"] = c.get("valu_peak_mix")
                 o["traffic"] = c.get("hbm_bytes_per_leapfrog") and c["hbm_bytes_per_leapfrog"] * leap / launches
                 o["hbm_measured_frac"] = c.get("hbm_bytes_per_leapfrog") and lf_per_s * c["hbm_bytes_per_leapfrog"] / 1e9 / HBM_PEAK_GBS
                 o["valu_busy_fraction_under_rocprof"] = c.get("valu_busy")
@@ -383,9 +395,12 @@ def main():
             both.sort(key=lambda x: -x["launches"] * x["avg_launch_ms"])  # dominant = more device time in the timed region
             if both:
                 dom = both[0]
-                roof = {"bound": "valu", "unit": "Gwave-instr/s", "peak": VALU_PEAK_GINSTR, "achieved": dom["achieved"], "frac": dom["frac"],
+                roof = {"bound": "valu", "unit": "Gwave-instr/s", "peak": dom.get("peak", VALU_PEAK_GINSTR), "achieved": dom["achieved"], "frac": dom["frac"],
                         "traffic": dom["traffic"], "kernel": dom["kernel"], "counters": counters_src,
-                        "peak_definition": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+                        "peak_definition": ("mix-weighted VALU issue peak of this kernel: N / sum_c n_c / rate_c over its dynamic instruction classes, rate_c "
+                                            "measured per class on the MI355X (scripts/probe/valu_rate.hip, profiles/r3_valu_rate.json; scripts/valu_mix.py)"
+                                            if dom.get("peak_is_mix_weighted") else
+                                            "uncalibrated: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (no class mix for this kernel)"),
                         "dominant": dom, "other": both[1] if len(both) > 1 else None,
                         "device_time_share_of_timed_region": sum(x["launches"] * x["avg_launch_ms"] for x in both) / 1e3 / med["dt"]}
         else:
@@ -427,6 +442,8 @@ def main():
                                     "divergent": med["div_all"]},
                 "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()) if cfg["target"] == "iso" else None,
                 "gathered_draws": g["n_draws"], "gather": g["how"],
+                "draws_materialised_in_timed_region": (None if args.no_draws_out else
+                                                       {"shape_D_N_K": [D, N, n_draws], "gib": D * N * n_draws * itemsize / 2**30, "where": "device (HBM)"}),
                 "ess": ess_info,
             },
             "roofline": roof,
@@ -459,9 +476,7 @@ def main():
             except Exception as ex:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         try:  # RCCL writes its version banner to the C stdout when the first communicator is made: push it out first, so
-            import ctypes  # that the JSON line is the LAST line of stdout whatever the buffering
-
-            ctypes.CDLL(None).fflush(None)
+            ctypes.CDLL(None).fflush(None)  # that the JSON line is the LAST line of stdout whatever the buffering
         except Exception:
             pass
         print(json.dumps(out), flush=True)  # flushed NOW: with a process group alive the interpreter's exit path (RCCL / c10d

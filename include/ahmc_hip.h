@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHMC_ABI_VERSION 3
+#define AHMC_ABI_VERSION 4
 
 typedef struct ahmc_ctx ahmc_ctx;
 
@@ -64,7 +64,9 @@ enum {
   AHMC_TARGET_FUNNEL = 2,     /* θ1~N(0,3²), θi~N(0,e^{θ1})        research/notebooks/geweke_test.ipynb cell 4 */
   AHMC_TARGET_HIER_GAUSS = 3, /* θ=(μ,logτ,x..): μ~N(0,1), logτ~N(0,1), xi~N(μ,τ²)  SURVEY §8d cfg5 */
   AHMC_TARGET_DENSE_GAUSS = 4,/* ℓπ = -½ θᵀPθ, params: P (D,D) column-major precision  SURVEY §8d cfg4 */
-  AHMC_TARGET_EXTERNAL = 5
+  AHMC_TARGET_EXTERNAL = 5,   /* the caller evaluates: ask / tell (ahmc_ext_*), ahmc_lf_pre / ahmc_lf_post              */
+  AHMC_TARGET_PLUGIN = 6,     /* a user device FUNCTION compiled into the trajectory kernels (ahmc_set_target_plugin)     */
+  AHMC_TARGET_KERNEL = 7      /* a user device KERNEL the engine launches itself (ahmc_set_target_kernel)                */
 };
 
 /* integrator: src/integrator.jl:71-74 (Leapfrog), :112-156 (Jittered), :174-209 (Tempered) */
@@ -127,6 +129,33 @@ void* ahmc_stream(ahmc_ctx* ctx);
 /* Hamiltonian.ℓπ/∂ℓπ∂θ (src/hamiltonian.jl:1-20): choose a built-in family.  `params` holds
  * n_params elements of T (layout per family above) or NULL.                                  */
 int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params);
+
+/* A user log-density ON THE DEVICE — the `h.∂ℓπ∂θ(θ)` callable of src/hamiltonian.jl:45-48 / LogDensityProblems'
+ * logdensity_and_gradient behind src/AdvancedHMC.jl:163-186 — without a host round trip.  Two forms (contract, helper
+ * functions and an example: include/ahmc_user_target.h):
+ *
+ * ahmc_set_target_plugin: `plugin_so` is a shared object made from the user's device FUNCTION and the engine's own kernel
+ *   sources (advancedhmc.jl_amd/build.py: build_target_plugin) for the context's element type and thread geometry
+ *   (ahmc_get_info: AHMC_INFO_GROUP_LANES / _ELEMS_PER_LANE).  From then on every call of the built-in families' path —
+ *   phasepoint, step, refresh, static and NUTS transitions, find_good_stepsize, ahmc_sample with the fused warm-up — runs
+ *   the SAME fused kernels with the user's density inside.  `params`: n_params values of T the function reads (copied to
+ *   device memory), or NULL.  Errors: AHMC_ERR_ARGUMENT if the file cannot be bound or was built for another element type /
+ *   geometry / engine version.
+ *
+ * ahmc_set_target_kernel: `handle` is a device KERNEL the caller already owns — handle_kind AHMC_KERNEL_HIP_FUNCTION: a
+ *   hipFunction_t (hipModuleGetFunction; what AMDGPU.jl compiles a Julia kernel to); AHMC_KERNEL_HIP_SYMBOL: the host
+ *   address of a __global__ function linked into the process; AHMC_KERNEL_HOST (CPU checker only): a plain C function.
+ *   Signature, for every kind (T = the context's element type):
+ *       void f(const T* theta, T* lp, T* grad_neg, const int32_t* cols, int64_t n_cols, int32_t D, int64_t N, void* user)
+ *   for k < n_cols: chain c = cols ? cols[k] : k; read theta[c·D .. c·D+D); write lp[c] = ℓπ(θ_c) and grad_neg[c·D + d] =
+ *   −∂ℓπ/∂θ_d.  The engine launches it on the context's stream with ⌈n_cols / chains_per_block⌉ blocks of block_threads
+ *   threads wherever the ask / tell protocol would hand the chains to the caller: whole transitions (static, NUTS),
+ *   find_good_stepsize, phasepoint, step and ahmc_sample all work as for a built-in family, on the step-synchronous engine.
+ *   A non-finite ℓπ becomes −Inf (src/hamiltonian.jl:95-104).                                                        */
+enum { AHMC_KERNEL_HIP_FUNCTION = 0, AHMC_KERNEL_HIP_SYMBOL = 1, AHMC_KERNEL_HOST = 2 };
+int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void* params, int64_t n_params);
+int32_t ahmc_set_target_kernel(ahmc_ctx* ctx, int32_t handle_kind, void* handle, int32_t block_threads,
+                               int32_t chains_per_block, void* user);
 
 /* metric constructors + renew (src/metric.jl:31,61-69,104-117).  Unit: Minv ignored.
  * Diag: n == D (one M⁻¹ shared by all chains) or n == D*N (per-chain (D,N), F5 in SURVEY).
@@ -284,7 +313,8 @@ typedef struct {
 /* Runs n_samples transitions (+ adapt! for i <= n_adapts): the loop body of `sample`
  * (src/sampler.jl:182-228).  samples_out: NULL, or device/host buffer of (D, N, n_keep) receiving θ
  * after each kept transition (n_keep = n_samples - (drop_warmup ? n_adapts : 0)).
- * Accumulators (see ahmc_get_accum) are reset at the first kept transition.
+ * Accumulators (see ahmc_get_accum) are reset at the first kept transition — when that transition lies in this call
+ * (ahmc_sample_from with i_first beyond it continues them).
  * Chains are independent, so NUTS transitions are issued in batches (AHMC_INFO_NUTS_BATCH per kernel
  * launch) — in the warm-up too, where adapt! then runs inside the kernel after every transition (step sizes
  * and per-chain Diag mass matrices never need another chain's data).  The results are bit-identical to
@@ -307,6 +337,15 @@ int32_t ahmc_sample_from(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_fi
 int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transitions,
                        int64_t* n_divergent, void* sum_theta, void* sumsq_theta);
 int32_t ahmc_reset_accum(ahmc_ctx* ctx);
+/* The accumulators as part of a checkpoint (with ahmc_get/set_adaptor_state and ahmc_get/set_phasepoint): n_transitions,
+ * per-chain Σ n_steps and divergence counts (int64[N] each), Σθ, Σθ² ((D,N) of T) and the five running sums of the kept
+ * transitions' energies behind ahmc_ebfmi ((5,N) of T).  Host or device pointers; any may be NULL.  A run resumed with
+ * ahmc_sample_from(i_first > first kept iteration) CONTINUES the accumulators (it does not reset them), so after
+ * set_accum_state in a new context ahmc_get_accum / ahmc_gather_moments / ahmc_ebfmi cover the whole run.              */
+int32_t ahmc_get_accum_state(ahmc_ctx* ctx, int64_t* n_transitions, int64_t* n_steps, int64_t* n_divergent,
+                             void* sum_theta, void* sumsq_theta, void* energy_sums);
+int32_t ahmc_set_accum_state(ahmc_ctx* ctx, int64_t n_transitions, const int64_t* n_steps, const int64_t* n_divergent,
+                             const void* sum_theta, const void* sumsq_theta, const void* energy_sums);
 
 /* ------------------------------------------------------------------------------------------ */
 /* whole transitions with an EXTERNAL target: ask / tell                                      */

@@ -26,7 +26,8 @@ const LIB = get(ENV, "AHMC_HIP_LIB", "libahmc_hip.so")
 const F32, F64 = Cint(0), Cint(1)
 const METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = Cint(0), Cint(1), Cint(2)
 const TARGET_ISO_GAUSS, TARGET_DIAG_GAUSS, TARGET_FUNNEL, TARGET_HIER_GAUSS = Cint.(0:3)
-const TARGET_DENSE_GAUSS, TARGET_EXTERNAL = Cint(4), Cint(5)
+const TARGET_DENSE_GAUSS, TARGET_EXTERNAL, TARGET_PLUGIN, TARGET_KERNEL = Cint(4), Cint(5), Cint(6), Cint(7)
+const KERNEL_HIP_FUNCTION, KERNEL_HIP_SYMBOL = Cint(0), Cint(1)
 const VAR_WELFORD, VAR_NUTPIE, VAR_POOLED = Cint(0), Cint(1), Cint(2)
 const TS_ENDPOINT, TS_MULTINOMIAL, TS_SLICE = Cint.(0:2)
 const TC_CLASSIC, TC_GENERALISED, TC_STRICT = Cint.(0:2)
@@ -321,7 +322,7 @@ function sample_device(seed::Integer, h::Hamiltonian, κ::HMCKernel, θ::Matrix{
     return out
 end
 
-# --- ABI v3: checkpoint / resume, the final gather, device-side diagnostics ---------------------------------
+# --- ABI v3 (+ v4: accum_state / restore_accum! below): checkpoint / resume, the final gather, device-side diagnostics ---------------------------------
 # struct ahmc_adaptor_state (include/ahmc_hip.h): the value the reference carries in HMCState.adaptor
 # (src/abstractmcmc.jl:11-27) — isbits, same field order and alignment as the C struct
 struct AdaptorState
@@ -389,6 +390,37 @@ function gather_moments(z::MI355XChains)
                        z.ctx, μ, σ², n, steps, ndiv))
     return (mean=μ, var=σ², n_draws=n[], n_steps=steps[], n_divergent=ndiv[])
 end
+
+# --- ABI v4: a user log-density ON THE DEVICE (no host round trip per leapfrog) ------------------------------
+# (1) a device KERNEL the host already owns.  With AMDGPU.jl:  k = @roc launch=false my_kernel(θ, ℓπ, g, cols, n, D, N, user)
+#     compiles a Julia kernel with the C-ABI signature of include/ahmc_hip.h; `k.fun.handle` (hipFunction_t) goes in here and the
+#     engine launches it itself between its tree kernels — `transition`, `find_good_stepsize`, `sample_device` then run as for
+#     a built-in family (DeviceTarget), not through ext_drive!.
+"ahmc_set_target_kernel: `fun` = hipFunction_t; grid = ⌈n_cols / chains_per_block⌉ blocks of `block_threads` threads"
+function set_target_kernel!(z::MI355XChains, fun::Ptr{Cvoid}; block_threads::Integer=256, chains_per_block::Integer=1, user::Ptr{Cvoid}=C_NULL)
+    check(z.ctx, ccall((:ahmc_set_target_kernel, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}),
+                       z.ctx, KERNEL_HIP_FUNCTION, fun, block_threads, chains_per_block, user))
+end
+# (2) a device FUNCTION in HIP C++ compiled into the engine's fused kernels (include/ahmc_user_target.h); `plugin_so` comes from
+#     `python -c "from ahmc_amd.build import build_target_plugin; print(build_target_plugin(src, 'float64', G, E))"` (or the hipcc
+#     line in that header) with (G, E) = the context's thread geometry.
+function set_target_plugin!(z::MI355XChains{T}, plugin_so::AbstractString, params::Vector{T}=T[]) where {T}
+    check(z.ctx, ccall((:ahmc_set_target_plugin, LIB), Cint, (Ptr{Cvoid}, Cstring, Ptr{T}, Int64), z.ctx, plugin_so,
+                       isempty(params) ? C_NULL : params, length(params)))
+end
+
+"the running accumulators (Σθ, Σθ², Σ n_steps, divergences, the energy sums behind EBFMI) as part of a Checkpoint"
+function accum_state(z::MI355XChains{T}) where {T}
+    n = Ref{Int64}(0)
+    steps, ndiv = Vector{Int64}(undef, z.N), Vector{Int64}(undef, z.N)
+    Σθ, Σθ², E = Matrix{T}(undef, z.D, z.N), Matrix{T}(undef, z.D, z.N), Matrix{T}(undef, z.N, 5)
+    check(z.ctx, ccall((:ahmc_get_accum_state, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
+                       z.ctx, n, steps, ndiv, Σθ, Σθ², E))
+    return (n_transitions=n[], n_steps=steps, n_divergent=ndiv, sum_theta=Σθ, sumsq_theta=Σθ², energy_sums=E)
+end
+restore_accum!(z::MI355XChains{T}, a) where {T} =
+    check(z.ctx, ccall((:ahmc_set_accum_state, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
+                       z.ctx, a.n_transitions, a.n_steps, a.n_divergent, a.sum_theta, a.sumsq_theta, a.energy_sums))
 
 "EBFMI (src/diagnosis.jl:1-3) per chain over the kept transitions of the last `sample_device` / `resume_device!` call"
 function AdvancedHMC.EBFMI(z::MI355XChains{T}) where {T}

@@ -197,6 +197,10 @@ struct Target {
   // AHMC_TARGET_EXTERNAL: while an ahmc_ext_* run is in progress, the evaluation is a hand-over to the caller
   T (*ext_eval)(void* self, int64_t D, const T* th, T* g) = nullptr;
   void* ext_self = nullptr;
+  // AHMC_TARGET_KERNEL, the checker's form (AHMC_KERNEL_HOST): the user's "kernel" is a plain C function with the kernel's
+  // signature, called for one chain at a time (n_cols = 1, cols = NULL, the chain's θ / lp / grad_neg at offset 0)
+  void (*kernel_host)(const T* theta, T* lp, T* grad_neg, const int32_t* cols, int64_t n_cols, int32_t D, int64_t N, void* user) = nullptr;
+  void* kernel_user = nullptr;
 };
 
 // (ℓπ(θ), ∇ℓπ(θ)) — the user callback `h.∂ℓπ∂θ(θ)` of src/hamiltonian.jl:46.  `g` receives +∇ℓπ.
@@ -270,6 +274,14 @@ T logdensity_and_gradient(const Target<T>& tg, int64_t D, const T* th, T* g) {
       for (int64_t i = 0; i < D; ++i) v += th[i] * g[i];
       return v / 2;
     }
+    case AHMC_TARGET_KERNEL:
+      if (tg.kernel_host) {  // h.∂ℓπ∂θ(θ) (src/hamiltonian.jl:45-48) as the user's function; it returns −∇ℓπ
+        T lp = std::numeric_limits<T>::quiet_NaN();
+        tg.kernel_host(th, &lp, g, nullptr, 1, (int32_t)D, 1, tg.kernel_user);
+        for (int64_t d = 0; d < D; ++d) g[d] = -g[d];
+        return lp;
+      }
+      [[fallthrough]];
     case AHMC_TARGET_EXTERNAL:
       if (tg.ext_eval) return tg.ext_eval(tg.ext_self, D, th, g);  // the caller's h.∂ℓπ∂θ(θ) (ask / tell)
       [[fallthrough]];  // outside an ahmc_ext_* run there is nobody to ask
@@ -803,6 +815,7 @@ struct Ctx : CtxBase {
   StanWindows windows;
   // accumulators
   int64_t acc_nsteps = 0, acc_ntrans = 0, acc_ndiv = 0;
+  std::vector<int64_t> acc_nsteps_c, acc_ndiv_c;  // per chain (the checkpoint's form, ahmc_get/set_accum_state)
   std::vector<T> acc_sum, acc_sumsq;
   std::vector<T> acc_energy;  // (5,N): n, E_prev, Σ(ΔE)², mean(E), M2(E) over the kept transitions (ahmc_ebfmi)
   int64_t windows_n_adapts = 0;
@@ -1060,9 +1073,12 @@ void accumulate(Ctx<T>* c) {
   }
   c->acc_ntrans += 1;
   if (c->acc_energy.empty()) c->acc_energy.assign(5 * c->N, T(0));
+  if (c->acc_nsteps_c.empty()) { c->acc_nsteps_c.assign(c->N, 0); c->acc_ndiv_c.assign(c->N, 0); }
   for (int64_t i = 0; i < c->N; ++i) {
     c->acc_nsteps += c->stat[i].n_steps;
     c->acc_ndiv += c->stat[i].numerical_error;
+    c->acc_nsteps_c[i] += c->stat[i].n_steps;
+    c->acc_ndiv_c[i] += c->stat[i].numerical_error;
     // running sums for EBFMI (src/diagnosis.jl:1-3), the recursion the HIP kernels use (accumulate_energy)
     T* ea = c->acc_energy.data();
     const T H = c->stat[i].hamiltonian_energy, n0 = ea[i], prev = ea[c->N + i], n = n0 + 1;
@@ -1686,6 +1702,26 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
   });
 }
 
+int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char*, const void*, int64_t) {
+  FOR_CTX_MUT(ctx, { return fail(c, AHMC_ERR_UNSUPPORTED, "set_target_plugin: a target plugin is device code of the HIP engine; the CPU checker takes the same "
+                                                          "density as a host function (ahmc_set_target_kernel, AHMC_KERNEL_HOST) or through ask / tell"); });
+}
+
+int32_t ahmc_set_target_kernel(ahmc_ctx* ctx, int32_t handle_kind, void* handle, int32_t block_threads, int32_t chains_per_block, void* user) {
+  FOR_CTX_MUT(ctx, {
+    if (handle_kind != AHMC_KERNEL_HOST) return fail(c, AHMC_ERR_UNSUPPORTED, "set_target_kernel: the CPU checker takes AHMC_KERNEL_HOST (a plain C function) only");
+    if (!handle) return fail(c, AHMC_ERR_ARGUMENT, "set_target_kernel: handle is NULL");
+    if (block_threads < 1 || block_threads > 1024 || chains_per_block < 1) return fail(c, AHMC_ERR_ARGUMENT, "set_target_kernel: block_threads in 1..1024, chains_per_block >= 1");
+    c->target.kind = AHMC_TARGET_KERNEL;
+    c->target.params.clear();
+    using F = void (*)(const T*, T*, T*, const int32_t*, int64_t, int32_t, int64_t, void*);
+    c->target.kernel_host = reinterpret_cast<F>(handle);
+    c->target.kernel_user = user;
+    c->have_point = false;
+    return AHMC_OK;
+  });
+}
+
 int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n) {
   FOR_CTX_MUT(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
 }
@@ -2042,8 +2078,11 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "sample before set_position");
     if (drop_warmup && c->adapt_kind == AHMC_ADAPT_NONE)
       return fail(c, AHMC_ERR_ARGUMENT, "Cannot drop warmup samples if there is no adaptation phase.");  // src/sampler.jl:172
+    if (i_first > 1 && c->adapt_kind == AHMC_ADAPT_STAN && c->adapting && i_first <= n_adapts && c->stan_i != i_first - 1)
+      return fail(c, AHMC_ERR_STATE, "sample_from: i_first = " + std::to_string(i_first) + " but the adaptor has seen " + std::to_string(c->stan_i) +
+                                         " iterations (restore the checkpoint taken after iteration i_first - 1: ahmc_set_adaptor_state)");
     T* so = static_cast<T*>(samples_out);
-    bool reset_done = false;
+    bool reset_done = i_first > (drop_warmup ? n_adapts + 1 : 1);  // a run resumed beyond its first kept transition continues the accumulators
     for (int64_t i = i_first; i <= n_samples; ++i) {  // src/sampler.jl:182-228
       int rc = cfg->nuts ? nuts_transition_all(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, (T)cfg->refresh_alpha)
                          : hmc_transition(c, cfg->L, cfg->lambda, cfg->sampler, (T)cfg->refresh_alpha);
@@ -2051,7 +2090,7 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
       rc = adapt(c, i, n_adapts);
       if (rc) return rc;
       if (!drop_warmup || i > n_adapts) {
-        if (!reset_done) { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); c->acc_energy.clear(); reset_done = true; }
+        if (!reset_done) { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); c->acc_energy.clear(); c->acc_nsteps_c.clear(); c->acc_ndiv_c.clear(); reset_done = true; }
         accumulate(c);
         int64_t j = i - (drop_warmup ? n_adapts : 0);
         if (so) std::memcpy(so + (j - 1) * c->D * c->N, c->th.data(), sizeof(T) * c->D * c->N);
@@ -2074,7 +2113,37 @@ int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transit
 }
 
 int32_t ahmc_reset_accum(ahmc_ctx* ctx) {
-  FOR_CTX_MUT(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); c->acc_energy.clear(); return AHMC_OK; });
+  FOR_CTX_MUT(ctx, { c->acc_nsteps = c->acc_ntrans = c->acc_ndiv = 0; c->acc_sum.clear(); c->acc_sumsq.clear(); c->acc_energy.clear(); c->acc_nsteps_c.clear(); c->acc_ndiv_c.clear(); return AHMC_OK; });
+}
+
+int32_t ahmc_get_accum_state(ahmc_ctx* ctx, int64_t* n_transitions, int64_t* n_steps, int64_t* n_divergent, void* sum_theta, void* sumsq_theta,
+                             void* energy_sums) {
+  FOR_CTX(ctx, {
+    const size_t N = (size_t)c->N, nb = sizeof(T) * (size_t)c->D * N;
+    if (n_transitions) *n_transitions = c->acc_ntrans;
+    auto put = [&](void* dst, const void* src, size_t bytes, bool empty) { if (dst) { if (empty) std::memset(dst, 0, bytes); else std::memcpy(dst, src, bytes); } };
+    put(n_steps, c->acc_nsteps_c.data(), sizeof(int64_t) * N, c->acc_nsteps_c.empty());
+    put(n_divergent, c->acc_ndiv_c.data(), sizeof(int64_t) * N, c->acc_ndiv_c.empty());
+    put(sum_theta, c->acc_sum.data(), nb, c->acc_sum.empty());
+    put(sumsq_theta, c->acc_sumsq.data(), nb, c->acc_sumsq.empty());
+    put(energy_sums, c->acc_energy.data(), sizeof(T) * 5 * N, c->acc_energy.empty());
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_set_accum_state(ahmc_ctx* ctx, int64_t n_transitions, const int64_t* n_steps, const int64_t* n_divergent, const void* sum_theta,
+                             const void* sumsq_theta, const void* energy_sums) {
+  FOR_CTX_MUT(ctx, {
+    if (n_transitions < 0) return fail(c, AHMC_ERR_ARGUMENT, "set_accum_state: n_transitions < 0");
+    const size_t N = (size_t)c->N, DN = (size_t)c->D * N;
+    c->acc_ntrans = n_transitions;
+    if (n_steps) { c->acc_nsteps_c.assign(n_steps, n_steps + N); c->acc_nsteps = 0; for (int64_t v : c->acc_nsteps_c) c->acc_nsteps += v; }
+    if (n_divergent) { c->acc_ndiv_c.assign(n_divergent, n_divergent + N); c->acc_ndiv = 0; for (int64_t v : c->acc_ndiv_c) c->acc_ndiv += v; }
+    if (sum_theta) { const T* q = static_cast<const T*>(sum_theta); c->acc_sum.assign(q, q + DN); }
+    if (sumsq_theta) { const T* q = static_cast<const T*>(sumsq_theta); c->acc_sumsq.assign(q, q + DN); }
+    if (energy_sums) { const T* q = static_cast<const T*>(energy_sums); c->acc_energy.assign(q, q + 5 * N); }
+    return AHMC_OK;
+  });
 }
 
 // ---- adaptor checkpoint / resume, the final gather, device-side diagnostics (ABI v3) ----

@@ -35,6 +35,8 @@ def main():
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise SystemExit(r.stderr[-3000:])
+        if B.isa_check.available() and B.isa_check.check_object(o, f"{name}/{uname}"):
+            raise SystemExit(f"{name}/{uname}: masked-spill pattern in the code object (isa_check.py) - variant not built")
         return o
 
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:

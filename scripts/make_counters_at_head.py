@@ -13,7 +13,36 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ahmc_amd as A  # noqa: E402
-from ahmc_amd.build import kernel_digest  # noqa: E402
+from ahmc_amd.build import kernel_digest, OBJ  # noqa: E402
+from ahmc_amd import isa_check  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import valu_mix  # noqa: E402
+
+ROUND = os.environ.get("AHMC_ROUND", "r3")
+RATES = os.path.join(ROOT, "profiles", f"{ROUND}_valu_rate.json")   # scripts/probe/valu_rate.hip on the MI355X
+
+
+def kernel_text(kernel_name):
+    """disassembly of ONE kernel (by its demangled name in the kernel trace) from the object cache of the build"""
+    import re
+    import tempfile
+    m = re.search(r"k_nuts<(double|float), (\d+), (\d+), (\d+), (\d+)>", kernel_name)
+    if not m:
+        return None
+    unit = os.path.join(OBJ, f"inst_{'f64' if m.group(1) == 'double' else 'f32'}_t{m.group(5)}.o")
+    if not os.path.exists(unit):
+        return None
+    with tempfile.TemporaryDirectory(prefix="ahmc_isa_") as tmp:
+        text = isa_check.disassemble(unit, tmp)
+    names = subprocess.run(["c++filt"], input=text, capture_output=True, text=True).stdout
+    want = f"k_nuts<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>"
+    out, on = [], False
+    for raw, dem in zip(text.splitlines(), names.splitlines()):
+        if re.match(r"^[0-9a-f]+ <.*>:$", raw.strip()):
+            on = want in dem
+        if on:
+            out.append(raw)
+    return "\n".join(out) if out else None
 
 kd = kernel_digest()
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
@@ -38,13 +67,33 @@ for cfg in sys.argv[1:]:
     c = {}
     for mode, r in s["counters"].items():
         c[mode] = {k: r.get(k) for k in ("valu_per_leapfrog", "salu_per_leapfrog", "lds_per_leapfrog", "vmem_per_leapfrog", "mfma_f64_per_leapfrog",
-                                          "hbm_bytes_per_leapfrog", "valu_busy", "mean_waves_per_simd")}
+                                          "hbm_bytes_per_leapfrog", "valu_busy", "mean_waves_per_simd", "valu_mix_per_leapfrog")}
+        # the mix-weighted VALU-issue roof of this kernel: measured per-class issue rates (the probe) weighted by its dynamic
+        # instruction mix (SQ_INSTS_VALU_* per leapfrog; the classes the hardware does not count are split by the static
+        # census of the kernel's hot loop) — scripts/valu_mix.py
+        kn = (s.get(f"{mode}_launches") or {}).get("kernel")
+        if kn and r.get("valu_mix_per_leapfrog") and os.path.exists(RATES):
+            text = kernel_text(kn)
+            if text:
+                w = max(1, min(8, int(round(r.get("mean_waves_per_simd") or 4))))
+                w = {1: 1, 2: 2, 3: 4, 4: 4, 5: 4, 6: 8, 7: 8, 8: 8}[w]
+                try:
+                    a = valu_mix.analyse(text, valu_mix.load_rates(RATES, f"W{w}"), r["valu_mix_per_leapfrog"], r["valu_per_leapfrog"], 1, f"W{w}")
+                    a0 = valu_mix.analyse(text, valu_mix.load_rates(RATES, f"W{w}"), r["valu_mix_per_leapfrog"], r["valu_per_leapfrog"], 0, f"W{w}")
+                    c[mode]["valu_peak_mix_gwave_instr_per_s"] = a["peak_mix_gwave_instr_per_s"]
+                    c[mode]["valu_peak_mix"] = {"rates": os.path.relpath(RATES, ROOT), "priced_at_waves_per_simd": w, "kernel": kn,
+                                                "class_counts_per_leapfrog": a["dynamic"]["class_counts_per_leapfrog"],
+                                                "issue_time_share": a["dynamic"]["issue_time_share"],
+                                                "hot_loop_static_valu": a["hot_loop"]["static_valu"],
+                                                "sensitivity_innermost_loop_peak": a0["peak_mix_gwave_instr_per_s"]}
+                except Exception as ex:  # noqa: BLE001
+                    c[mode]["valu_peak_mix_error"] = repr(ex)
     out["configs"][cfg] = c
     keep = {k: s.get(k) for k in ("config", "command", "kernel_digest", "kernel_stats", "mode0_launches", "mode3_launches", "counters", "leapfrogs_by_pass", "per_kernel_counters")}
     keep["bench_plain"] = s.get("bench_plain")
-    with open(os.path.join(ROOT, "profiles", f"r2_{cfg}_profile_summary.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", f"{ROUND}_{cfg}_profile_summary.json"), "w") as f:
         json.dump(keep, f, indent=1)
-    with open(os.path.join(ROOT, "profiles", f"r2_{cfg}_top_kernels.txt"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", f"{ROUND}_{cfg}_top_kernels.txt"), "w") as f:
         f.write(f"# {s.get('command')}\n# rocprofv3 --kernel-trace --stats, device code {kd[:16]}, after commit {head}\n")
         for k in s.get("kernel_stats", []):
             f.write("%10.1f ms %7d calls %10.1f us avg %5.1f %%  %s\n" % (k["total_us"] / 1e3, k["calls"], k["average_us"], k["percent"], k["name"]))

@@ -60,7 +60,7 @@ if cur:
 
 per_mode = {"mode0": defaultdict(float), "mode3": defaultdict(float)}
 lf_by_pass = {}
-for name in ("fetch", "write", "sq1", "sq2", "grbm"):
+for name in ("fetch", "write", "sq1", "sq2", "sq3", "grbm"):
     cur = db(name)
     b = bench_json(name)
     if not cur or "config" not in b:
@@ -74,16 +74,20 @@ for name in ("fetch", "write", "sq1", "sq2", "grbm"):
             if not rx.search(kn):
                 continue
             for cn, v in cur.execute("select counter_name, sum(value) from counters_collection where kernel_name = ? group by counter_name", (kn,)):
+                if name == "sq3" and cn == "SQ_INSTS_VALU":
+                    cn = "SQ_INSTS_VALU_MIXPASS"   # (also taken by sq1: keep the two passes' totals apart)
                 per_mode[f"mode{m}"][cn] += v / lf[f"mode{m}"]   # per leapfrog, with THIS pass's leapfrog count
 out["leapfrogs_by_pass"] = lf_by_pass
 # every kernel of the run: counters summed over all its dispatches (what the dense engine's kernels — k_dgemm, k_d_tree —
 # are read from: bytes moved, MFMA instructions, time from the kernel trace)
 per_kernel = defaultdict(lambda: defaultdict(float))
-for name in ("fetch", "write", "sq1", "sq2", "grbm"):
+for name in ("fetch", "write", "sq1", "sq2", "sq3", "grbm"):
     cur = db(name)
     if not cur:
         continue
     for kn, cn, v in cur.execute("select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
+        if name == "sq3" and cn == "SQ_INSTS_VALU":
+            cn = "SQ_INSTS_VALU_MIXPASS"
         per_kernel[kn][cn] += v
 tk = {k["name"]: k for k in out.get("kernel_stats", [])}
 rows = []
@@ -112,6 +116,12 @@ for mode, c in per_mode.items():
         r["lds_per_leapfrog"] = c.get("SQ_INSTS_LDS")
         r["vmem_per_leapfrog"] = (c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0))
         r["mfma_f64_per_leapfrog"] = c.get("SQ_INSTS_VALU_MFMA_F64")
+    if "SQ_INSTS_VALU_FMA_F64" in c:
+        # dynamic class mix (its own pass: SQ_INSTS_VALU of THAT pass is the denominator of the shares)
+        r["valu_mix_pass_total_per_leapfrog"] = c.get("SQ_INSTS_VALU_MIXPASS")
+        r["valu_mix_per_leapfrog"] = {k[len("SQ_INSTS_VALU_"):].lower(): c.get(k) for k in
+                                      ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+                                       "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT")}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         r["hbm_bytes_per_leapfrog"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
     if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:

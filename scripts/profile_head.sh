@@ -18,7 +18,7 @@ for CFG in "$@"; do
   timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/kt.json 2> $O/kt.err
   # PROFILE_PASSES bounds the run for the dense configs (hundreds of thousands of dispatches per pass: the five
   # databases of a 4-step cfg4 run filled the box's disk)
-  P=" ${PROFILE_PASSES:-fetch write sq1 sq2 grbm} "
+  P=" ${PROFILE_PASSES:-fetch write sq1 sq2 sq3 grbm} "
   pmc() { name=$1; shift; case "$P" in *" $name "*) ;; *) return;; esac
           timeout 900 rocprofv3 --pmc "$@" --kernel-trace -d $O/$name -o $name -- $CMD > $O/$name.json 2> $O/$name.err
           find $O/$name -name "*.csv" -size +8M -delete; }
@@ -26,6 +26,8 @@ for CFG in "$@"; do
   pmc write WRITE_SIZE
   pmc sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_F64
   pmc sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
+  # the dynamic instruction MIX of the VALU stream (what the mix-weighted issue roof is made from, scripts/probe/valu_rate.hip)
+  pmc sq3 SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT
   pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
   python scripts/profile_counters.py $O $CFG > $O/summary.json 2> $O/summary.err
   # keep the merge-back small: the per-dispatch databases stay on the box
