@@ -177,6 +177,13 @@ struct Ctx : CtxBase {
   // step-synchronous dense engine (ahmc_dense.hpp): M⁻¹, U⁻¹ (D,D); vector slots; per-chain tree state
   T *dn_minv = nullptr, *dn_uinv = nullptr, *dn_W = nullptr, *dn_es = nullptr, *dn_RB = nullptr, *dn_VB = nullptr;
   DChain<T>* dn_S = nullptr;
+  // the point pool of the NUTS loop (k_d_tree2): pool, ρ vectors, per-chain state, the point each chain's leapfrog is in
+  T *dn_P = nullptr, *dn_R = nullptr;
+  DChain2<T>* dn_S2 = nullptr;
+  int* dn_ptcur = nullptr;
+  int dn_npt = 0, dn_nrho = 0;
+  int64_t dn_gemm_big = 0, dn_gemm_small = 0;  // launches of the 64×64-tile / 64×16-tile GEMM (introspection for the tests)
+  int dn_last_pipelines = 0, dn_last_pool = 0;
   int* dn_active = nullptr;
   int* dn_list = nullptr;
   size_t dn_slots = 0, dn_batch_elems = 0;
@@ -214,7 +221,8 @@ struct Ctx : CtxBase {
       if (e) (void)hipEventDestroy(e);
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
-                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C, ext_gstage, ext_lpstage};
+                    dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C, ext_gstage, ext_lpstage,
+                    dn_P, dn_R, dn_S2, dn_ptcur};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending, &ev_pending_warm})
@@ -633,14 +641,16 @@ int64_t nuts_batch(Ctx<T>* c) {
     // ... and under a quarter of what is free on THIS device now (several contexts on one GPU, a user log-density at large
     // D·N, a part with less than 288 GB): the buffers already held by this context (dn_batch_elems) count as free
     size_t free_b = 0, total_b = 0;
-    size_t budget = 48ull << 30;
+    // (round 3: up to 1 024 transitions under 128 GiB — with the step-size adaptation inside the tree kernel the warm-up runs in
+    // batches as well, and the idle tail of a batch is the same number of global steps however long the batch is)
+    size_t budget = 128ull << 30;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const size_t held = c->dn_batch_elems * 2 * sizeof(T) + c->znorm_elems * sizeof(T);
-      budget = std::min<size_t>(budget, (free_b + held) / 4);
+      budget = std::min<size_t>(budget, (free_b + held) / 3);
     }
     (void)hipGetLastError();
     const int64_t capd = (int64_t)budget / (int64_t)(3 * sizeof(T) * c->D * c->N);
-    return std::max<int64_t>(1, std::min<int64_t>(256, capd));
+    return std::max<int64_t>(1, std::min<int64_t>(1024, capd));
   }
   // Round 2: 32 -> 128 under an 8 GiB cap.  A launch cannot end before its slowest chain, and in the warm-up (step sizes
   // still moving, the dual averaging restarting at every window end) a few chains build 10-30x the mean tree for a
@@ -1609,6 +1619,25 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         i += k;
         continue;
       }
+      static const int dense_pool_env = getenv("AHMC_DENSE_POOL") ? atoi(getenv("AHMC_DENSE_POOL")) : 1;
+      if (adapting && fused_adapt && dense_pool_env != 0 && cfg->nuts && dense_engine(c) && c->adapt_kind == AHMC_ADAPT_STEPSIZE &&
+          cfg->criterion == AHMC_TC_GENERALISED && (cfg->sampler == AHMC_TS_MULTINOMIAL || cfg->sampler == AHMC_TS_SLICE) &&
+          c->integ_kind != AHMC_INTEGRATOR_TEMPERED && cfg->refresh_alpha == 0 && c->target_kind != AHMC_TARGET_EXTERNAL &&
+          (!so || !keep || so_on_device)) {
+        // dense engine, StepSizeAdaptor: the warm-up in batches too — every chain adapts its own ϵ at the end of each of its
+        // transitions inside the tree kernel and goes on, instead of all chains waiting for the longest tree of every transition
+        const int64_t left = std::min(n_adapts, n_samples) - i + 1, nb_left = (left + batch - 1) / batch;
+        const int64_t k = (left + nb_left - 1) / nb_left;
+        const int64_t j = i - (drop_warmup ? n_adapts : 0);
+        T* dst = (so && keep) ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
+        int rc = dn_nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, keep, (int)k, dst, i - 1, n_adapts);
+        if (rc) return rc;
+        c->eps_scalar = false;
+        if (i + k - 1 >= n_adapts) c->adapting = false;
+        if (keep) c->acc_ntrans += k;
+        i += k;
+        continue;
+      }
       int rc = cfg->nuts ? nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, keep)
                          : hmc_transition(c, cfg->L, cfg->lambda, cfg->sampler, cfg->refresh_alpha, keep);
       if (rc) return rc;
@@ -1683,6 +1712,10 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
         *out = (int64_t)c->nuts_warm_kernel_ns;
         break;
       }
+      case AHMC_INFO_DENSE_GEMM_LAUNCHES: *out = c->dn_gemm_big; break;
+      case AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES: *out = c->dn_gemm_small; break;
+      case AHMC_INFO_DENSE_PIPELINES: *out = c->dn_last_pipelines; break;
+      case AHMC_INFO_DENSE_POOL: *out = c->dn_last_pool; break;
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
     }
     return AHMC_OK;

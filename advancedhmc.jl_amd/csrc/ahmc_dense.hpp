@@ -58,10 +58,13 @@ constexpr int GB_P = AHMC_GB_P;
 // loads of tile t+P are issued before tile t is multiplied, so a lone workgroup on a CU (the tail of a
 // NUTS batch, when few chains are still running) still covers the ≈1-2 µs load latency with
 // P·16 MFMAs ≈ 1.7 µs of matrix work.  One barrier per tile.
+// Point pool (k_d_tree2): a column's vector may live in the chain's pool point ptidx[col] instead of a fixed (D,N) array — then
+// its address is base + ptidx[col]·xps (X) / ·yps (Y, Y2) + col·D.  xps / yps = 0: the plain (D,N) array.
 template <class T>
 __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N,
                                                const int* __restrict__ idx,  // idx: optional list of the N columns (chains) to process
-                                               const T* __restrict__ A2, T* __restrict__ Y2) {  // optional second product Y2 = A2·X in the same launch
+                                               const T* __restrict__ A2, T* __restrict__ Y2,  // optional second product Y2 = A2·X in the same launch
+                                               const int* __restrict__ ptidx, int64_t xps, int64_t yps) {
   __shared__ T As[2][GB_K][GB_M + GB_PAD];
   __shared__ T Bs[2][GB_K][GB_N + GB_PAD];
   using M = Mfma<T>;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
   const int64_t bcol = n0 + bn < N ? (idx ? (int64_t)idx[n0 + bn] : n0 + bn) : -1;
   const bool arow0 = m0 + ai < D, arow1 = m0 + ai + 1 < D;
   const T* Ap = A + (m0 + ai);
-  const T* Xp = X + (bcol >= 0 ? bcol : 0) * (int64_t)D;
+  const T* Xp = X + (bcol >= 0 ? bcol : 0) * (int64_t)D + ((ptidx && bcol >= 0) ? (int64_t)ptidx[bcol] * xps : 0);
   auto load_tile = [&](int k0, T (&a)[4], T (&b)[4]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -151,10 +154,11 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
     for (int tj = 0; tj < 2; ++tj) {
       const int64_t j = n0 + wn + tj * 16 + (lane & 15);
       const int64_t col = j < N ? (idx ? (int64_t)idx[j] : j) : -1;
+      const int64_t yoff = col >= 0 ? col * D + (ptidx ? (int64_t)ptidx[col] * yps : 0) : 0;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = m0 + wm + ti * 16 + M::row(lane, v);
-        if (row < D && col >= 0) Y[row + col * D] = acc[ti][tj][v];
+        if (row < D && col >= 0) Y[row + yoff] = acc[ti][tj][v];
       }
     }
 }
@@ -164,7 +168,8 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
 // wave is 4× shorter (≈10 µs instead of ≈38 µs at D = 512).
 template <class T>
 __global__ __launch_bounds__(256) void k_dgemm_small(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N,
-                                                     const int* __restrict__ idx, const T* __restrict__ A2, T* __restrict__ Y2) {
+                                                     const int* __restrict__ idx, const T* __restrict__ A2, T* __restrict__ Y2,
+                                                     const int* __restrict__ ptidx, int64_t xps, int64_t yps) {
   constexpr int BN = 16;
   __shared__ T As[2][GB_K][GB_M + GB_PAD];
   __shared__ T Bs[2][GB_K][BN + 4];
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void k_dgemm_small(const T* __restrict__ A, co
   const int64_t bcol = n0 + bn < N ? (idx ? (int64_t)idx[n0 + bn] : n0 + bn) : -1;
   const bool arow0 = m0 + ai < D, arow1 = m0 + ai + 1 < D;
   const T* Ap = A + (m0 + ai);
-  const T* Xp = X + (bcol >= 0 ? bcol : 0) * (int64_t)D;
+  const T* Xp = X + (bcol >= 0 ? bcol : 0) * (int64_t)D + ((ptidx && bcol >= 0) ? (int64_t)ptidx[bcol] * xps : 0);
   auto load_tile = [&](int k0, T (&a)[4], T& b) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -224,10 +229,11 @@ __global__ __launch_bounds__(256) void k_dgemm_small(const T* __restrict__ A, co
   }
   const int64_t j = n0 + (lane & 15);
   const int64_t col = j < N ? (idx ? (int64_t)idx[j] : j) : -1;
+  const int64_t yoff = col >= 0 ? col * D + (ptidx ? (int64_t)ptidx[col] * yps : 0) : 0;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int row = m0 + w * 16 + M::row(lane, v);
-    if (row < D && col >= 0) Y[row + col * D] = acc[v];
+    if (row < D && col >= 0) Y[row + yoff] = acc[v];
   }
 }
 
@@ -411,7 +417,11 @@ __device__ __forceinline__ void vcopy(T* __restrict__ dst, const T* __restrict__
 // serves user log-densities of any dimension (ahmc_ext_*), where a request at D = 128 paid 127 µs for a kernel shaped
 // for D = 512.
 constexpr int DT_THREADS = 256;
-inline int dt_threads_for(int64_t D) { return D <= 128 ? 64 : (D <= 256 ? 128 : DT_THREADS); }
+inline int dt_threads_for(int64_t D) {
+  static const int ov = getenv("AHMC_DENSE_DT") ? atoi(getenv("AHMC_DENSE_DT")) : 0;  // experiments: 64 / 128 / 256 threads per chain
+  if (ov == 64 || ov == 128 || ov == 256) return ov;
+  return D <= 128 ? 64 : (D <= 256 ? 128 : DT_THREADS);
+}
 // all-reduce of a pair over the DT_THREADS threads of the workgroup (every decision of d_tree_advance is taken on
 // such sums or on per-chain scalars, so all threads follow the same control flow and reach the barriers together)
 template <int DT, class T>
@@ -1001,6 +1011,508 @@ __global__ __launch_bounds__(256) void k_d_tree_reset(DChain<T>* S, T* es, int* 
   S[c].phase = DPH_START;
   S[c].it = 0;
   es[c] = T(0);
+}
+
+// ================================================================================================
+// The NUTS loop on a POINT POOL (round 3): k_d_tree2.
+//
+// k_d_tree keeps "the current point" in fixed (D,N) arrays and COPIES whatever must outlive a leapfrog: every leaf that does
+// not end its subtree parks five vectors (ρ, v_first, candidate θ / r / g), an accepted subtree copies its candidate, a
+// change of direction swaps five vectors, a new transition copies the state into eight slots — ≈ 20 D-vectors of HBM traffic
+// per chain-step where the two half-steps need 8, and at cfg4 that kernel was as long as the GEMM it alternates with
+// (profiles/r2_cfg4_top_kernels.txt: 40 % of device time).
+//
+// Here a phase point is an immutable record in a per-chain pool, P[pt][θ r g v w][N][D], and everything the tree remembers
+// is an INDEX: the other edge, the tree-level candidate, per pending level the first-built leaf (→ its v for the U-turn test
+// and, at level 0, its r = the one-leaf subtree's ρ) and the level's candidate.  The first half-step of a leapfrog reads its
+// start point and writes a FRESH point (θ′, r½, v½) — no more traffic than updating in place —, the GEMM reads θ′ and
+// writes g′, w′ into that point through a per-column offset (k_dgemm: ptidx), the second half-step completes it in place.
+// Parking, accepting and changing direction move no vector at all; only the ρ of merged subtrees (sums, not points) are
+// vectors of their own, written straight into the slot of the level they will be parked at.  A new transition starts on
+// the candidate's own point (fresh r, v written over it; its g and w = M⁻¹g are still valid, so the motionless warm-up step
+// of k_d_tree is needed for the first transition of a batch only).  A free point is any index no holder names
+// (≤ 2·max_depth + 2 live at once; found from a bit mask, no reference counts).
+//
+// GeneralisedNoUTurn, untempered leapfrogs, MultinomialTS / SliceTS — the default NUTS; the other criteria and the
+// TemperedLeapfrog keep k_d_tree_crit, ask / tell (ahmc_ext_*) keeps k_d_tree (its positions must sit in ctx->th).
+// Same draws in the same order, same arithmetic per element as k_d_tree: chains are bit-identical to it.
+// ================================================================================================
+enum { PV_TH = 0, PV_R = 1, PV_G = 2, PV_V = 3, PV_W = 4, PV_COUNT = 5 };
+enum { PR_TREE = 0, PR_SUB0 = 1, PR_SUB1 = 2, PR_LEVEL0 = 2 };  // ρ vectors: whole tree, two scratch, level l >= 1 at PR_LEVEL0 + l
+
+template <class T>
+struct DChain2 {
+  T H0, eps, w_tree, sa_tree, dh_tree, lu;
+  T cand_lp, cand_lk;
+  T pw[DN_MAXLEV], psa[DN_MAXLEV], pdh[DN_MAXLEV], plp[DN_MAXLEV], plk[DN_MAXLEV];
+  int32_t pna[DN_MAXLEV];
+  int32_t phase, it, jw, leaf, v, cur_is_left, na_tree, depth, numerical;
+  uint32_t k;
+  int8_t p_first[DN_MAXLEV], p_cand[DN_MAXLEV];  // per pending level: point of its first-built leaf, point of its candidate
+  int8_t cur, oth, cand, pad_;                   // the leaf in flight (moving edge), the other edge, the tree-level candidate
+};
+
+template <class T>
+struct DP2 {
+  T* P;             // point pool  [n_pt][PV_COUNT][N][D]
+  T* R;             // ρ vectors   [PR_LEVEL0 + n_lev][N][D]
+  DChain2<T>* S;
+  int* ptcur;       // (N,) pool point of the leapfrog in flight: what the GEMM reads θ′ from and writes g′, w′ to
+  T* es;
+  const T* RB;
+  const T* VB;
+  int n_trans;
+  int n_pt;
+  int* n_active;
+  const int* list;
+  int64_t n_list;
+  int dense_metric;
+  int staged;       // 1: the target is not the dense Gaussian — θ′ goes to ctx->th as well and (ℓπ, g′) come back in ctx->lp / ctx->g
+  // StepSizeAdaptor inside the kernel (warm-up in batches): adapt!(h, κ, adaptor, i, n_adapts, z, α) of src/sampler.jl:72-90 for a
+  // NesterovDualAveraging (stepsize.jl:178-210) needs only the chain's own α, so a chain adapts its ϵ at the end of each of its
+  // transitions and starts the next one at once — no barrier of all chains per transition (k_nuts MODE 3 does the same)
+  int adapt_ss;
+  int64_t i0, n_adapts;  // iterations done before this batch; the adaptor stops after iteration n_adapts (finalize!)
+  T delta, gamma, t0, kappa;
+  int32_t* da_m;
+  T *da_eps, *da_mu, *da_xbar, *da_Hbar;
+};
+
+template <class T>
+__device__ __forceinline__ T* ppt(const DP2<T>& q, const KP<T>& p, int pt, int vec, int64_t c) {
+  return q.P + (((int64_t)pt * PV_COUNT + vec) * p.N + c) * p.D;
+}
+template <class T>
+__device__ __forceinline__ T* prho(const DP2<T>& q, const KP<T>& p, int slot, int64_t c) {
+  return q.R + ((int64_t)slot * p.N + c) * p.D;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_d_compact2(const DChain2<T>* __restrict__ S, const int* __restrict__ in, int64_t n, int* __restrict__ out,
+                                                    int* __restrict__ count) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int c = in ? in[j] : (int)j;
+  if (S[c].phase != DPH_IDLE) out[atomicAdd(count, 1)] = c;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_d_tree2_reset(DChain2<T>* S, T* es, int* ptcur, int* n_active, int64_t N) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *n_active = (int)N;
+  if (c >= N) return;
+  S[c].phase = DPH_START;
+  S[c].it = 0;
+  S[c].cur = S[c].oth = S[c].cand = 0;
+  es[c] = T(0);
+  ptcur[c] = 0;
+}
+
+// The tree bookkeeping of one completed leapfrog (the leaf is the pool point S.cur, its energies lp_in / lk_in).  Returns the
+// signed step of the chain's next leapfrog (0 = idle, or the motionless warm-up step) and, in `src`, the pool point that
+// leapfrog starts from; `used` = bit mask of the points that must survive it.
+template <class T, int DT>
+__device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, int64_t c, int lane, T lp_in, T lk_in, int& src, uint64_t& used) {
+  DChain2<T>& S = q.S[c];
+  const int D = p.D;
+  const bool slice = p.sampler == 2;
+  Rng rng = make_rng(p, c);
+  DrawStream ds;
+  auto resume_draws = [&](uint32_t it, uint32_t k) {
+    rng.iter = p.iteration + it;
+    ds.resume(rng, k);
+  };
+  auto bit = [](int pt) { return (uint64_t)1 << pt; };
+  int phase = S.phase, it = S.it;
+  const int cur = S.cur;
+  if (phase == DPH_WARM) {
+    // the motionless step has produced w = M⁻¹g at the start point of the batch's first transition: let the first leapfrog go
+    const T e_first = S.v < 0 ? -S.eps : S.eps;
+    __syncthreads();  // (every thread has read the phase before thread 0 changes it)
+    if (lane == 0) S.phase = DPH_RUN;
+    src = cur;
+    used = bit(cur);  // cur = oth = cand = the start point
+    return e_first;
+  }
+  bool start = phase == DPH_START;
+  T lp_start = lp_in;
+  int start_pt = cur;
+  if (!start) {
+    resume_draws((uint32_t)it, S.k);
+    const T H0 = S.H0, eps = S.eps;
+    const int v = S.v, jw = S.jw;
+    const int leaf = S.leaf;
+    const uint32_t nleaf = 1u << jw;
+    const int oth = S.oth;
+    int cand_tree = S.cand;
+    const T lp = lp_in, lk = lk_in;
+    // ---- leaf (:638-647) ----
+    const T ne = lp + lk;
+    const T dH = -ne - H0;
+    T sa_c = exp(jl_min(T(0), -dH)), dh_c = dH, w_c;
+    int na_c = 1;
+    bool sub_term;
+    if (slice) {
+      w_c = (S.lu <= ne) ? T(1) : T(0);
+      sub_term = !(S.lu < p.delta_max + ne);
+    } else {
+      w_c = H0 + ne;
+      sub_term = !(-H0 < p.delta_max + ne);
+    }
+    bool numerical = S.numerical != 0 || sub_term;
+    const int cur_is_left_in = S.cur_is_left;
+    __syncthreads();  // every thread has read the chain's scalars: from here on thread 0 may update them
+    // the subtree being assembled: its first-built leaf, its candidate (pool points) and its ρ (a view: the leaf's own r
+    // until the first merge, then a ρ vector)
+    const T* Vc = ppt(q, p, cur, PV_V, c);
+    const T* rho_v = ppt(q, p, cur, PV_R, c);
+    int first_c = cur, cand_c = cur;
+    T sub_lp = lp, sub_lk = lk;
+    // ---- merges: one per trailing zero bit of `leaf` (:649-673) ----
+    const int nm = __builtin_ctz((uint32_t)leaf);
+    const bool will_park = (uint32_t)leaf < nleaf;
+    int merged = 0;
+    for (int lvl = 0; lvl < nm && !sub_term; ++lvl) {
+      const int pf = S.p_first[lvl];
+      const T* p_rho = lvl == 0 ? ppt(q, p, pf, PV_R, c) : prho(q, p, PR_LEVEL0 + lvl, c);
+      const T* p_vf = ppt(q, p, pf, PV_V, c);
+      // the merged subtree has level lvl + 1: the last merge of a subtree that will be parked writes its ρ straight into
+      // that level's slot (free: a first half is completing there), the others into the two scratch vectors in turn
+      T* out = (lvl == nm - 1 && will_park) ? prho(q, p, PR_LEVEL0 + nm, c) : prho(q, p, (lvl & 1) ? PR_SUB1 : PR_SUB0, c);
+      const T w_p = S.pw[lvl];
+      bool keep_first;
+      T w_new;
+      if (slice) {
+        w_new = w_p + w_c;
+        keep_first = w_new * (T)ds.uniform() < w_p;
+      } else {
+        w_new = logaddexp(w_p, w_c);
+        keep_first = w_new < w_p + (T)ds.randexp();
+      }
+      if (keep_first) {
+        cand_c = S.p_cand[lvl];
+        sub_lp = S.plp[lvl];
+        sub_lk = S.plk[lvl];
+      }
+      w_c = w_new;
+      sa_c = S.psa[lvl] + sa_c;
+      na_c = S.pna[lvl] + na_c;
+      const T dh_p = S.pdh[lvl];
+      dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+      // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
+      T dots[2] = {0, 0};
+      for (int d = lane; d < D; d += DT) {
+        const T rho = p_rho[d] + rho_v[d];
+        dots[0] += rho * p_vf[d];
+        dots[1] += rho * Vc[d];
+        out[d] = rho;
+      }
+      rho_v = out;
+      first_c = pf;
+      block_allsum2<DT>(dots[0], dots[1]);
+      sub_term = (dots[0] <= 0) || (dots[1] <= 0);
+      merged = lvl + 1;
+    }
+    bool subtree_over = true;
+    if (sub_term) {
+      // enclosing unfinished subtrees still absorb the statistics of their first halves (:666)
+      const uint32_t pend = (((uint32_t)leaf - 1u) >> merged) << merged;
+      for (int qq = merged; (pend >> qq) != 0u; ++qq) {
+        if ((pend >> qq) & 1u) {
+          sa_c = S.psa[qq] + sa_c;
+          na_c = S.pna[qq] + na_c;
+          const T dh_p = S.pdh[qq];
+          dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+        }
+      }
+    } else if (will_park) {
+      // park the finished level-nm subtree until its sibling is built: indices and scalars only (its ρ is the first leaf's r
+      // at level 0 and already sits in the level's slot otherwise)
+      uint64_t u = bit(cur) | bit(oth) | bit(cand_tree) | bit(first_c) | bit(cand_c);
+      for (int l = 0; l < DN_MAXLEV; ++l)
+        if (l != nm && (((uint32_t)leaf >> l) & 1u)) u |= bit(S.p_first[l]) | bit(S.p_cand[l]);
+      __syncthreads();  // (all threads have read p_first / p_cand of the pending levels)
+      if (lane == 0) {
+        S.p_first[nm] = (int8_t)first_c;
+        S.p_cand[nm] = (int8_t)cand_c;
+        S.pw[nm] = w_c;
+        S.psa[nm] = sa_c;
+        S.pdh[nm] = dh_c;
+        S.pna[nm] = na_c;
+        S.plp[nm] = sub_lp;
+        S.plk[nm] = sub_lk;
+        S.leaf = leaf + 1;
+        S.numerical = numerical ? 1 : 0;
+        S.k = ds.k;
+      }
+      subtree_over = false;  // next leapfrog: same edge, same direction
+      src = cur;
+      used = u;
+    }
+    if (!subtree_over) return v > 0 ? eps : -eps;
+
+    // ---- top level of the doubling loop (:708-722) ----
+    T w_tree = S.w_tree, sa_tree = S.sa_tree, dh_tree = S.dh_tree;
+    int na_tree = S.na_tree, depth = S.depth;
+    T cand_lp = S.cand_lp, cand_lk = S.cand_lk;
+    if (!sub_term) {
+      ++depth;
+      bool acc;  // mh_accept(rng, sampler, sampler′): biased progressive sampling (:202-206)
+      if (slice) acc = w_tree * (T)ds.uniform() < w_c;
+      else acc = w_tree < w_c + (T)ds.randexp();
+      if (acc) {
+        cand_tree = cand_c;
+        cand_lp = sub_lp;
+        cand_lk = sub_lk;
+      }
+    }
+    sa_tree = sa_tree + sa_c;
+    na_tree = na_tree + na_c;
+    dh_tree = v < 0 ? maxabs(dh_c, dh_tree) : maxabs(dh_tree, dh_c);
+    w_tree = slice ? w_tree + w_c : logaddexp(w_tree, w_c);
+    // isterminated on the whole tree; its edges are `cur` and the other one
+    bool turn;
+    {
+      T* t_rho = prho(q, p, PR_TREE, c);
+      const T* o_v = ppt(q, p, oth, PV_V, c);
+      T dots[2] = {0, 0};
+      for (int d = lane; d < D; d += DT) {
+        const T rho = t_rho[d] + rho_v[d];
+        dots[0] += rho * Vc[d];
+        dots[1] += rho * o_v[d];
+        t_rho[d] = rho;
+      }
+      block_allsum2<DT>(dots[0], dots[1]);
+      turn = (dots[0] <= 0) || (dots[1] <= 0);
+    }
+    const bool done = sub_term || turn || (jw + 1 >= p.max_depth);
+    if (!done) {
+      // ---- next doubling: direction (:693), edge selection — a change of direction swaps two indices ----
+      const bool vleft = ds.boolean();
+      const bool cur_is_left = cur_is_left_in != 0;
+      const bool swap = vleft != cur_is_left;
+      const int new_oth = swap ? cur : oth;
+      src = swap ? oth : cur;
+      used = bit(src) | bit(new_oth) | bit(cand_tree);
+      if (lane == 0) {
+        S.w_tree = w_tree; S.sa_tree = sa_tree; S.dh_tree = dh_tree; S.na_tree = na_tree; S.depth = depth;
+        S.cand_lp = cand_lp; S.cand_lk = cand_lk;
+        S.cand = (int8_t)cand_tree;
+        S.oth = (int8_t)new_oth;
+        S.numerical = numerical ? 1 : 0;
+        S.cur_is_left = vleft ? 1 : 0;
+        S.v = vleft ? -1 : 1;
+        S.jw = jw + 1;
+        S.leaf = 1;
+        S.k = ds.k;
+      }
+      return vleft ? -eps : eps;
+    }
+    // ---- Transition(zcand, stats) (:725-741) ----
+    {
+      const T* c_th = ppt(q, p, cand_tree, PV_TH, c);
+      T* s1 = p.acc_sum() + c * D;
+      T* s2 = p.acc_sumsq() + c * D;
+      T* so = p.samples_out ? p.samples_out + ((int64_t)it * p.N + c) * D : nullptr;
+      const bool last = it + 1 >= q.n_trans;
+      if (p.accum || so || last) {
+        const T* c_r = ppt(q, p, cand_tree, PV_R, c);
+        const T* c_g = ppt(q, p, cand_tree, PV_G, c);
+        T* th = p.th() + c * D;
+        T* r = p.r() + c * D;
+        T* g = p.g() + c * D;
+        for (int d = lane; d < D; d += DT) {
+          const T t = c_th[d];
+          if (p.accum) { s1[d] += t; s2[d] += t * t; }
+          if (so) so[d] = t;
+          if (last) {  // the state the context holds after the batch (ahmc_get_phasepoint, the next call's start point)
+            th[d] = t;
+            r[d] = c_r[d];
+            g[d] = c_g[d];
+          }
+        }
+      }
+      if (lane == 0) {
+        const T H = -(cand_lp + cand_lk);
+        p.lp()[c] = cand_lp;
+        p.lk()[c] = cand_lk;
+        p.eps_cur()[c] = eps;
+        p.st_nsteps()[c] = na_tree;
+        p.st_accept()[c] = 1;
+        p.st_accrate()[c] = sa_tree / (T)na_tree;
+        p.st_logdens()[c] = cand_lp;
+        p.st_H()[c] = H;
+        p.st_Herr()[c] = H - H0;
+        p.st_maxHerr()[c] = dh_tree;
+        p.st_depth()[c] = depth;
+        p.st_numerr()[c] = numerical ? 1 : 0;
+        if (p.accum) {
+          p.acc_nsteps()[c] += na_tree;
+          p.acc_ndiv()[c] += numerical ? 1 : 0;
+          accumulate_energy(p, c, H);
+        }
+        if (q.adapt_ss) {  // this chain's adapt! (the same arithmetic as k_adapt_da: a batched warm-up == the per-iteration one)
+          const int64_t i = q.i0 + it + 1;
+          if (i <= q.n_adapts) {
+            DAState<T> das{q.da_m[c], q.da_eps[c], q.da_mu[c], q.da_xbar[c], q.da_Hbar[c]};
+            da_step(das, sa_tree / (T)na_tree, q.delta, q.gamma, q.t0, q.kappa);
+            if (i == q.n_adapts) das.eps = exp(das.xbar);  // finalize! (stepsize.jl:55-62)
+            q.da_m[c] = das.m; q.da_eps[c] = das.eps; q.da_mu[c] = das.mu; q.da_xbar[c] = das.xbar; q.da_Hbar[c] = das.Hbar;
+            p.eps_nom()[c] = das.eps;                      // update(κ, adaptor): nominal step size ← getϵ
+          }
+        }
+      }
+      ++it;
+      if (it >= q.n_trans) {
+        if (lane == 0) {
+          S.phase = DPH_IDLE;
+          S.it = it;
+          atomicSub(q.n_active, 1);
+        }
+        src = cand_tree;
+        used = bit(cand_tree);
+        return T(0);
+      }
+      if (q.adapt_ss) {  // the next transition's ϵ is read from memory by every thread (chain_eps): thread 0's store must be visible
+        __threadfence_block();
+        __syncthreads();
+      }
+      start = true;
+      lp_start = cand_lp;
+      start_pt = cand_tree;  // the next transition starts ON the candidate's point
+    }
+  }
+  // ---- start of transition `it` (src/sampler.jl:54-57, src/trajectory.jl:677-690) on the point start_pt: θ, g (and w) are
+  // the candidate's (first transition of a batch: copied in from the context), fresh r and v = M⁻¹r from the batch ----
+  {
+    resume_draws((uint32_t)it, 0u);
+    const T eps = chain_eps(p, rng, c);
+    const T* rb = q.RB + ((int64_t)it * p.N + c) * D;
+    const T* vb = q.VB + ((int64_t)it * p.N + c) * D;
+    T* s_r = ppt(q, p, start_pt, PV_R, c);
+    T* s_v = ppt(q, p, start_pt, PV_V, c);
+    T* t_rho = prho(q, p, PR_TREE, c);
+    const bool first_of_batch = phase == DPH_START;
+    T* s_th = ppt(q, p, start_pt, PV_TH, c);
+    T* s_g = ppt(q, p, start_pt, PV_G, c);
+    const T* th = p.th() + c * D;
+    const T* g = p.g() + c * D;
+    T dots[2] = {0, 0};
+    for (int d = lane; d < D; d += DT) {
+      const T rd = rb[d], vd = vb[d];
+      dots[0] += rd * vd;
+      s_r[d] = rd;
+      s_v[d] = vd;
+      t_rho[d] = rd;
+      if (first_of_batch) {
+        s_th[d] = th[d];
+        s_g[d] = g[d];
+      }
+    }
+    block_allsum2<DT>(dots[0], dots[1]);
+    const T lp = lp_start;
+    const T lk = sanitize(-dots[0] / 2);
+    const T H0 = -(lp + lk);
+    T lu = 0, w_tree;
+    if (slice) {
+      lu = -H0 - (T)ds.randexp();  // SliceTS(rng, z0) (:144-145)
+      w_tree = 1;
+    } else {
+      w_tree = 0;  // MultinomialTS(rng, z0): ℓw = 0 (:155)
+    }
+    const bool vleft = ds.boolean();
+    const bool warm = q.dense_metric && first_of_batch;  // w = M⁻¹g of the start point is not known yet
+    if (lane == 0) {
+      p.lk()[c] = lk;
+      S.H0 = H0; S.eps = eps; S.lu = lu; S.w_tree = w_tree; S.sa_tree = 0; S.dh_tree = 0; S.na_tree = 0;
+      S.cand_lp = lp; S.cand_lk = lk;
+      S.depth = 0; S.numerical = 0; S.jw = 0; S.leaf = 1;
+      S.cur_is_left = vleft ? 1 : 0;
+      S.v = vleft ? -1 : 1;
+      S.k = ds.k;
+      S.it = it;
+      S.cur = S.oth = S.cand = (int8_t)start_pt;
+      S.phase = warm ? DPH_WARM : DPH_RUN;
+    }
+    src = start_pt;
+    used = bit(start_pt);
+    return warm ? T(0) : (vleft ? -eps : eps);
+  }
+}
+
+// One global step for every listed chain: second half of the leapfrog in flight (completing its pool point) → d_tree_advance2
+// → first half of the next leapfrog INTO A FRESH POINT.  One chain per workgroup of DT threads.
+template <class T, int DT>
+__global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
+  const int lane = threadIdx.x;
+  const int64_t j = blockIdx.x;
+  if (j >= q.n_list) return;
+  const int64_t c = q.list ? q.list[j] : j;
+  DChain2<T>& S = q.S[c];
+  if (S.phase == DPH_IDLE) return;
+  const int D = p.D;
+  T lp = p.lp()[c], lk = p.lk()[c];
+  const int cur = S.cur;
+  if (do_post) {
+    T* TH = ppt(q, p, cur, PV_TH, c);
+    T* R = ppt(q, p, cur, PV_R, c);
+    T* G = ppt(q, p, cur, PV_G, c);
+    T* V = ppt(q, p, cur, PV_V, c);
+    const T* W = q.dense_metric ? ppt(q, p, cur, PV_W, c) : nullptr;
+    const T* g_in = q.staged ? p.g() + c * D : G;  // staged: the target kernel left g′ in the context's array
+    const T e = q.es[c];
+    T s[2] = {0, 0};
+    for (int d = lane; d < D; d += DT) {
+      const T gd = g_in[d];
+      T rn = R[d], vn;
+      if (e != T(0)) rn = rn - e / 2 * gd;
+      if (W) vn = e != T(0) ? V[d] - e / 2 * W[d] : V[d];
+      else vn = minv ? minv[per_chain ? c * D + d : d] * rn : rn;
+      if (e != T(0) || !W) { R[d] = rn; V[d] = vn; }
+      if (q.staged) G[d] = gd;
+      s[0] += rn * vn;
+      s[1] += TH[d] * gd;
+    }
+    block_allsum2<DT>(s[0], s[1]);
+    lk = sanitize(-s[0] / 2);
+    if (dense_target) lp = sanitize(-s[1] / 2);
+    if (lane == 0) {
+      p.lk()[c] = lk;
+      if (dense_target) p.lp()[c] = lp;
+    }
+  }
+  int src = cur;
+  uint64_t used = 0;
+  const T e = d_tree_advance2<T, DT>(p, q, c, lane, lp, lk, src, used);
+  if (lane == 0) q.es[c] = e;
+  if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237): src → a fresh point
+    const int dst = __builtin_ctzll(~used);
+    const T* sTH = ppt(q, p, src, PV_TH, c);
+    const T* sR = ppt(q, p, src, PV_R, c);
+    const T* sG = ppt(q, p, src, PV_G, c);
+    const T* sV = ppt(q, p, src, PV_V, c);
+    const T* sW = q.dense_metric ? ppt(q, p, src, PV_W, c) : nullptr;
+    T* dTH = ppt(q, p, dst, PV_TH, c);
+    T* dR = ppt(q, p, dst, PV_R, c);
+    T* dV = ppt(q, p, dst, PV_V, c);
+    T* th_st = q.staged ? p.th() + c * D : nullptr;
+    for (int d = lane; d < D; d += DT) {
+      const T rh = sR[d] - e / 2 * sG[d];
+      const T vh = sW ? sV[d] - e / 2 * sW[d] : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
+      const T tn = sTH[d] + e * vh;
+      dR[d] = rh;
+      dV[d] = vh;
+      dTH[d] = tn;
+      if (th_st) th_st[d] = tn;
+    }
+    __syncthreads();  // (every thread has read S.cur)
+    if (lane == 0) {
+      S.cur = (int8_t)dst;
+      q.ptcur[c] = dst;
+    }
+  } else if (lane == 0) {
+    q.ptcur[c] = src;  // motionless / idle: the GEMM (if any) serves the point the chain sits on
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

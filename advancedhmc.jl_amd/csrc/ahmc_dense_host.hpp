@@ -48,7 +48,8 @@ int dn_other_target(Ctx<T>* c, const int* list, int64_t n) {
 }
 
 template <class T>
-int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* list = nullptr, const T* A2 = nullptr, T* Y2 = nullptr) {
+int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* list = nullptr, const T* A2 = nullptr, T* Y2 = nullptr,
+            const int* ptidx = nullptr, int64_t xps = 0, int64_t yps = 0) {  // ptidx / xps / yps: operands in the chains' pool points (k_dgemm)
   if (ncols <= 0) return AHMC_OK;
   // few columns: the 64×16-tile kernel puts 4× as many workgroups on the chip (same arithmetic per column,
   // so results do not depend on which kernel ran).  A2 / Y2: a second product on the same X in the same launch.
@@ -56,14 +57,16 @@ int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* l
   static const int64_t small_below = getenv("AHMC_GEMM_SMALL_BELOW") ? atoll(getenv("AHMC_GEMM_SMALL_BELOW")) : 1;  // measured D=512: N=512 22 vs 38 µs, N=2048 38 vs 40, N=4096 67 vs 59
   if (row_blocks * ((ncols + GB_N - 1) / GB_N) < small_below * c->n_cu) {
     dim3 grid((unsigned)row_blocks, (unsigned)((ncols + 15) / 16));
-    hipLaunchKernelGGL((k_dgemm_small<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2);
+    hipLaunchKernelGGL((k_dgemm_small<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2, ptidx, xps, yps);
     HIPCHK(hipGetLastError());
+    c->dn_gemm_small += 1;
     return AHMC_OK;
   }
   const int64_t cb8 = ((ncols + GB_N - 1) / GB_N + 7) / 8 * 8;  // column blocks padded to the 8 XCDs (see k_dgemm)
   dim3 grid((unsigned)(row_blocks * cb8));
-  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2);
+  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2, ptidx, xps, yps);
   HIPCHK(hipGetLastError());
+  c->dn_gemm_big += 1;
   return AHMC_OK;
 }
 
@@ -116,6 +119,33 @@ int dn_ensure(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
     HIPCHK(hipMemsetAsync(c->dn_es, 0, (size_t)c->N * sizeof(T), c->stream));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), 4 * sizeof(int)));                   // [0] batch counter, [1..2] compaction counts
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_list), 4 * (size_t)c->N * sizeof(int)));       // two ping-pong lists per pipeline
+  }
+  return AHMC_OK;
+}
+
+// the point pool of k_d_tree2 for trees of up to max_depth doublings: 2·max_depth + 2 points of 5 vectors per chain, and
+// max_depth + 2 ρ vectors (cfg4's shard, D = 512, 8 192 chains, max_depth 10: 3.7 GB + 0.4 GB of the 288)
+template <class T>
+int dn_ensure_pool(Ctx<T>* c, int max_depth) {
+  const int npt = 2 * max_depth + 2, nrho = PR_LEVEL0 + (max_depth > 1 ? max_depth : 2);
+  const size_t DN = (size_t)c->D * (size_t)c->N;
+  if (npt > c->dn_npt) {
+    if (c->dn_P) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->dn_P)); c->dn_P = nullptr; c->dn_npt = 0; }
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_P), (size_t)npt * PV_COUNT * DN * sizeof(T)));
+    HIPCHK(hipMemsetAsync(c->dn_P, 0, (size_t)npt * PV_COUNT * DN * sizeof(T), c->stream));
+    c->dn_npt = npt;
+  }
+  if (nrho > c->dn_nrho) {
+    if (c->dn_R) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->dn_R)); c->dn_R = nullptr; c->dn_nrho = 0; }
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_R), (size_t)nrho * DN * sizeof(T)));
+    HIPCHK(hipMemsetAsync(c->dn_R, 0, (size_t)nrho * DN * sizeof(T), c->stream));
+    c->dn_nrho = nrho;
+  }
+  if (!c->dn_S2) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_S2), (size_t)c->N * sizeof(DChain2<T>)));
+    HIPCHK(hipMemsetAsync(c->dn_S2, 0, (size_t)c->N * sizeof(DChain2<T>), c->stream));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_ptcur), (size_t)c->N * sizeof(int)));
+    HIPCHK(hipMemsetAsync(c->dn_ptcur, 0, (size_t)c->N * sizeof(int), c->stream));
   }
   return AHMC_OK;
 }
@@ -465,11 +495,13 @@ void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, cons
 // n_trans NUTS transitions of every chain (asynchronous chains, see ahmc_dense.hpp)
 template <class T>
 int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha, bool accum,
-                       int n_trans, T* samples_dev) {
+                       int n_trans, T* samples_dev, int64_t adapt_i0 = -1, int64_t adapt_n = 0) {  // adapt_i0 >= 0: StepSizeAdaptor inside the kernel
   int rc = dn_check(c, "nuts_transition", refresh_alpha);
   if (rc) return rc;
   if (criterion < AHMC_TC_CLASSIC || criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
   if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");
+  if (adapt_i0 >= 0 && !(criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED && refresh_alpha == 0))
+    return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: the in-kernel StepSizeAdaptor needs the point-pool kernel (GeneralisedNoUTurn, untempered, full refreshment)");
   if (refresh_alpha != 0 && n_trans > 1) {
     // a partially refreshed momentum depends on the momentum the previous transition ended with, so the batch's
     // momenta cannot be drawn up front: one transition per batch
@@ -492,13 +524,49 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   p.samples_out = samples_dev;
   DP<T> q = make_dp(c);
   q.n_trans = n_trans;
-  hipLaunchKernelGGL((k_d_tree_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, c->dn_es, c->dn_active, c->N);
   const bool dm = c->metric_kind == AHMC_METRIC_DENSE, dt = c->target_kind == AHMC_TARGET_DENSE_GAUSS;
   const T* minv_d = c->metric_kind == AHMC_METRIC_DIAG ? c->minv : nullptr;
   const int pc = c->minv_per_chain ? 1 : 0;
   T* Wcur = dm ? c->dn_W + (size_t)DS_CUR_W * c->D * c->N : nullptr;
-  // start of transition 0 (and, for Unit/Diag metrics, the first half of its first leapfrog)
-  launch_d_tree(c, criterion, (unsigned)c->N, p, q, minv_d, pc, dt ? 1 : 0, 0);
+  // The default NUTS (GeneralisedNoUTurn, untempered) runs on the point pool (k_d_tree2: no park / candidate / edge copies);
+  // the other criteria and the TemperedLeapfrog on the copying kernel.  AHMC_DENSE_POOL=0 forces the latter (A/B, tests).
+  const int pool_env = getenv("AHMC_DENSE_POOL") ? atoi(getenv("AHMC_DENSE_POOL")) : 1;
+  const bool pool = pool_env != 0 && criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED;
+  c->dn_last_pool = pool ? 1 : 0;
+  DP2<T> q2;
+  memset(&q2, 0, sizeof(q2));
+  const int64_t PS = (int64_t)PV_COUNT * c->N * c->D;  // pool stride between the points of a chain
+  T *Pth = nullptr, *Pg = nullptr, *Pw = nullptr;
+  const int dtt = dt_threads_for(c->D);
+  auto launch_tree2 = [&](unsigned grid, int do_post) {
+    if (dtt == 64) hipLaunchKernelGGL((k_d_tree2<T, 64>), dim3(grid), dim3(64), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);
+    else if (dtt == 128) hipLaunchKernelGGL((k_d_tree2<T, 128>), dim3(grid), dim3(128), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);
+    else hipLaunchKernelGGL((k_d_tree2<T, 256>), dim3(grid), dim3(256), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);
+  };
+  if (pool) {
+    rc = dn_ensure_pool(c, max_depth);
+    if (rc) return rc;
+    q2.P = c->dn_P; q2.R = c->dn_R; q2.S = c->dn_S2; q2.ptcur = c->dn_ptcur; q2.es = c->dn_es; q2.RB = c->dn_RB; q2.VB = c->dn_VB;
+    q2.n_trans = n_trans; q2.n_pt = c->dn_npt; q2.n_active = c->dn_active; q2.list = nullptr; q2.n_list = c->N;
+    q2.dense_metric = dm ? 1 : 0;
+    q2.staged = dt ? 0 : 1;
+    if (adapt_i0 >= 0) {
+      q2.adapt_ss = 1;
+      q2.i0 = adapt_i0;
+      q2.n_adapts = adapt_n;
+      q2.delta = (T)c->da_delta; q2.gamma = T(0.05); q2.t0 = T(10); q2.kappa = T(0.75);  // stepsize.jl:168-172
+      q2.da_m = c->da_m; q2.da_eps = c->da_eps; q2.da_mu = c->da_mu; q2.da_xbar = c->da_xbar; q2.da_Hbar = c->da_Hbar;
+    }
+    Pth = c->dn_P + (size_t)PV_TH * c->N * c->D;
+    Pg = c->dn_P + (size_t)PV_G * c->N * c->D;
+    Pw = c->dn_P + (size_t)PV_W * c->N * c->D;
+    hipLaunchKernelGGL((k_d_tree2_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S2, c->dn_es, c->dn_ptcur, c->dn_active, c->N);
+    launch_tree2((unsigned)c->N, 0);  // start of transition 0 (and, for Unit/Diag metrics, the first half of its first leapfrog)
+  } else {
+    hipLaunchKernelGGL((k_d_tree_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S, c->dn_es, c->dn_active, c->N);
+    // start of transition 0 (and, for Unit/Diag metrics, the first half of its first leapfrog)
+    launch_d_tree(c, criterion, (unsigned)c->N, p, q, minv_d, pc, dt ? 1 : 0, 0);
+  }
   HIPCHK(hipGetLastError());
   // global steps until every chain has finished the batch.  Every CHUNK steps the list of chains
   // still running is compacted and its length read back, so the tail of the batch (few chains with
@@ -522,6 +590,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
   const int split_env = getenv("AHMC_DENSE_SPLIT") ? atoi(getenv("AHMC_DENSE_SPLIT")) : 1;  // (read per call: the tests toggle it)
   const int NP = (split_env != 0 && dt && c->N >= 2048) ? 2 : 1;
+  c->dn_last_pipelines = NP;
   struct Pipe { hipStream_t s; const int* list; int64_t n_list; int pp; int* lists; int* cnt; int active; };
   Pipe pipes[2];
   if (NP == 2 && !c->stream2) {
@@ -569,26 +638,36 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
         q.n_list = h.n_list;
         // one global step = g′ = Pθ′ (or the built-in family's kernel), w′ = M⁻¹g′, then the fused
         // second-half / tree / first-half kernel
+        q2.list = h.list;
+        q2.n_list = h.n_list;
+        const int* pti = pool ? c->dn_ptcur : nullptr;
+        const T* gX = pool ? Pth : c->th;   // θ′ of the leapfrogs in flight
+        T* gY = pool ? Pg : c->g;           // g′
+        T* gW = pool ? Pw : Wcur;           // w′
+        const int64_t ps = pool ? PS : 0;
         if (by_kind) {
           c->stream = main_stream;
           if (tree_recorded[k] && hipStreamWaitEvent(main_stream, c->ev_tree[k], 0) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipStreamWaitEvent failed"));
-          rc = dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list, c->dn_C, Wcur);
+          rc = dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, c->dn_C, gW, pti, ps, ps);
           if (rc) return bail(rc);
           if (hipEventRecord(c->ev_gemm[k], main_stream) != hipSuccess || hipStreamWaitEvent(h.s, c->ev_gemm[k], 0) != hipSuccess)
             return bail(fail(c, AHMC_ERR_RUNTIME, "hipEventRecord / hipStreamWaitEvent failed"));
           c->stream = h.s;
         } else if (dt && dm && c->dn_fused_ok) {
-          rc = dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list, c->dn_C, Wcur);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
+          rc = dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, c->dn_C, gW, pti, ps, ps);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
           if (rc) return bail(rc);
         } else {
-          rc = dt ? dn_gemm(c, c->tparams, c->th, c->g, h.n_list, h.list) : dn_other_target(c, h.list, h.n_list);
+          // (a target that is not the dense Gaussian reads θ′ from / leaves g′ in the context's arrays: the pool is "staged")
+          rc = dt ? dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps) : dn_other_target(c, h.list, h.n_list);
           if (rc) return bail(rc);
           if (dm) {
-            rc = dn_gemm(c, c->dn_minv, c->g, Wcur, h.n_list, h.list);
+            rc = dt ? dn_gemm(c, c->dn_minv, (const T*)gY, gW, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps)
+                    : dn_gemm(c, c->dn_minv, (const T*)c->g, gW, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, (int64_t)0, ps);
             if (rc) return bail(rc);
           }
         }
-        launch_d_tree(c, criterion, (unsigned)h.n_list, p, q, minv_d, pc, dt ? 1 : 0, 1);
+        if (pool) launch_tree2((unsigned)h.n_list, 1);
+        else launch_d_tree(c, criterion, (unsigned)h.n_list, p, q, minv_d, pc, dt ? 1 : 0, 1);
         if (by_kind) {
           if (hipEventRecord(c->ev_tree[k], h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipEventRecord failed"));
           tree_recorded[k] = true;
@@ -603,7 +682,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
       c->stream = h.s;
       int* out = h.lists + (size_t)h.pp * c->N;
       if (hipMemsetAsync(h.cnt, 0, sizeof(int), h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipMemsetAsync failed"));
-      hipLaunchKernelGGL((k_d_compact<T>), dim3((unsigned)((h.n_list + 255) / 256)), dim3(256), 0, h.s, c->dn_S, h.list, h.n_list, out, h.cnt);
+      if (pool) hipLaunchKernelGGL((k_d_compact2<T>), dim3((unsigned)((h.n_list + 255) / 256)), dim3(256), 0, h.s, c->dn_S2, h.list, h.n_list, out, h.cnt);
+      else hipLaunchKernelGGL((k_d_compact<T>), dim3((unsigned)((h.n_list + 255) / 256)), dim3(256), 0, h.s, c->dn_S, h.list, h.n_list, out, h.cnt);
       if (hipMemcpyAsync(&h.active, h.cnt, sizeof(int), hipMemcpyDeviceToHost, h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipMemcpyAsync failed"));
     }
     for (int k = 0; k < NP; ++k) {

@@ -15,9 +15,12 @@ namespace ahmc {
 // a target plugin (ahmc_set_target_plugin) is compiled for the ONE geometry of the context it serves
 #define AHMC_GEOMETRIES(X) X(AHMC_PLUGIN_G, AHMC_PLUGIN_E)
 #else
+#ifndef AHMC_GEOMETRIES_EXTRA
+#define AHMC_GEOMETRIES_EXTRA(X)  // (experiments: -D'AHMC_GEOMETRIES_EXTRA(X)=X(8,4)' adds geometries to a variant build)
+#endif
 #define AHMC_GEOMETRIES(X) \
   X(4, 1) X(8, 1) X(16, 1) X(32, 1) X(64, 1) X(4, 2) X(8, 2) X(16, 2) X(32, 2) X(64, 2) X(32, 4) X(64, 4) X(64, 8) \
-  X(128, 4) X(256, 4) X(512, 4) X(128, 8) X(256, 8) X(512, 8)
+  X(128, 4) X(256, 4) X(512, 4) X(128, 8) X(256, 8) X(512, 8) AHMC_GEOMETRIES_EXTRA(X)
 #endif
 
 // call f(std::integral_constant<int,G>{}, std::integral_constant<int,E>{}) for a run-time geometry

@@ -41,7 +41,13 @@ def code_digest(text) -> str:
         t = line.strip()
         if not t or t == "...":
             continue
-        h.update(re.sub(r"\s*//.*$", "", t).encode())
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", t)
+        if m:
+            t = m.group(1)            # a kernel's header line: its name, not its address
+        else:
+            t = re.sub(r"\s*//.*$", "", t)            # encodings / addresses
+            t = re.sub(r"\s*<[^>]*\+0x[0-9a-f]+>", "", t)  # a branch target spelled as symbol + offset (the offset operand itself stays)
+        h.update(t.encode())
         h.update(b"\n")
     return h.hexdigest()
 

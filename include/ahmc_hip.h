@@ -435,7 +435,11 @@ typedef enum {
   AHMC_INFO_ITERATION = 4,        /* transitions done (the Philox iteration counter)             */
   AHMC_INFO_NUTS_KERNEL_NS = 5,   /* Σ device time of those launches, ns (HIP events; synchronises) */
   AHMC_INFO_NUTS_WARM_LAUNCHES = 6,  /* the same two for the warm-up instantiation of the kernel (adapt! inside)  */
-  AHMC_INFO_NUTS_WARM_KERNEL_NS = 7
+  AHMC_INFO_NUTS_WARM_KERNEL_NS = 7,
+  AHMC_INFO_DENSE_GEMM_LAUNCHES = 8,        /* step-synchronous engine: launches of the 64×64-tile MFMA GEMM since ahmc_create   */
+  AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES = 9,  /* … of the 64×16-tile GEMM (few columns: the tails of the batches)              */
+  AHMC_INFO_DENSE_PIPELINES = 10,           /* chain pipelines (streams) of the last dense NUTS batch: 1 or 2                 */
+  AHMC_INFO_DENSE_POOL = 11                 /* 1: the last dense NUTS batch ran on the point pool (k_d_tree2), 0: the copying kernel */
 } ahmc_info;
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out);
 

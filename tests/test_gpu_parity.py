@@ -418,6 +418,36 @@ def test_dense_bulk_sample_and_stepsize_adaptation(hip, rng):
     np.testing.assert_allclose(var, np.diag(cov), rtol=0.08)
 
 
+@pytest.mark.parametrize("target", ["dense", "funnel"])
+def test_dense_fused_stepsize_warmup_equals_stepwise(hip, rng, target):
+    """dense engine, StepSizeAdaptor: the warm-up in BATCHES (every chain adapts its own ϵ at the end of each of its transitions
+    inside the point-pool tree kernel, no per-transition barrier) == transition + adapt! once per iteration, bit for bit —
+    for the dense target (pool addressed by the GEMM) and for a built-in family behind the dense metric (staged pool)"""
+    D, N = 20, 700
+    h = _dense_hamiltonian(D, N, rng, "dense", target)
+    lf = A.Leapfrog(np.full(N, 0.12))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=7)))
+    th0 = 0.5 * rng.normal(size=(D, N))
+    n_adapts, n_total = 14, 18
+    a = A.Engine(h, N, rng=5, lib=hip); a.set_integrator(lf); a.set_position(th0); a.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+    b = A.Engine(h, N, rng=5, lib=hip); b.set_integrator(lf); b.set_position(th0); b.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+    a.run(k, n_total, n_adapts)                      # two launches: 14 adapting transitions in one batch, 4 draws in one
+    assert a.info("dense_pool") == 1
+    for i in range(1, n_total + 1):
+        b.transition(k)
+        b.adapt(i, n_adapts)
+    za, zb = a.phasepoint(), b.phasepoint()
+    np.testing.assert_array_equal(za.theta, zb.theta)
+    np.testing.assert_array_equal(za.r, zb.r)
+    np.testing.assert_array_equal(a.get_stepsize(), b.get_stepsize())
+    sa, sb = a.get_state(), b.get_state()
+    np.testing.assert_array_equal(sa["da"], sb["da"])
+    assert sa["adaptor"] == sb["adaptor"]
+    np.testing.assert_array_equal(a.stats()["n_steps"], b.stats()["n_steps"])
+    assert len(np.unique(a.get_stepsize())) > N // 2   # every chain has its own adapted step size
+    a.close(); b.close()
+
+
 def test_dense_two_pipelines_equal_one(hip, rng, monkeypatch):
     """the dense NUTS loop cut into two chain halves — a stream per half (AHMC_DENSE_SPLIT=1, the default) or a stream per
     kernel kind with event hand-over (=2) — must give exactly the chains of the single pipeline (=0): chains are
@@ -428,8 +458,9 @@ def test_dense_two_pipelines_equal_one(hip, rng, monkeypatch):
     k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=7)))
     th0 = 0.5 * rng.normal(size=(D, N))
     res = []
-    for split in ("0", "1", "2"):
-        monkeypatch.setenv("AHMC_DENSE_SPLIT", split)
+    for split in ("0", "1", "2", "1nopool"):
+        monkeypatch.setenv("AHMC_DENSE_SPLIT", split[0])
+        monkeypatch.setenv("AHMC_DENSE_POOL", "0" if split.endswith("nopool") else "1")  # (the point-pool kernel == the copying kernel, bit for bit)
         e = A.Engine(h, N, rng=31, lib=hip)
         e.set_integrator(lf)
         e.set_position(th0)
@@ -999,6 +1030,8 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric):
             np.testing.assert_allclose(eg[sl][same], o.get_stepsize()[same], rtol=1e-9, err_msg=f"ϵ after adapt! {i}")
             depth_seen = max(depth_seen, int(st_o["tree_depth"].max()))
     assert depth_seen >= 5, depth_seen   # trees of 32+ leaves: merges on several pending levels, compaction of finished chains
+    # what ran: the 64×64-tile GEMM, two pipelines, the point-pool tree kernel
+    assert g.info("dense_gemm_launches") > 0 and g.info("dense_pipelines") == 2 and g.info("dense_pool") == 1
     g.close()
     for o in os_:
         o.close()
