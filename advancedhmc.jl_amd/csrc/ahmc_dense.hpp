@@ -59,12 +59,13 @@ constexpr int GB_P = AHMC_GB_P;
 // NUTS batch, when few chains are still running) still covers the ≈1-2 µs load latency with
 // P·16 MFMAs ≈ 1.7 µs of matrix work.  One barrier per tile.
 // Point pool (k_d_tree2): a column's vector may live in the chain's pool point ptidx[col] instead of a fixed (D,N) array — then
-// its address is base + ptidx[col]·xps (X) / ·yps (Y, Y2) + col·D.  xps / yps = 0: the plain (D,N) array.
+// its address is base + col·xcs + ptidx[col]·xps (X) / col·ycs + ptidx[col]·yps (Y, Y2): the pool is chain-major, a chain's points
+// are contiguous.  Without ptidx (or with xps / yps = 0 and xcs / ycs = D): the plain (D,N) array.
 template <class T>
 __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N,
                                                const int* __restrict__ idx,  // idx: optional list of the N columns (chains) to process
                                                const T* __restrict__ A2, T* __restrict__ Y2,  // optional second product Y2 = A2·X in the same launch
-                                               const int* __restrict__ ptidx, int64_t xps, int64_t yps) {
+                                               const int* __restrict__ ptidx, int64_t xps, int64_t yps, int64_t xcs, int64_t ycs) {
   __shared__ T As[2][GB_K][GB_M + GB_PAD];
   __shared__ T Bs[2][GB_K][GB_N + GB_PAD];
   using M = Mfma<T>;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
   const int64_t bcol = n0 + bn < N ? (idx ? (int64_t)idx[n0 + bn] : n0 + bn) : -1;
   const bool arow0 = m0 + ai < D, arow1 = m0 + ai + 1 < D;
   const T* Ap = A + (m0 + ai);
-  const T* Xp = X + (bcol >= 0 ? bcol : 0) * (int64_t)D + ((ptidx && bcol >= 0) ? (int64_t)ptidx[bcol] * xps : 0);
+  const T* Xp = X + (bcol >= 0 ? bcol : 0) * xcs + ((ptidx && bcol >= 0) ? (int64_t)ptidx[bcol] * xps : 0);
   auto load_tile = [&](int k0, T (&a)[4], T (&b)[4]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
     for (int tj = 0; tj < 2; ++tj) {
       const int64_t j = n0 + wn + tj * 16 + (lane & 15);
       const int64_t col = j < N ? (idx ? (int64_t)idx[j] : j) : -1;
-      const int64_t yoff = col >= 0 ? col * D + (ptidx ? (int64_t)ptidx[col] * yps : 0) : 0;
+      const int64_t yoff = col >= 0 ? col * ycs + (ptidx ? (int64_t)ptidx[col] * yps : 0) : 0;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = m0 + wm + ti * 16 + M::row(lane, v);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void k_dgemm(const T* __restrict__ A, const T*
 template <class T>
 __global__ __launch_bounds__(256) void k_dgemm_small(const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y, int D, int64_t N,
                                                      const int* __restrict__ idx, const T* __restrict__ A2, T* __restrict__ Y2,
-                                                     const int* __restrict__ ptidx, int64_t xps, int64_t yps) {
+                                                     const int* __restrict__ ptidx, int64_t xps, int64_t yps, int64_t xcs, int64_t ycs) {
   constexpr int BN = 16;
   __shared__ T As[2][GB_K][GB_M + GB_PAD];
   __shared__ T Bs[2][GB_K][BN + 4];
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void k_dgemm_small(const T* __restrict__ A, co
   const int64_t bcol = n0 + bn < N ? (idx ? (int64_t)idx[n0 + bn] : n0 + bn) : -1;
   const bool arow0 = m0 + ai < D, arow1 = m0 + ai + 1 < D;
   const T* Ap = A + (m0 + ai);
-  const T* Xp = X + (bcol >= 0 ? bcol : 0) * (int64_t)D + ((ptidx && bcol >= 0) ? (int64_t)ptidx[bcol] * xps : 0);
+  const T* Xp = X + (bcol >= 0 ? bcol : 0) * xcs + ((ptidx && bcol >= 0) ? (int64_t)ptidx[bcol] * xps : 0);
   auto load_tile = [&](int k0, T (&a)[4], T& b) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void k_dgemm_small(const T* __restrict__ A, co
   }
   const int64_t j = n0 + (lane & 15);
   const int64_t col = j < N ? (idx ? (int64_t)idx[j] : j) : -1;
-  const int64_t yoff = col >= 0 ? col * D + (ptidx ? (int64_t)ptidx[col] * yps : 0) : 0;
+  const int64_t yoff = col >= 0 ? col * ycs + (ptidx ? (int64_t)ptidx[col] * yps : 0) : 0;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int row = m0 + w * 16 + M::row(lane, v);
@@ -420,7 +421,8 @@ constexpr int DT_THREADS = 256;
 inline int dt_threads_for(int64_t D) {
   static const int ov = getenv("AHMC_DENSE_DT") ? atoi(getenv("AHMC_DENSE_DT")) : 0;  // experiments: 64 / 128 / 256 threads per chain
   if (ov == 64 || ov == 128 || ov == 256) return ov;
-  return D <= 128 ? 64 : (D <= 256 ? 128 : DT_THREADS);
+  // round 3, cfg4 (D = 512, two pipelines, point-pool kernel), whole loop: 256 threads 2.54e7, 128 threads 2.67e7, 64 threads 2.55e7
+  return D <= 128 ? 64 : (D <= 512 ? 128 : DT_THREADS);
 }
 // all-reduce of a pair over the DT_THREADS threads of the workgroup (every decision of d_tree_advance is taken on
 // such sums or on per-chain scalars, so all threads follow the same control flow and reach the barriers together)
@@ -1022,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_d_tree_reset(DChain<T>* S, T* es, int* 
 // per chain-step where the two half-steps need 8, and at cfg4 that kernel was as long as the GEMM it alternates with
 // (profiles/r2_cfg4_top_kernels.txt: 40 % of device time).
 //
-// Here a phase point is an immutable record in a per-chain pool, P[pt][θ r g v w][N][D], and everything the tree remembers
+// Here a phase point is an immutable record in a per-chain pool, P[chain][pt][θ r g v w][D], and everything the tree remembers
 // is an INDEX: the other edge, the tree-level candidate, per pending level the first-built leaf (→ its v for the U-turn test
 // and, at level 0, its r = the one-leaf subtree's ρ) and the level's candidate.  The first half-step of a leapfrog reads its
 // start point and writes a FRESH point (θ′, r½, v½) — no more traffic than updating in place —, the GEMM reads θ′ and
@@ -1052,17 +1054,27 @@ struct DChain2 {
   int8_t cur, oth, cand, pad_;                   // the leaf in flight (moving edge), the other edge, the tree-level candidate
 };
 
+// the scalars of a chain every call needs: read at the top of k_d_tree2, together with the energies and the step, so that the
+// tree bookkeeping does not start with a memory round trip of its own after the second half-step's reduction
+template <class T>
+struct DHot {
+  T H0, eps, lu;
+  int32_t phase, it, jw, leaf, v, cur_is_left, numerical;
+  uint32_t k;
+  int cur, oth, cand;
+};
+
 template <class T>
 struct DP2 {
-  T* P;             // point pool  [n_pt][PV_COUNT][N][D]
-  T* R;             // ρ vectors   [PR_LEVEL0 + n_lev][N][D]
+  T* P;             // point pool  [N][n_pt][PV_COUNT][D]   (chain-major: a chain's points are one contiguous region — with the
+  T* R;             // ρ vectors   [N][n_rho][D]             point-major layout every chain touched pages all over the pool)
   DChain2<T>* S;
   int* ptcur;       // (N,) pool point of the leapfrog in flight: what the GEMM reads θ′ from and writes g′, w′ to
   T* es;
   const T* RB;
   const T* VB;
   int n_trans;
-  int n_pt;
+  int n_pt, n_rho;
   int* n_active;
   const int* list;
   int64_t n_list;
@@ -1080,11 +1092,11 @@ struct DP2 {
 
 template <class T>
 __device__ __forceinline__ T* ppt(const DP2<T>& q, const KP<T>& p, int pt, int vec, int64_t c) {
-  return q.P + (((int64_t)pt * PV_COUNT + vec) * p.N + c) * p.D;
+  return q.P + ((c * q.n_pt + pt) * PV_COUNT + vec) * p.D;
 }
 template <class T>
 __device__ __forceinline__ T* prho(const DP2<T>& q, const KP<T>& p, int slot, int64_t c) {
-  return q.R + ((int64_t)slot * p.N + c) * p.D;
+  return q.R + (c * q.n_rho + slot) * p.D;
 }
 
 template <class T>
@@ -1112,7 +1124,9 @@ __global__ __launch_bounds__(256) void k_d_tree2_reset(DChain2<T>* S, T* es, int
 // signed step of the chain's next leapfrog (0 = idle, or the motionless warm-up step) and, in `src`, the pool point that
 // leapfrog starts from; `used` = bit mask of the points that must survive it.
 template <class T, int DT>
-__device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, int64_t c, int lane, T lp_in, T lk_in, int& src, uint64_t& used) {
+__device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, int64_t c, int lane, T lp_in, T lk_in, const DHot<T>& hot, int& src,
+                                             uint64_t& used, bool& rewritten /* the point `src` was given a fresh momentum in this call */) {
+  rewritten = false;
   DChain2<T>& S = q.S[c];
   const int D = p.D;
   const bool slice = p.sampler == 2;
@@ -1123,11 +1137,11 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
     ds.resume(rng, k);
   };
   auto bit = [](int pt) { return (uint64_t)1 << pt; };
-  int phase = S.phase, it = S.it;
-  const int cur = S.cur;
+  int phase = hot.phase, it = hot.it;
+  const int cur = hot.cur;
   if (phase == DPH_WARM) {
     // the motionless step has produced w = M⁻¹g at the start point of the batch's first transition: let the first leapfrog go
-    const T e_first = S.v < 0 ? -S.eps : S.eps;
+    const T e_first = hot.v < 0 ? -hot.eps : hot.eps;
     __syncthreads();  // (every thread has read the phase before thread 0 changes it)
     if (lane == 0) S.phase = DPH_RUN;
     src = cur;
@@ -1138,13 +1152,13 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
   T lp_start = lp_in;
   int start_pt = cur;
   if (!start) {
-    resume_draws((uint32_t)it, S.k);
-    const T H0 = S.H0, eps = S.eps;
-    const int v = S.v, jw = S.jw;
-    const int leaf = S.leaf;
+    resume_draws((uint32_t)it, hot.k);
+    const T H0 = hot.H0, eps = hot.eps;
+    const int v = hot.v, jw = hot.jw;
+    const int leaf = hot.leaf;
     const uint32_t nleaf = 1u << jw;
-    const int oth = S.oth;
-    int cand_tree = S.cand;
+    const int oth = hot.oth;
+    int cand_tree = hot.cand;
     const T lp = lp_in, lk = lk_in;
     // ---- leaf (:638-647) ----
     const T ne = lp + lk;
@@ -1153,15 +1167,14 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
     int na_c = 1;
     bool sub_term;
     if (slice) {
-      w_c = (S.lu <= ne) ? T(1) : T(0);
-      sub_term = !(S.lu < p.delta_max + ne);
+      w_c = (hot.lu <= ne) ? T(1) : T(0);
+      sub_term = !(hot.lu < p.delta_max + ne);
     } else {
       w_c = H0 + ne;
       sub_term = !(-H0 < p.delta_max + ne);
     }
-    bool numerical = S.numerical != 0 || sub_term;
-    const int cur_is_left_in = S.cur_is_left;
-    __syncthreads();  // every thread has read the chain's scalars: from here on thread 0 may update them
+    bool numerical = hot.numerical != 0 || sub_term;
+    const int cur_is_left_in = hot.cur_is_left;
     // the subtree being assembled: its first-built leaf, its candidate (pool points) and its ρ (a view: the leaf's own r
     // until the first merge, then a ρ vector)
     const T* Vc = ppt(q, p, cur, PV_V, c);
@@ -1436,14 +1449,19 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
     }
     src = start_pt;
     used = bit(start_pt);
+    rewritten = true;
     return warm ? T(0) : (vleft ? -eps : eps);
   }
 }
 
 // One global step for every listed chain: second half of the leapfrog in flight (completing its pool point) → d_tree_advance2
 // → first half of the next leapfrog INTO A FRESH POINT.  One chain per workgroup of DT threads.
+// The kernel is a chain of dependent memory round trips (scalars → the point's vectors → [merge operands] → stores); the
+// values of the completed point stay in registers (NE elements per thread) for the first half-step that usually follows from
+// the same point, so that half-step does not read them again.
 template <class T, int DT>
 __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
+  constexpr int NE = 4;  // elements of a vector a thread keeps in registers (D <= NE·DT: every default thread count)
   const int lane = threadIdx.x;
   const int64_t j = blockIdx.x;
   if (j >= q.n_list) return;
@@ -1452,7 +1470,14 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
   if (S.phase == DPH_IDLE) return;
   const int D = p.D;
   T lp = p.lp()[c], lk = p.lk()[c];
-  const int cur = S.cur;
+  DHot<T> hot;
+  hot.H0 = S.H0; hot.eps = S.eps; hot.lu = S.lu;
+  hot.phase = S.phase; hot.it = S.it; hot.jw = S.jw; hot.leaf = S.leaf; hot.v = S.v; hot.cur_is_left = S.cur_is_left; hot.numerical = S.numerical;
+  hot.k = S.k;
+  hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand;
+  const int cur = hot.cur;
+  const bool in_regs = do_post && D <= NE * DT;
+  T k_th[NE], k_r[NE], k_g[NE], k_v[NE], k_w[NE];
   if (do_post) {
     T* TH = ppt(q, p, cur, PV_TH, c);
     T* R = ppt(q, p, cur, PV_R, c);
@@ -1462,16 +1487,27 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
     const T* g_in = q.staged ? p.g() + c * D : G;  // staged: the target kernel left g′ in the context's array
     const T e = q.es[c];
     T s[2] = {0, 0};
-    for (int d = lane; d < D; d += DT) {
-      const T gd = g_in[d];
+    auto second_half = [&](int d, T& o_th, T& o_r, T& o_g, T& o_v, T& o_w) {
+      const T gd = g_in[d], td = TH[d], wd = W ? W[d] : T(0);
       T rn = R[d], vn;
       if (e != T(0)) rn = rn - e / 2 * gd;
-      if (W) vn = e != T(0) ? V[d] - e / 2 * W[d] : V[d];
+      if (W) vn = e != T(0) ? V[d] - e / 2 * wd : V[d];
       else vn = minv ? minv[per_chain ? c * D + d : d] * rn : rn;
       if (e != T(0) || !W) { R[d] = rn; V[d] = vn; }
       if (q.staged) G[d] = gd;
       s[0] += rn * vn;
-      s[1] += TH[d] * gd;
+      s[1] += td * gd;
+      o_th = td; o_r = rn; o_g = gd; o_v = vn; o_w = wd;
+    };
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int d = lane + i * DT;
+        if (d < D) second_half(d, k_th[i], k_r[i], k_g[i], k_v[i], k_w[i]);
+      }
+    } else {
+      T t0, t1, t2, t3, t4;
+      for (int d = lane; d < D; d += DT) second_half(d, t0, t1, t2, t3, t4);
     }
     block_allsum2<DT>(s[0], s[1]);
     lk = sanitize(-s[0] / 2);
@@ -1483,29 +1519,40 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
   }
   int src = cur;
   uint64_t used = 0;
-  const T e = d_tree_advance2<T, DT>(p, q, c, lane, lp, lk, src, used);
+  bool rewritten = false;
+  __syncthreads();  // (every thread holds the chain's scalars: from here on thread 0 may update them)
+  const T e = d_tree_advance2<T, DT>(p, q, c, lane, lp, lk, hot, src, used, rewritten);
   if (lane == 0) q.es[c] = e;
   if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237): src → a fresh point
     const int dst = __builtin_ctzll(~used);
-    const T* sTH = ppt(q, p, src, PV_TH, c);
-    const T* sR = ppt(q, p, src, PV_R, c);
-    const T* sG = ppt(q, p, src, PV_G, c);
-    const T* sV = ppt(q, p, src, PV_V, c);
-    const T* sW = q.dense_metric ? ppt(q, p, src, PV_W, c) : nullptr;
     T* dTH = ppt(q, p, dst, PV_TH, c);
     T* dR = ppt(q, p, dst, PV_R, c);
     T* dV = ppt(q, p, dst, PV_V, c);
     T* th_st = q.staged ? p.th() + c * D : nullptr;
-    for (int d = lane; d < D; d += DT) {
-      const T rh = sR[d] - e / 2 * sG[d];
-      const T vh = sW ? sV[d] - e / 2 * sW[d] : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
-      const T tn = sTH[d] + e * vh;
+    const bool dm = q.dense_metric != 0;
+    auto first_half = [&](int d, T td, T rd, T gd, T vd, T wd) {
+      const T rh = rd - e / 2 * gd;
+      const T vh = dm ? vd - e / 2 * wd : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
+      const T tn = td + e * vh;
       dR[d] = rh;
       dV[d] = vh;
       dTH[d] = tn;
       if (th_st) th_st[d] = tn;
+    };
+    if (in_regs && src == cur && !rewritten) {  // the usual case inside a subtree: the point just completed, still in registers
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int d = lane + i * DT;
+        if (d < D) first_half(d, k_th[i], k_r[i], k_g[i], k_v[i], k_w[i]);
+      }
+    } else {
+      const T* sTH = ppt(q, p, src, PV_TH, c);
+      const T* sR = ppt(q, p, src, PV_R, c);
+      const T* sG = ppt(q, p, src, PV_G, c);
+      const T* sV = ppt(q, p, src, PV_V, c);
+      const T* sW = dm ? ppt(q, p, src, PV_W, c) : nullptr;
+      for (int d = lane; d < D; d += DT) first_half(d, sTH[d], sR[d], sG[d], sV[d], sW ? sW[d] : T(0));
     }
-    __syncthreads();  // (every thread has read S.cur)
     if (lane == 0) {
       S.cur = (int8_t)dst;
       q.ptcur[c] = dst;

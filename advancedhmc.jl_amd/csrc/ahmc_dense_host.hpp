@@ -49,7 +49,9 @@ int dn_other_target(Ctx<T>* c, const int* list, int64_t n) {
 
 template <class T>
 int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* list = nullptr, const T* A2 = nullptr, T* Y2 = nullptr,
-            const int* ptidx = nullptr, int64_t xps = 0, int64_t yps = 0) {  // ptidx / xps / yps: operands in the chains' pool points (k_dgemm)
+            const int* ptidx = nullptr, int64_t xps = 0, int64_t yps = 0, int64_t xcs = 0, int64_t ycs = 0) {  // operands in the chains' pool points (k_dgemm)
+  if (xcs == 0) xcs = c->D;  // (column stride of a plain (D,N) array)
+  if (ycs == 0) ycs = c->D;
   if (ncols <= 0) return AHMC_OK;
   // few columns: the 64×16-tile kernel puts 4× as many workgroups on the chip (same arithmetic per column,
   // so results do not depend on which kernel ran).  A2 / Y2: a second product on the same X in the same launch.
@@ -57,14 +59,14 @@ int dn_gemm(Ctx<T>* c, const T* A, const T* X, T* Y, int64_t ncols, const int* l
   static const int64_t small_below = getenv("AHMC_GEMM_SMALL_BELOW") ? atoll(getenv("AHMC_GEMM_SMALL_BELOW")) : 1;  // measured D=512: N=512 22 vs 38 µs, N=2048 38 vs 40, N=4096 67 vs 59
   if (row_blocks * ((ncols + GB_N - 1) / GB_N) < small_below * c->n_cu) {
     dim3 grid((unsigned)row_blocks, (unsigned)((ncols + 15) / 16));
-    hipLaunchKernelGGL((k_dgemm_small<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2, ptidx, xps, yps);
+    hipLaunchKernelGGL((k_dgemm_small<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2, ptidx, xps, yps, xcs, ycs);
     HIPCHK(hipGetLastError());
     c->dn_gemm_small += 1;
     return AHMC_OK;
   }
   const int64_t cb8 = ((ncols + GB_N - 1) / GB_N + 7) / 8 * 8;  // column blocks padded to the 8 XCDs (see k_dgemm)
   dim3 grid((unsigned)(row_blocks * cb8));
-  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2, ptidx, xps, yps);
+  hipLaunchKernelGGL((k_dgemm<T>), grid, dim3(256), 0, c->stream, A, X, Y, (int)c->D, ncols, list, A2, Y2, ptidx, xps, yps, xcs, ycs);
   HIPCHK(hipGetLastError());
   c->dn_gemm_big += 1;
   return AHMC_OK;
@@ -535,7 +537,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   c->dn_last_pool = pool ? 1 : 0;
   DP2<T> q2;
   memset(&q2, 0, sizeof(q2));
-  const int64_t PS = (int64_t)PV_COUNT * c->N * c->D;  // pool stride between the points of a chain
+  const int64_t PS = (int64_t)PV_COUNT * c->D;  // pool stride between the points of a chain; between chains: CS (set below)
+  int64_t CS = 0;
   T *Pth = nullptr, *Pg = nullptr, *Pw = nullptr;
   const int dtt = dt_threads_for(c->D);
   auto launch_tree2 = [&](unsigned grid, int do_post) {
@@ -547,7 +550,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     rc = dn_ensure_pool(c, max_depth);
     if (rc) return rc;
     q2.P = c->dn_P; q2.R = c->dn_R; q2.S = c->dn_S2; q2.ptcur = c->dn_ptcur; q2.es = c->dn_es; q2.RB = c->dn_RB; q2.VB = c->dn_VB;
-    q2.n_trans = n_trans; q2.n_pt = c->dn_npt; q2.n_active = c->dn_active; q2.list = nullptr; q2.n_list = c->N;
+    q2.n_trans = n_trans; q2.n_pt = c->dn_npt; q2.n_rho = c->dn_nrho; q2.n_active = c->dn_active; q2.list = nullptr; q2.n_list = c->N;
+    CS = (int64_t)c->dn_npt * PS;
     q2.dense_metric = dm ? 1 : 0;
     q2.staged = dt ? 0 : 1;
     if (adapt_i0 >= 0) {
@@ -557,9 +561,9 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
       q2.delta = (T)c->da_delta; q2.gamma = T(0.05); q2.t0 = T(10); q2.kappa = T(0.75);  // stepsize.jl:168-172
       q2.da_m = c->da_m; q2.da_eps = c->da_eps; q2.da_mu = c->da_mu; q2.da_xbar = c->da_xbar; q2.da_Hbar = c->da_Hbar;
     }
-    Pth = c->dn_P + (size_t)PV_TH * c->N * c->D;
-    Pg = c->dn_P + (size_t)PV_G * c->N * c->D;
-    Pw = c->dn_P + (size_t)PV_W * c->N * c->D;
+    Pth = c->dn_P + (size_t)PV_TH * c->D;
+    Pg = c->dn_P + (size_t)PV_G * c->D;
+    Pw = c->dn_P + (size_t)PV_W * c->D;
     hipLaunchKernelGGL((k_d_tree2_reset<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->dn_S2, c->dn_es, c->dn_ptcur, c->dn_active, c->N);
     launch_tree2((unsigned)c->N, 0);  // start of transition 0 (and, for Unit/Diag metrics, the first half of its first leapfrog)
   } else {
@@ -644,25 +648,25 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
         const T* gX = pool ? Pth : c->th;   // θ′ of the leapfrogs in flight
         T* gY = pool ? Pg : c->g;           // g′
         T* gW = pool ? Pw : Wcur;           // w′
-        const int64_t ps = pool ? PS : 0;
+        const int64_t ps = pool ? PS : 0, cs = pool ? CS : 0;
         if (by_kind) {
           c->stream = main_stream;
           if (tree_recorded[k] && hipStreamWaitEvent(main_stream, c->ev_tree[k], 0) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipStreamWaitEvent failed"));
-          rc = dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, c->dn_C, gW, pti, ps, ps);
+          rc = dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, c->dn_C, gW, pti, ps, ps, cs, cs);
           if (rc) return bail(rc);
           if (hipEventRecord(c->ev_gemm[k], main_stream) != hipSuccess || hipStreamWaitEvent(h.s, c->ev_gemm[k], 0) != hipSuccess)
             return bail(fail(c, AHMC_ERR_RUNTIME, "hipEventRecord / hipStreamWaitEvent failed"));
           c->stream = h.s;
         } else if (dt && dm && c->dn_fused_ok) {
-          rc = dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, c->dn_C, gW, pti, ps, ps);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
+          rc = dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, c->dn_C, gW, pti, ps, ps, cs, cs);  // g′ = Pθ′ and w′ = (M⁻¹P)θ′, one launch
           if (rc) return bail(rc);
         } else {
           // (a target that is not the dense Gaussian reads θ′ from / leaves g′ in the context's arrays: the pool is "staged")
-          rc = dt ? dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps) : dn_other_target(c, h.list, h.n_list);
+          rc = dt ? dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps, cs, cs) : dn_other_target(c, h.list, h.n_list);
           if (rc) return bail(rc);
           if (dm) {
-            rc = dt ? dn_gemm(c, c->dn_minv, (const T*)gY, gW, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps)
-                    : dn_gemm(c, c->dn_minv, (const T*)c->g, gW, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, (int64_t)0, ps);
+            rc = dt ? dn_gemm(c, c->dn_minv, (const T*)gY, gW, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps, cs, cs)
+                    : dn_gemm(c, c->dn_minv, (const T*)c->g, gW, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, (int64_t)0, ps, (int64_t)0, cs);
             if (rc) return bail(rc);
           }
         }

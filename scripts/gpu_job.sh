@@ -1,14 +1,12 @@
-O=gpurun_out/r3i; mkdir -p $O; export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_zz_external_target_gpu.py tests/test_v3_state_gather.py -m gpu -q -x -k "dense or cfg4 or Dense or state" 2>&1 | tail -40 ) > $O/pytest_dense.log
-tail -5 $O/pytest_dense.log
-for steps in 6 20; do
-  timeout 900 python bench.py --config cfg4 --steps $steps --warmup 0 --repeats 1 --no-cpu-baseline > $O/cfg4_s$steps.json 2> $O/cfg4_s$steps.err
-  python - $O/cfg4_s$steps.json <<'PY'
-import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d["config"]
-    print(sys.argv[1], "e2e %.3e  warm %.3e  draw %.3e  TF %.1f  lf/tr %.0f/%.0f" % (d["value"], c["warmup_phase"]["value"], c["post_adaptation"]["value"], d["roofline"]["achieved"], c["warmup_phase"]["mean_leapfrogs_per_transition"], c["post_adaptation"]["mean_leapfrogs_per_transition"]))
-except Exception as e: print(sys.argv[1], "FAILED", e)
+O=gpurun_out/r3m; mkdir -p $O; export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+ADAPT=10 DRAWS=10 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python scripts/user_target_bench.py kernel > $O/kt.log 2>&1
+python - <<'PY'
+import glob, sqlite3
+f=glob.glob("gpurun_out/r3m/kt/**/*_results.db", recursive=True)
+cur=sqlite3.connect(f[0]).cursor()
+for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 12"):
+    print("%10.1f ms %7d calls %9.1f us %5.1f%%  %s" % (r[2]/1e6, r[1], r[3]/1e3, r[4], r[0][:100]))
 PY
-done
-tail -3 $O/cfg4_s6.err
+tail -3 $O/kt.log
+find $O -name "*.db" -size +8M -delete

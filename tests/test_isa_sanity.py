@@ -24,7 +24,7 @@ def test_build_runs_the_scan_and_fails_on_a_finding(monkeypatch, tmp_path):
     from ahmc_amd import build as B
 
     src = open(B.__file__).read()
-    assert "isa_check.check_object(obj, name)" in src and "raise RuntimeError" in src
+    assert "isa_check.analyse_object(obj, name)" in src and "raise RuntimeError" in src
     assert not os.path.realpath(B.OBJ).startswith(os.path.realpath(ROOT) + os.sep), "object cache must live outside the repository"
     assert A.build_hip_library() and os.path.exists(B.OUT)
 
