@@ -189,6 +189,8 @@ struct Ctx : CtxBase {
   size_t dn_slots = 0, dn_batch_elems = 0;
   int64_t dn_global_steps = 0, dn_chain_steps = 0;
   hipStream_t stream2 = nullptr;  // second pipeline of the dense NUTS loop (dn_nuts_transition)
+  hipStream_t stream_x[2] = {nullptr, nullptr};  // third / fourth pipeline (AHMC_DENSE_PIPES)
+  hipEvent_t ev_join_x[2] = {nullptr, nullptr};
   hipEvent_t ev_split = nullptr, ev_join = nullptr;
   hipEvent_t ev_gemm[2] = {nullptr, nullptr}, ev_tree[2] = {nullptr, nullptr};  // AHMC_DENSE_SPLIT=2: GEMM stream <-> tree stream hand-over per chain half
   // WelfordCov of the shared dense metric: μ (D) [+ batch mean + column-sum partials], M, batch scatter, estimate
@@ -215,6 +217,10 @@ struct Ctx : CtxBase {
     if (red) (void)hipFree(red);
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    for (int k = 0; k < 2; ++k) {
+      if (stream_x[k]) { (void)hipStreamSynchronize(stream_x[k]); (void)hipStreamDestroy(stream_x[k]); }
+      if (ev_join_x[k]) (void)hipEventDestroy(ev_join_x[k]);
+    }
     for (hipEvent_t e : {ev_split, ev_join, ev_gemm[0], ev_gemm[1], ev_tree[0], ev_tree[1]})
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {stage_ready[0], stage_ready[1], stage_free[0], stage_free[1]})

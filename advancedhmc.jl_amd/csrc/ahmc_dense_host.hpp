@@ -119,7 +119,7 @@ int dn_ensure(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
     HIPCHK(hipMemsetAsync(c->dn_S, 0, (size_t)c->N * sizeof(DChain<T>), c->stream));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_es), (size_t)c->N * sizeof(T)));
     HIPCHK(hipMemsetAsync(c->dn_es, 0, (size_t)c->N * sizeof(T), c->stream));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), 4 * sizeof(int)));                   // [0] batch counter, [1..2] compaction counts
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_active), 8 * sizeof(int)));                   // [0] batch counter, [1..4] compaction counts of the pipelines
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_list), 4 * (size_t)c->N * sizeof(int)));       // two ping-pong lists per pipeline
   }
   return AHMC_OK;
@@ -593,15 +593,24 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   const int CHUNK = 16;
   const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
   const int split_env = getenv("AHMC_DENSE_SPLIT") ? atoi(getenv("AHMC_DENSE_SPLIT")) : 1;  // (read per call: the tests toggle it)
-  const int NP = (split_env != 0 && dt && c->N >= 2048) ? 2 : 1;
+  // AHMC_DENSE_PIPES=3|4 (with AHMC_DENSE_SPLIT=1): more, smaller pipelines — more chances for one pipeline's memory-bound tree
+  // kernel to run beside another's GEMM, smaller GEMM launches
+  const int pipes_env = getenv("AHMC_DENSE_PIPES") ? atoi(getenv("AHMC_DENSE_PIPES")) : 2;
+  const int NP = (split_env != 0 && dt && c->N >= 2048) ? ((split_env == 1 && pipes_env >= 2 && pipes_env <= 4 && c->N >= 512 * pipes_env) ? pipes_env : 2) : 1;
   c->dn_last_pipelines = NP;
   struct Pipe { hipStream_t s; const int* list; int64_t n_list; int pp; int* lists; int* cnt; int active; };
-  Pipe pipes[2];
-  if (NP == 2 && !c->stream2) {
+  Pipe pipes[4];
+  const int64_t per = (c->N + NP - 1) / NP;  // capacity of one running-chain list of a pipeline (two per pipeline: 2·NP·per <= 4·N ints)
+  if (NP >= 2 && !c->stream2) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_split, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
+  for (int k = 2; k < NP; ++k)
+    if (!c->stream_x[k - 2]) {
+      HIPCHK(hipStreamCreateWithFlags(&c->stream_x[k - 2], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->ev_join_x[k - 2], hipEventDisableTiming));
+    }
   const bool by_kind = NP == 2 && split_env == 2 && dm && c->dn_fused_ok;  // (one GEMM launch per half and step)
   if (by_kind && !c->ev_gemm[0]) {
     for (int k = 0; k < 2; ++k) {
@@ -611,28 +620,34 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   }
   for (int k = 0; k < NP; ++k) {
     Pipe& h = pipes[k];
-    h.s = (k == 0 && !by_kind) ? c->stream : c->stream2;  // (by kind: the stream of the half's tree kernel, compaction and read-back)
-    h.lists = c->dn_list + (size_t)k * 2 * c->N;
+    h.s = k >= 2 ? c->stream_x[k - 2] : ((k == 0 && !by_kind) ? c->stream : c->stream2);  // (by kind: the stream of the half's tree kernel, compaction and read-back)
+    h.lists = c->dn_list + (size_t)k * 2 * per;
     h.cnt = c->dn_active + 1 + k;
     h.pp = 0;
     h.active = 0;
     if (NP == 1) { h.list = nullptr; h.n_list = c->N; }
     else {
-      const int64_t lo = k == 0 ? 0 : c->N / 2, n = k == 0 ? c->N / 2 : c->N - c->N / 2;
-      hipLaunchKernelGGL((k_d_iota<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, h.lists + c->N, (int)lo, n);  // (second buffer: the first compaction writes the first)
-      h.list = h.lists + c->N;
+      const int64_t lo = (int64_t)k * (c->N / NP), n = k == NP - 1 ? c->N - lo : c->N / NP;
+      hipLaunchKernelGGL((k_d_iota<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, h.lists + per, (int)lo, n);  // (second buffer: the first compaction writes the first)
+      h.list = h.lists + per;
       h.n_list = n;
     }
   }
   HIPCHK(hipGetLastError());
   hipStream_t main_stream = c->stream;
-  if (NP == 2) {  // everything enqueued so far (momenta, start of transition 0, the lists) precedes the second pipeline
+  if (NP >= 2) {  // everything enqueued so far (momenta, start of transition 0, the lists) precedes the other pipelines
     HIPCHK(hipEventRecord(c->ev_split, main_stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_split, 0));
+    for (int k = 2; k < NP; ++k) HIPCHK(hipStreamWaitEvent(c->stream_x[k - 2], c->ev_split, 0));
   }
   auto bail = [&](int code) { c->stream = main_stream; return code; };
   bool tree_recorded[2] = {false, false};
-  for (int64_t done_steps = 0; done_steps < max_steps && (pipes[0].n_list > 0 || (NP == 2 && pipes[1].n_list > 0));) {
+  auto any_running = [&]() {
+    for (int k = 0; k < NP; ++k)
+      if (pipes[k].n_list > 0) return true;
+    return false;
+  };
+  for (int64_t done_steps = 0; done_steps < max_steps && any_running();) {
     for (int s = 0; s < CHUNK; ++s) {
       for (int k = 0; k < NP; ++k) {
         Pipe& h = pipes[k];
@@ -684,7 +699,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
       Pipe& h = pipes[k];
       if (h.n_list <= 0) continue;
       c->stream = h.s;
-      int* out = h.lists + (size_t)h.pp * c->N;
+      int* out = h.lists + (size_t)h.pp * (NP == 1 ? c->N : per);
       if (hipMemsetAsync(h.cnt, 0, sizeof(int), h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipMemsetAsync failed"));
       if (pool) hipLaunchKernelGGL((k_d_compact2<T>), dim3((unsigned)((h.n_list + 255) / 256)), dim3(256), 0, h.s, c->dn_S2, h.list, h.n_list, out, h.cnt);
       else hipLaunchKernelGGL((k_d_compact<T>), dim3((unsigned)((h.n_list + 255) / 256)), dim3(256), 0, h.s, c->dn_S, h.list, h.n_list, out, h.cnt);
@@ -695,15 +710,19 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
       if (h.n_list <= 0) continue;
       if (hipStreamSynchronize(h.s) != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "hipStreamSynchronize failed"));
       c->dn_chain_steps += (int64_t)CHUNK * h.n_list;
-      h.list = h.lists + (size_t)h.pp * c->N;
+      h.list = h.lists + (size_t)h.pp * (NP == 1 ? c->N : per);
       h.n_list = h.active;
       h.pp ^= 1;
     }
   }
   c->stream = main_stream;
-  if (NP == 2) {  // whatever is enqueued on the context's stream next comes after the second pipeline
+  if (NP >= 2) {  // whatever is enqueued on the context's stream next comes after the other pipelines
     HIPCHK(hipEventRecord(c->ev_join, c->stream2));
     HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join, 0));
+    for (int k = 2; k < NP; ++k) {
+      HIPCHK(hipEventRecord(c->ev_join_x[k - 2], c->stream_x[k - 2]));
+      HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join_x[k - 2], 0));
+    }
   }
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] dense NUTS batch of %d: %lld global steps so far, %lld chain-slots stepped\n", n_trans, (long long)c->dn_global_steps, (long long)c->dn_chain_steps);

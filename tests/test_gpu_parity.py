@@ -458,13 +458,16 @@ def test_dense_two_pipelines_equal_one(hip, rng, monkeypatch):
     k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=7)))
     th0 = 0.5 * rng.normal(size=(D, N))
     res = []
-    for split in ("0", "1", "2", "1nopool"):
+    for split in ("0", "1", "2", "1nopool", "1pipes3", "1pipes4"):
         monkeypatch.setenv("AHMC_DENSE_SPLIT", split[0])
         monkeypatch.setenv("AHMC_DENSE_POOL", "0" if split.endswith("nopool") else "1")  # (the point-pool kernel == the copying kernel, bit for bit)
+        monkeypatch.setenv("AHMC_DENSE_PIPES", split[-1] if "pipes" in split else "2")
         e = A.Engine(h, N, rng=31, lib=hip)
         e.set_integrator(lf)
         e.set_position(th0)
         e.run(k, 5)
+        if "pipes" in split:
+            assert e.info("dense_pipelines") == int(split[-1])
         res.append((e.phasepoint(), e.stats(), e.accum()))
         e.close()
     z0, s0, a0 = res[0]
