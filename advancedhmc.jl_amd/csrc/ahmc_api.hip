@@ -662,8 +662,10 @@ int64_t nuts_batch(Ctx<T>* c) {
   // still moving, the dual averaging restarting at every window end) a few chains build 10-30x the mean tree for a
   // while: over 31 transitions they set the launch time (44 ms measured against 28 ms of work); over 125 they average
   // out.  cfg2 warm-up 1.84e9 -> 2.00e9 leapfrog/s (batch 64: 1.94e9), sampling phase +1 %.
-  const int64_t cap = (int64_t)(8ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
-  return std::max<int64_t>(1, std::min<int64_t>(128, cap));
+  // Round 3: 128 -> 256 under 16 GiB (cfg2 whole loop, two runs each: 125 per launch 2.39–2.42e9, 250 2.433e9, 500 2.445e9,
+  // 1 000 2.450e9 — but 64 GiB of normals cost a second to allocate and first-touch).
+  const int64_t cap = (int64_t)(16ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
+  return std::max<int64_t>(1, std::min<int64_t>(256, cap));
 }
 
 // nsteps(τ) for FixedIntegrationTime(λ) (src/trajectory.jl:241-243): max(1, floor(λ / nominal step size)).  Needs ONE
