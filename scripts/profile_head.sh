@@ -12,7 +12,9 @@ for CFG in "$@"; do
   rm -rf $O; mkdir -p $O
   STEPS=${PROFILE_STEPS:-20}
   # one timed run, no throw-away engine, no ESS leg: every launch of the dominant kernels belongs to the reported run
-  CMD="python bench.py --config $CFG --steps $STEPS --warmup 0 --repeats 1 --ess 0 --no-cpu-baseline"
+  # PROFILE_EXTRA: more bench arguments (e.g. "--transitions-per-step 4" for a run short enough for PMC passes over the dense
+  # engine's hundreds of dispatches per transition)
+  CMD="python bench.py --config $CFG --steps $STEPS --warmup 0 --repeats 1 --ess 0 --no-cpu-baseline ${PROFILE_EXTRA:-}"
   echo "$CMD" > $O/cmd.txt
   timeout 600 $CMD > $O/bench_plain.json 2> $O/bench_plain.err
   timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/kt.json 2> $O/kt.err
@@ -20,7 +22,7 @@ for CFG in "$@"; do
   # databases of a 4-step cfg4 run filled the box's disk)
   P=" ${PROFILE_PASSES:-fetch write sq1 sq2 sq3 grbm} "
   pmc() { name=$1; shift; case "$P" in *" $name "*) ;; *) return;; esac
-          timeout 900 rocprofv3 --pmc "$@" --kernel-trace -d $O/$name -o $name -- $CMD > $O/$name.json 2> $O/$name.err
+          timeout ${PROFILE_PASS_TIMEOUT:-900} rocprofv3 --pmc "$@" --kernel-trace -d $O/$name -o $name -- $CMD > $O/$name.json 2> $O/$name.err
           find $O/$name -name "*.csv" -size +8M -delete; }
   pmc fetch FETCH_SIZE
   pmc write WRITE_SIZE
