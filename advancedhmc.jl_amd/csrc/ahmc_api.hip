@@ -664,8 +664,11 @@ int64_t nuts_batch(Ctx<T>* c) {
   // out.  cfg2 warm-up 1.84e9 -> 2.00e9 leapfrog/s (batch 64: 1.94e9), sampling phase +1 %.
   // Round 3: 128 -> 256 under 16 GiB (cfg2 whole loop, two runs each: 125 per launch 2.39–2.42e9, 250 2.433e9, 500 2.445e9,
   // 1 000 2.450e9 — but 64 GiB of normals cost a second to allocate and first-touch).
+  // cfg3 (D = 32: 16 MiB of normals per transition; heavy-tailed funnel trees): 256 per launch 1.51e9, 512 1.63e9 — the count is
+  // bounded by the bytes only (cfg2: 256, cfg3: 1 024, cfg5: 32 — where 50 / 100 per launch measured slower: 6.44 / 6.30e7
+  // against 6.58e7, the dispatch order is re-sorted by measured work between launches).
   const int64_t cap = (int64_t)(16ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
-  return std::max<int64_t>(1, std::min<int64_t>(256, cap));
+  return std::max<int64_t>(1, std::min<int64_t>(1024, cap));
 }
 
 // nsteps(τ) for FixedIntegrationTime(λ) (src/trajectory.jl:241-243): max(1, floor(λ / nominal step size)).  Needs ONE

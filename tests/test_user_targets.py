@@ -248,8 +248,8 @@ def test_plugin_banana_against_oracle(hip, oracle, D):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,D", [("iso_gauss_f64", 128), ("banana_f64", 50)])
-def test_kernel_target_against_oracle(hip, oracle, name, D):
+@pytest.mark.parametrize("name,D,metric", [("iso_gauss_f64", 128, "diag"), ("banana_f64", 50, "diag"), ("banana_f64", 40, "dense")])
+def test_kernel_target_against_oracle(hip, oracle, name, D, metric):
     """ahmc_set_target_kernel: a hipFunction_t from a separately compiled code object; the engine launches it between its tree
     kernels (phasepoint, step, static HMC, NUTS in batches through ahmc_sample, find_good_stepsize).  Oracle: the same
     density as a host function (AHMC_KERNEL_HOST)."""
@@ -264,15 +264,21 @@ def test_kernel_target_against_oracle(hip, oracle, name, D):
     user = torch.tensor([a_, b_], dtype=torch.float64, device="cuda")
     fn = (lambda th: (-(th * th).sum(axis=0) / 2 - th.shape[0] * LOG2PI / 2, -th)) if name.startswith("iso") else banana_numpy(a_, b_)
     cb = host_kernel(fn)
-    minv = np.asfortranarray(0.5 + rs.random((D, N)))
+    if metric == "dense":  # the user's kernel behind a shared DenseEuclideanMetric: w′ = M⁻¹g′ on MFMA from the staged gradient
+        Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+        Mi = (Q * np.linspace(0.6, 2.0, D)) @ Q.T
+        make_metric = lambda: A.DenseEuclideanMetric(np.asfortranarray((Mi + Mi.T) / 2))  # noqa: E731
+    else:
+        minv = np.asfortranarray(0.5 + rs.random((D, N)))
+        make_metric = lambda: A.DiagEuclideanMetric(minv)  # noqa: E731
     th0 = 0.5 * rs.normal(size=(D, N))
     lf = A.Leapfrog(np.full(N, 0.2) * (0.7 + 0.6 * rs.random(N)))
     nuts = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=6)))
     hmc = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(4)))
     tg = A.KernelTarget(D, mod.function(name), handle_kind=capi.KERNEL_HIP_FUNCTION, block_threads=256, chains_per_block=4, user=user.data_ptr())
     to = A.KernelTarget(D, cb, handle_kind=capi.KERNEL_HOST)
-    g = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(minv), tg), N, rng=A.PhiloxRNG(8), lib=hip)
-    o = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(minv), to), N, rng=A.PhiloxRNG(8), lib=oracle)
+    g = A.Engine(A.Hamiltonian(make_metric(), tg), N, rng=A.PhiloxRNG(8), lib=hip)
+    o = A.Engine(A.Hamiltonian(make_metric(), to), N, rng=A.PhiloxRNG(8), lib=oracle)
     for e in (g, o):
         e.set_integrator(lf)
         e.set_position(th0)
