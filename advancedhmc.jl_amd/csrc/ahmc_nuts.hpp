@@ -23,6 +23,9 @@
 // start at the end (vector work only, no reductions, no RNG), which halves the pending state and
 // removes every candidate copy from the merge path.
 #pragma once
+#ifndef AHMC_PREFETCH_SWAP
+#define AHMC_PREFETCH_SWAP 0   // experiment: request the other edge's θ and g (global scratch) before the U-turn reduction of a doubling's top
+#endif
 #ifndef AHMC_SCALAR_ANY
 #define AHMC_SCALAR_ANY 1      // loop-control predicates of a wave-owning chain are tested directly instead of through a ballot (0: ballot)
 #endif
@@ -234,7 +237,31 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   sl.glb = p.scratch + wave_slot * (int64_t)(n_slots - n_lds_slots) * SLOT_ELEMS;
   sl.n_lds = n_lds_slots;
   sl.lane_off = (unsigned)lane64 * CH;
-  const int DORM = NV * NLEV;  // first dormant slot
+  const int DORM = NV * NLEV;  // first dormant slot (logical numbering: levels first, then the dormant vectors)
+  // Physical slot order = order of use (the first n_lds_slots live in LDS, the rest in global scratch).  Round 3, from the
+  // counters: a wave spends ≈ 16 000 quad-cycles per transition in s_waitcnt — ≈ 15 dependent memory round trips, six of them
+  // the loads of the whole-tree ρ and of the other edge's r from GLOBAL scratch at the top of every doubling, because the
+  // nine LDS slots went to the pending levels 0–3 and level 4.  In the fast kernels a one-leaf subtree's ρ and first-built r are
+  // the same vector (the leaf's r), so level 0 needs ONE slot, and the nine become: level 0, levels 1–3 (A, RF), whole-tree ρ,
+  // other edge's r — every slot the tree touches once per doubling or more often is in LDS.
+  //   fast kernels : L0 | L1.A L1.RF | L2.A L2.RF | L3.A L3.RF | TREE_A | OTH_R | L4.A L4.RF … | OTH_TH OTH_G Z0_R Z0_G START_R
+  //   GENERAL (run-time sampler / criterion; Classic keeps θ_first in A, Strict a third vector per level): the logical order
+  const int NL_HOT = NLEV < 4 ? NLEV : 4;
+  const int HOT_END = 2 * NL_HOT - 1;                                  // first slot after the hot levels
+  const int COLD_DORM = HOT_END + 2 + 2 * (NLEV > 4 ? NLEV - 4 : 0);   // first slot of the remaining dormant vectors
+  auto LA = [&](int l) -> int {  // level l: ρ (Classic: θ) of the pending first half
+    if constexpr (GENERAL) return NV * l;
+    else return l == 0 ? 0 : (l < NL_HOT ? 2 * l - 1 : HOT_END + 2 + 2 * (l - 4));
+  };
+  auto LRF = [&](int l) -> int {  // level l: r of the pending first half's first-built leaf (level 0, fast kernels: the same slot as A)
+    if constexpr (GENERAL) return NV * l + 1;
+    else return l == 0 ? 0 : (l < NL_HOT ? 2 * l : HOT_END + 3 + 2 * (l - 4));
+  };
+  auto DS = [&](int k) -> int {  // dormant vector k (SL_*)
+    if constexpr (GENERAL) return DORM + k;
+    else return k == SL_TREE_A ? HOT_END : (k == SL_OTH_R ? HOT_END + 1
+                : COLD_DORM + (k == SL_OTH_TH ? 0 : k == SL_OTH_G ? 1 : k == SL_Z0_R ? 2 : k == SL_Z0_G ? 3 : 4));
+  };
   const bool classic = GENERAL && p.criterion == 0;
   const bool slice = GENERAL && p.sampler == 2;
 
@@ -329,12 +356,12 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     DrawStreamT<(G >= 64)> ds;
     ds.init(rng);
     // both edges of the one-leaf tree are z0 (src/trajectory.jl:682-685)
-    sl.store(DORM + SL_OTH_TH, cur.th);
-    sl.store(DORM + SL_OTH_R, cur.r);
-    sl.store(DORM + SL_OTH_G, cur.g);
-    sl.store(DORM + SL_Z0_R, cur.r);
-    sl.store(DORM + SL_Z0_G, cur.g);
-    if (!classic) sl.store(DORM + SL_TREE_A, cur.r);  // ρ = r0 (TurnStatistic, :461-463)
+    sl.store(DS(SL_OTH_TH), cur.th);
+    sl.store(DS(SL_OTH_R), cur.r);
+    sl.store(DS(SL_OTH_G), cur.g);
+    sl.store(DS(SL_Z0_R), cur.r);
+    sl.store(DS(SL_Z0_G), cur.g);
+    if (!classic) sl.store(DS(SL_TREE_A), cur.r);  // ρ = r0 (TurnStatistic, :461-463)
     T w_tree, sa_tree = 0, dh_tree = 0, lu = 0;
     int na_tree = 0, ck_tree = 0;
     if (slice) {
@@ -344,6 +371,9 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       w_tree = LINW ? T(1) : T(0);  // MultinomialTS(rng, z0): ℓw = 0 (:155); LINW carries W = exp(ℓw)
     }
     bool cur_is_left = false;
+#if AHMC_PREFETCH_SWAP
+    T pf_th[E], pf_r[E], pf_g[E];  // the other edge as requested at the top of the previous doubling (fast kernels)
+#endif
     int pos_cur = 0, pos_oth = 0;  // leaf index (signed distance from z0) of the two edges
     bool numerical = false;
     bool redo = false;  // LINW only: a weight came too close to overflow
@@ -361,12 +391,19 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         if (need_swap) {
           if (jw > 0) {  // at jw == 0 both edges are z0
             Point<T, E> t;
-            sl.load(DORM + SL_OTH_TH, t.th);
-            sl.load(DORM + SL_OTH_R, t.r);
-            sl.load(DORM + SL_OTH_G, t.g);
-            sl.store(DORM + SL_OTH_TH, cur.th);
-            sl.store(DORM + SL_OTH_R, cur.r);
-            sl.store(DORM + SL_OTH_G, cur.g);
+#if AHMC_PREFETCH_SWAP
+            if constexpr (!GENERAL) {
+              copy_vec(t.th, pf_th); copy_vec(t.r, pf_r); copy_vec(t.g, pf_g);
+            } else
+#endif
+            {
+              sl.load(DS(SL_OTH_TH), t.th);
+              sl.load(DS(SL_OTH_R), t.r);
+              sl.load(DS(SL_OTH_G), t.g);
+            }
+            sl.store(DS(SL_OTH_TH), cur.th);
+            sl.store(DS(SL_OTH_R), cur.r);
+            sl.store(DS(SL_OTH_G), cur.g);
             copy_vec(cur.th, t.th);
             copy_vec(cur.r, t.r);
             copy_vec(cur.g, t.g);
@@ -376,7 +413,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         }
       }
       if (strict && AHMC_ANY(!done)) {
-        if (!done) sl.store(DORM + SL_START_R, cur.r);  // r of the edge the subtree grows from
+        if (!done) sl.store(DS(SL_START_R), cur.r);  // r of the edge the subtree grows from
       }
       // ---- build the subtree of 2^jw leaves (:626-675) ----
       const uint32_t nleaf = 1u << jw;
@@ -400,8 +437,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             // a merge follows: its two dot products ride in the leaf's all-reduce (they only need the new r)
             leapfrog_step_plus2<T, G, E, TK>(cur, minv, v > 0 ? eps : -eps, p.tp, lane, d0, dots_m0, [&](T& s0, T& s1) {
               T A_p[E];
-              sl.load(0, A_p);
-              sl.load(1, RF_m0);
+              sl.load(LA(0), A_p);  // level 0: one slot (ρ = first-built r = the leaf's r)
+              copy_vec(RF_m0, A_p);
               s0 = 0;
               s1 = 0;
 #pragma unroll
@@ -462,8 +499,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           {
             T A_p[E], RF_p[E];
             if constexpr (!pre.value) {
-              sl.load(NV * lvl, A_p);
-              sl.load(NV * lvl + 1, RF_p);
+              sl.load(LA(lvl), A_p);
+              if (!GENERAL && lvl == 0) copy_vec(RF_p, A_p); else sl.load(LRF(lvl), RF_p);
             }
             const T w_p = S_W(lvl);
             // combine(rng, sampler′, sampler′′): `first` = the half built first (:178-195)
@@ -574,11 +611,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         } else if (alive && leaf < nleaf) {
           // park the finished level-nm subtree until its sibling is built
           if (GENERAL || nm > 0) {
-            sl.store(NV * nm, A_c);
-            sl.store(NV * nm + 1, RF_c);
+            sl.store(LA(nm), A_c);
+            sl.store(LRF(nm), RF_c);
           } else {
-            sl.store(0, cur.r);
-            sl.store(1, cur.r);
+            sl.store(LA(0), cur.r);  // (level 0 of a fast kernel: ρ and first-built r are this one vector)
           }
           if (strict) sl.store(NV * nm + 2, cur.r);  // r of its last-built leaf
           S_W(nm) = w_c;
@@ -611,10 +647,17 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         // isterminated(tc, h, tree, tleft, tright) on the whole tree; its edges are `cur` and the dormant one
         bool turn;
         T oth_r[E];
-        sl.load(DORM + SL_OTH_R, oth_r);
+        sl.load(DS(SL_OTH_R), oth_r);
+#if AHMC_PREFETCH_SWAP
+        if constexpr (!GENERAL) {  // in flight during the reduction below; used if the next doubling changes direction
+          sl.load(DS(SL_OTH_TH), pf_th);
+          sl.load(DS(SL_OTH_G), pf_g);
+          copy_vec(pf_r, oth_r);
+        }
+#endif
         if (classic) {
           T oth_th[E];
-          sl.load(DORM + SL_OTH_TH, oth_th);
+          sl.load(DS(SL_OTH_TH), oth_th);
           T dots[2] = {0, 0};
 #pragma unroll
           for (int e = 0; e < E; ++e) {
@@ -628,7 +671,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           turn = (dots[0] >= 0) || (dots[1] >= 0);
         } else {
           T A_tree[E];
-          sl.load(DORM + SL_TREE_A, A_tree);
+          sl.load(DS(SL_TREE_A), A_tree);
           if (!strict) {
             T dots[2] = {0, 0};
 #pragma unroll
@@ -643,7 +686,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             // strict at the top: (ρ_tree + r_sub.first ; ends other edge, sub.first) and
             //                    (r_start + ρ_sub ; ends start edge, current edge)
             T rs[E];
-            sl.load(DORM + SL_START_R, rs);
+            sl.load(DS(SL_START_R), rs);
             T dots[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -661,7 +704,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             group_allsum<G>(dots);
             turn = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
           }
-          sl.store(DORM + SL_TREE_A, A_tree);
+          sl.store(DS(SL_TREE_A), A_tree);
         }
         if (sub_term || turn) done = true;
       }
@@ -675,8 +718,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       asm volatile("" : "+v"(ce));
       Point<T, E> zc;
       load_vec<T, E>(zc.th, p.th(), ce * p.D, d0, p.D, T(0));
-      sl.load(DORM + SL_Z0_R, zc.r);
-      sl.load(DORM + SL_Z0_G, zc.g);
+      sl.load(DS(SL_Z0_R), zc.r);
+      sl.load(DS(SL_Z0_G), zc.g);
       const int steps = on ? (ck_tree < 0 ? -ck_tree : ck_tree) : 0;
       const T es = ck_tree < 0 ? -eps : eps;
       for (int s = 0;; ++s) {
@@ -734,6 +777,9 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               load_vec<T, E>(mug, ak->wg_mu, ce * p.D, d0, p.D, T(0));
               load_vec<T, E>(Mg, ak->wg_M, ce * p.D, d0, p.D, T(0));
             }
+            // (round 3: requesting these, the accumulators and the energy sums at the top of the epilogue — one round trip with
+            // the start point instead of three behind the re-integration — was measured: the warm-up instantiation went from 89
+            // to 217 spilled VGPRs and from 2.26e9 to 1.45e9 leapfrog/s; not taken)
             if (do_push) {
 #pragma unroll
               for (int e = 0; e < E; ++e) {

@@ -21,10 +21,13 @@ round-1 headline) and the warm-up rate are sub-fields of `config`.
 registers, so SURVEY §8d's state-through-memory byte model is not a roof for it (a fraction > 1 in round 1); it is
 still reported as `hbm_model_frac`.  VALU roof: wave-instructions per leapfrog of the shipped kernel × leapfrogs of
 the launches ÷ their duration (HIP events recorded by the engine around every launch of the kernel on its stream)
-÷ the MIX-WEIGHTED issue peak of that kernel: the measured issue rate of every instruction class on this chip
-(scripts/probe/valu_rate.hip → profiles/r3_valu_rate.json: f64 arithmetic, DPP moves, multiplies ≈ 450–590 G wave-instr/s,
-32-bit add / xor / mov ≈ 1 000, permlane swaps ≈ 300) weighted by the kernel's dynamic instruction mix
-(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / INT32 / INT64 / CVT per leapfrog; scripts/valu_mix.py).  Instructions per leapfrog and HBM bytes come from
+÷ the MIX-WEIGHTED issue peak of that kernel: every instruction class priced at its nominal issue cycles — 2 (32-bit add /
+xor / mov), 4 (f64 arithmetic, DPP moves, 64-bit moves, multiplies, compares, selects), 8 (permlane swaps), 16 (f64 rcp) per
+wave64 instruction, the class of each instruction type read off its MEASURED rate on this chip (scripts/probe/valu_rate.hip →
+profiles/r3_valu_rate.json) — at 2.4 GHz × 1024 SIMDs, weighted by the kernel's dynamic instruction mix
+(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / INT32 / INT64 / CVT per leapfrog; scripts/valu_mix.py).  (Priced at the measured
+single-class rates themselves the roof comes out 10 % lower and the kernel exceeds it: a pure v_fma_f64 stream runs 27 % under
+nominal, a mixed stream does not.)  Instructions per leapfrog and HBM bytes come from
 rocprofv3 PMC passes over THIS command, committed as profiles/counters_at_head.json together with the digest of the
 kernel sources they were taken on: if the digest does not match the library in use the counters are stale and
 `frac`, `traffic` are null (never rescaled from an old measurement).
@@ -397,8 +400,9 @@ def main():
                 dom = both[0]
                 roof = {"bound": "valu", "unit": "Gwave-instr/s", "peak": dom.get("peak", VALU_PEAK_GINSTR), "achieved": dom["achieved"], "frac": dom["frac"],
                         "traffic": dom["traffic"], "kernel": dom["kernel"], "counters": counters_src,
-                        "peak_definition": ("mix-weighted VALU issue peak of this kernel: N / sum_c n_c / rate_c over its dynamic instruction classes, rate_c "
-                                            "measured per class on the MI355X (scripts/probe/valu_rate.hip, profiles/r3_valu_rate.json; scripts/valu_mix.py)"
+                        "peak_definition": ("mix-weighted VALU issue peak of this kernel: N / sum_c n_c * cycles_c over its dynamic instruction classes at 2.4 GHz x "
+                                            "1024 SIMDs, cycles_c in {2,4,8,16} per wave64 instruction = the class of each instruction type by its MEASURED rate "
+                                            "on the MI355X (scripts/probe/valu_rate.hip, profiles/r3_valu_rate.json; scripts/valu_mix.py)"
                                             if dom.get("peak_is_mix_weighted") else
                                             "uncalibrated: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (no class mix for this kernel)"),
                         "dominant": dom, "other": both[1] if len(both) > 1 else None,

@@ -75,13 +75,18 @@ for cfg in sys.argv[1:]:
         if kn and r.get("valu_mix_per_leapfrog") and os.path.exists(RATES):
             text = kernel_text(kn)
             if text:
-                w = max(1, min(8, int(round(r.get("mean_waves_per_simd") or 4))))
-                w = {1: 1, 2: 2, 3: 4, 4: 4, 5: 4, 6: 8, 7: 8, 8: 8}[w]
                 try:
-                    a = valu_mix.analyse(text, valu_mix.load_rates(RATES, f"W{w}"), r["valu_mix_per_leapfrog"], r["valu_per_leapfrog"], 1, f"W{w}")
-                    a0 = valu_mix.analyse(text, valu_mix.load_rates(RATES, f"W{w}"), r["valu_mix_per_leapfrog"], r["valu_per_leapfrog"], 0, f"W{w}")
-                    c[mode]["valu_peak_mix_gwave_instr_per_s"] = a["peak_mix_gwave_instr_per_s"]
-                    c[mode]["valu_peak_mix"] = {"rates": os.path.relpath(RATES, ROOT), "priced_at_waves_per_simd": w, "kernel": kn,
+                    # a roof is an upper bound: every class priced at its HIGHEST sustained rate over the probed occupancies
+                    a = valu_mix.analyse(text, valu_mix.load_rates(RATES, "max"), r["valu_mix_per_leapfrog"], r["valu_per_leapfrog"], 1, "max")
+                    a0 = valu_mix.analyse(text, valu_mix.load_rates(RATES, "max"), r["valu_mix_per_leapfrog"], r["valu_per_leapfrog"], 0, "max")
+                    a4 = valu_mix.analyse(text, valu_mix.load_rates(RATES, "W4"), r["valu_mix_per_leapfrog"], r["valu_per_leapfrog"], 1, "W4")
+                    c[mode]["valu_peak_mix_gwave_instr_per_s"] = a["peak_mix_nominal_gwave_instr_per_s"]
+                    c[mode]["valu_peak_mix"] = {"rates": os.path.relpath(RATES, ROOT),
+                                                "priced_at": "nominal issue cycles (2 / 4 / 8 / 16 per wave64 instruction; the class of every instruction type "
+                                                             "from its MEASURED rate) at 2.4 GHz x 1024 SIMDs",
+                                                "nominal_cycles_by_probe_entry": a["nominal_cycles_by_probe_entry"],
+                                                "peak_from_measured_single_class_rates": a["peak_mix_gwave_instr_per_s"],
+                                                "peak_if_priced_at_4_waves_per_simd": a4["peak_mix_gwave_instr_per_s"], "kernel": kn,
                                                 "class_counts_per_leapfrog": a["dynamic"]["class_counts_per_leapfrog"],
                                                 "issue_time_share": a["dynamic"]["issue_time_share"],
                                                 "hot_loop_static_valu": a["hot_loop"]["static_valu"],
