@@ -23,9 +23,6 @@
 // start at the end (vector work only, no reductions, no RNG), which halves the pending state and
 // removes every candidate copy from the merge path.
 #pragma once
-#ifndef AHMC_PREFETCH_SWAP
-#define AHMC_PREFETCH_SWAP 0   // experiment: request the other edge's θ and g (global scratch) before the U-turn reduction of a doubling's top
-#endif
 #ifndef AHMC_SCALAR_ANY
 #define AHMC_SCALAR_ANY 1      // loop-control predicates of a wave-owning chain are tested directly instead of through a ballot (0: ballot)
 #endif
@@ -371,9 +368,6 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       w_tree = LINW ? T(1) : T(0);  // MultinomialTS(rng, z0): ℓw = 0 (:155); LINW carries W = exp(ℓw)
     }
     bool cur_is_left = false;
-#if AHMC_PREFETCH_SWAP
-    T pf_th[E], pf_r[E], pf_g[E];  // the other edge as requested at the top of the previous doubling (fast kernels)
-#endif
     int pos_cur = 0, pos_oth = 0;  // leaf index (signed distance from z0) of the two edges
     bool numerical = false;
     bool redo = false;  // LINW only: a weight came too close to overflow
@@ -391,16 +385,9 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         if (need_swap) {
           if (jw > 0) {  // at jw == 0 both edges are z0
             Point<T, E> t;
-#if AHMC_PREFETCH_SWAP
-            if constexpr (!GENERAL) {
-              copy_vec(t.th, pf_th); copy_vec(t.r, pf_r); copy_vec(t.g, pf_g);
-            } else
-#endif
-            {
-              sl.load(DS(SL_OTH_TH), t.th);
-              sl.load(DS(SL_OTH_R), t.r);
-              sl.load(DS(SL_OTH_G), t.g);
-            }
+            sl.load(DS(SL_OTH_TH), t.th);
+            sl.load(DS(SL_OTH_R), t.r);
+            sl.load(DS(SL_OTH_G), t.g);
             sl.store(DS(SL_OTH_TH), cur.th);
             sl.store(DS(SL_OTH_R), cur.r);
             sl.store(DS(SL_OTH_G), cur.g);
@@ -648,13 +635,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         bool turn;
         T oth_r[E];
         sl.load(DS(SL_OTH_R), oth_r);
-#if AHMC_PREFETCH_SWAP
-        if constexpr (!GENERAL) {  // in flight during the reduction below; used if the next doubling changes direction
-          sl.load(DS(SL_OTH_TH), pf_th);
-          sl.load(DS(SL_OTH_G), pf_g);
-          copy_vec(pf_r, oth_r);
-        }
-#endif
+        // (round 3: requesting the other edge's θ and g — global scratch — here, in flight during the reduction below, for the change
+        // of direction that follows half of the doublings, was measured: 2.645e9 against 2.666e9 whole loop; not taken)
         if (classic) {
           T oth_th[E];
           sl.load(DS(SL_OTH_TH), oth_th);

@@ -39,8 +39,8 @@ def code_digest(text) -> str:
     h = hashlib.sha256()
     for line in text.splitlines():
         t = line.strip()
-        if not t or t == "...":
-            continue
+        if not t or t == "..." or "file format" in t or t.startswith("Disassembly of section"):
+            continue  # (the "file format" line carries the path of the temporary copy that was disassembled)
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", t)
         if m:
             t = m.group(1)            # a kernel's header line: its name, not its address
