@@ -1461,7 +1461,22 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
 int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t init_buffer, int32_t term_buffer, int32_t window_size) {
   FOR_CTX_MUT(ctx, {
     if (kind < AHMC_ADAPT_NONE || kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: unknown adaptor kind");
-    return adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
+    int rc = adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
+    if (rc) return rc;
+    // An adaptor announces a sampling run: reserve the buffer of its momentum normals now (setup), not inside the first
+    // launch of the run — a 16 GiB hipMalloc was seen to take up to a second now and then (one of three bench runs at
+    // 2.06e9 instead of 2.65e9 with the whole second in the warm-up phase's wall time, none of it in the kernels).
+    if (kind != AHMC_ADAPT_NONE && !dense_engine(c) && c->target_kind != AHMC_TARGET_EXTERNAL) {
+      const size_t need = (size_t)nuts_batch(c) * (size_t)c->D * (size_t)c->N;
+      if (need > c->znorm_elems) {
+        if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
+        c->znorm = nullptr;
+        c->znorm_elems = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->znorm), need * sizeof(T)));
+        c->znorm_elems = need;
+      }
+    }
+    return AHMC_OK;
   });
 }
 

@@ -170,6 +170,8 @@ typedef DrawStreamT<false> DrawStream;
 // is faster every time: cfg2 (64,2) 1.68e9 -> 1.79e9 (5 waves: 1.22e9), hier D=256 (64,4) 7.1e8 -> 1.0e9,
 // D=512 (64,8) 3.1e8 -> 5.5e8 (3 waves: 2.3e8), D=2048 (256,8) 5.8e7 -> 1.08e8.
 template <class T, int G, int E, int MODE, int TK>
+// (round 3: the warm-up instantiations capped for 3 waves per SIMD instead of 4 — 168 VGPRs, no spills, 12 LDS slots — run at 2.24e9
+// in-kernel against 2.37e9: occupancy matters more than the spills.)
 __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) : (E <= 2 ? 4 : (E <= 4 ? 3 : 2)))) void k_nuts(KP<T> p) {
   constexpr int CPW = G >= 64 ? 1 : 64 / G;  // chains per wave (G > 64: one chain per workgroup of G/64 waves)
   // A chain that owns whole waves makes every per-chain predicate wave-uniform; saying so (a ballot is uniform by
