@@ -433,7 +433,10 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   if (ov && atoi(ov) > 0) occ = atoi(ov);
   const size_t lds_per_cu = 160 * 1024;
   size_t per_wave = lds_per_cu / (size_t)occ;
-  if (per_wave > 64 * 1024 / (size_t)NW) per_wave = 64 * 1024 / (size_t)NW;  // <= 64 KB per workgroup
+  // (a gfx950 workgroup may hold more than 64 KB of LDS — the rate probe runs with 159 KB —: a multi-wave chain's workgroup takes
+  // its full share, 80 KB at two workgroups per CU = five 16 KB slots at D = 2 048 instead of four.  AHMC_NUTS_LDS_WG_KB caps it.)
+  static const size_t wg_cap = (size_t)(getenv("AHMC_NUTS_LDS_WG_KB") ? atoi(getenv("AHMC_NUTS_LDS_WG_KB")) : 160) * 1024;
+  if (per_wave > wg_cap / (size_t)NW) per_wave = wg_cap / (size_t)NW;
   per_wave = per_wave > scalar_bytes + 128 ? per_wave - scalar_bytes - 128 : 0;
   n_lds_slots = (int)std::min<size_t>((size_t)n_slots, per_wave / slot_bytes);
   const char* ovs = getenv("AHMC_NUTS_LDS_SLOTS");
