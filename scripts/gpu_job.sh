@@ -1,9 +1,13 @@
 export TMPDIR=/tmp
-for kb in 64 160; do
-  AHMC_NUTS_LDS_WG_KB=$kb AHMC_DEBUG=1 timeout 300 python bench.py --config cfg5 --steps 2 --warmup 0 --repeats 1 --no-cpu-baseline 2> /tmp/err_$kb.txt | python -c "
+O=gpurun_out/r3ae; mkdir -p $O
+for cfg in cfg3 cfg4 cfg5; do
+  st=20; [ $cfg = cfg5 ] && st=2
+  ( timeout 900 python bench.py --config $cfg --steps $st --warmup 1 --no-cpu-baseline 2> $O/bench_$cfg.err | tail -1 ) > $O/bench_$cfg.json
+  python - $O/bench_$cfg.json <<'PY'
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']
-print('cfg5 LDS/WG $kb KB', 'e2e %.3e  warm %.3e  draw %.3e' % (d['value'], c['warmup_phase']['value'], c['post_adaptation']['value']))"
-  grep "k_nuts<" /tmp/err_$kb.txt | sort | uniq -c | head -3
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']
+print(sys.argv[1], 'e2e %.4e  warm %.4e  draw %.4e runs %s' % (d['value'], c['warmup_phase']['value'], c['post_adaptation']['value'], c['runs']))
+PY
+  PROFILE_STEPS=2 PROFILE_PASSES=none bash scripts/profile_head.sh $cfg > /dev/null 2>&1
 done
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "multiwave or geometries" 2>&1 | tail -2
+( ADAPT=300 DRAWS=200 timeout 900 python scripts/user_target_bench.py builtin plugin 2>&1 | tail -1 ) > $O/user_target_bench_fused.json; cut -c1-300 $O/user_target_bench_fused.json
