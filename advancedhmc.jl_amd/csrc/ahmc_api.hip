@@ -151,6 +151,7 @@ struct Ctx : CtxBase {
   double da_delta = 0.8;
   int32_t* da_m = nullptr;
   T *da_eps = nullptr, *da_mu = nullptr, *da_xbar = nullptr, *da_Hbar = nullptr;
+  T* da_tab = nullptr;  // √m, m^(−κ) of the dual averaging, tabulated on the device (k_da_table)
   int64_t wv_n = 0, wv_nmin = 10;
   T *wv_mu = nullptr, *wv_M = nullptr, *wv_var = nullptr;
   int var_estimator = AHMC_VAR_WELFORD;            // WelfordVar or NutpieVar (massmatrix.jl:160-250)
@@ -228,7 +229,7 @@ struct Ctx : CtxBase {
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
                     dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C, ext_gstage, ext_lpstage,
-                    dn_P, dn_R, dn_S2, dn_ptcur};
+                    dn_P, dn_R, dn_S2, dn_ptcur, da_tab};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending, &ev_pending_warm})
@@ -751,6 +752,9 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
     if ((rc = dev_alloc(c, &c->da_mu, (size_t)c->N))) return rc;
     if ((rc = dev_alloc(c, &c->da_xbar, (size_t)c->N))) return rc;
     if ((rc = dev_alloc(c, &c->da_Hbar, (size_t)c->N))) return rc;
+    if ((rc = dev_alloc(c, &c->da_tab, (size_t)2 * DA_TAB_M))) return rc;
+    hipLaunchKernelGGL((k_da_table<T>), dim3(DA_TAB_M / 256), dim3(256), 0, c->stream, c->da_tab, T(0.75));  // κ of stepsize.jl:168-172
+    HIPCHK(hipGetLastError());
   }
   // NesterovDualAveraging(δ, ϵ) → DAState(ϵ) (src/adaptation/stepsize.jl:25-33): a reset with ϵ = nominal ϵ
   HIPCHK(hipMemcpyAsync(c->da_eps, c->eps_nom, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
@@ -846,6 +850,7 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     a.delta = (T)c->da_delta; a.gamma = T(0.05); a.t0 = T(10); a.kappa = T(0.75);  // stepsize.jl:168-172
     a.da_m = c->da_m; a.da_eps = c->da_eps; a.da_mu = c->da_mu; a.da_xbar = c->da_xbar; a.da_Hbar = c->da_Hbar;
     a.alpha = c->st_accrate;
+    a.da_tab = c->da_tab;
     if (alpha_ext) {  // caller-supplied α (host or device): stage it on the stream
       if (!c->ext_alpha) { int rc2 = dev_alloc(c, &c->ext_alpha, (size_t)c->N); if (rc2) return rc2; }
       HIPCHK(hipMemcpyAsync(c->ext_alpha, alpha_ext, sizeof(T) * c->N, hipMemcpyDefault, c->stream));
@@ -969,6 +974,7 @@ int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, in
   a.da_m = c->da_m; a.da_eps = c->da_eps; a.da_mu = c->da_mu; a.da_xbar = c->da_xbar; a.da_Hbar = c->da_Hbar;
   a.wv_mu = c->wv_mu; a.wv_M = c->wv_M; a.wv_var = c->wv_var; a.wg_mu = c->wg_mu; a.wg_M = c->wg_M;
   a.minv = c->minv; a.sqrt_minv = c->sqrt_minv; a.eps_nom = c->eps_nom;
+  a.da_tab = c->da_tab;
   int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, accum, k, samples_dev, &a);
   if (rc) return rc;
   for (int kt = 0; kt < k; ++kt) {  // the chain-independent part of adapt!'s state

@@ -1088,6 +1088,7 @@ struct DP2 {
   T delta, gamma, t0, kappa;
   int32_t* da_m;
   T *da_eps, *da_mu, *da_xbar, *da_Hbar;
+  const T* da_tab;
 };
 
 template <class T>
@@ -1368,7 +1369,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
           const int64_t i = q.i0 + it + 1;
           if (i <= q.n_adapts) {
             DAState<T> das{q.da_m[c], q.da_eps[c], q.da_mu[c], q.da_xbar[c], q.da_Hbar[c]};
-            da_step(das, sa_tree / (T)na_tree, q.delta, q.gamma, q.t0, q.kappa);
+            da_step(das, sa_tree / (T)na_tree, q.delta, q.gamma, q.t0, q.kappa, q.da_tab);
             if (i == q.n_adapts) das.eps = exp(das.xbar);  // finalize! (stepsize.jl:55-62)
             q.da_m[c] = das.m; q.da_eps[c] = das.eps; q.da_mu[c] = das.mu; q.da_xbar[c] = das.xbar; q.da_Hbar[c] = das.Hbar;
             p.eps_nom()[c] = das.eps;                      // update(κ, adaptor): nominal step size ← getϵ

@@ -531,15 +531,30 @@ struct DAState {
   int32_t m;
   T eps, mu, xbar, Hbar;
 };
+// The two transcendental functions of the iteration count in adapt_stepsize! — √m and m^(−κ) — tabulated ON THE DEVICE by the same
+// calls that da_step would make (k_da_table), for m < DA_TAB_M: every chain of every wave would otherwise evaluate an f64 `pow`
+// and an f64 `sqrt` per transition on a number that is the same for all of them (≈ 250 of the ≈ 640 VALU instructions per
+// transition that the warm-up instantiation of k_nuts issues beyond the sampling one, and its widest register peak).  Same bits:
+// the table holds what the functions return.
+constexpr int DA_TAB_M = 4096;
+template <class T>
+__global__ void k_da_table(T* __restrict__ tab, T kappa) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= DA_TAB_M) return;
+  tab[2 * m] = sqrt((T)m);
+  tab[2 * m + 1] = m > 0 ? pow((T)m, -kappa) : T(0);
+}
 // adapt_stepsize! (src/adaptation/stepsize.jl:178-210)
 template <class T>
-__device__ __forceinline__ void da_step(DAState<T>& s, T alpha, T delta, T gamma, T t0, T kappa) {
+__device__ __forceinline__ void da_step(DAState<T>& s, T alpha, T delta, T gamma, T t0, T kappa, const T* __restrict__ tab = nullptr) {
 #pragma clang fp contract(off)
   const int32_t m = s.m + 1;
   const T eta_H = T(1) / ((T)m + t0);
   const T Hbar = (T(1) - eta_H) * s.Hbar + eta_H * (delta - jl_min(T(1), alpha));
-  const T x = s.mu - Hbar * (sqrt((T)m) / gamma);
-  const T eta_x = pow((T)m, -kappa);
+  const bool tabulated = tab != nullptr && m < DA_TAB_M;
+  const T sqrt_m = tabulated ? tab[2 * m] : sqrt((T)m);
+  const T x = s.mu - Hbar * (sqrt_m / gamma);
+  const T eta_x = tabulated ? tab[2 * m + 1] : pow((T)m, -kappa);
   const T xbar = (T(1) - eta_x) * s.xbar + eta_x * x;
   const T eps = exp(x);
   if (is_finite(eps)) {  // otherwise the previous (m, ϵ, x̄, H̄) are kept (:199-203)
@@ -590,6 +605,7 @@ struct AdaptK {
   T *da_eps, *da_mu, *da_xbar, *da_Hbar;
   T *wv_mu, *wv_M, *wv_var, *wg_mu, *wg_M;
   T *minv, *sqrt_minv, *eps_nom;
+  const T* da_tab;   // √m, m^(−κ) for m < DA_TAB_M (k_da_table), or null
 };
 
 // stream-ordered upload of a small argument block (the previous launch may still be reading *dst)
@@ -607,6 +623,7 @@ struct AdaptP {
   int32_t* da_m;
   T *da_eps, *da_mu, *da_xbar, *da_Hbar;
   const T* alpha;  // acceptance_rate of the last transition
+  const T* da_tab; // √m, m^(−κ) for m < DA_TAB_M (k_da_table), or null
   T* eps_nom;      // update(κ, adaptor): nominal step size ← getϵ
   // Welford variance (massmatrix.jl:141-157)
   int do_push, do_update, wv_reset;
@@ -625,7 +642,7 @@ __global__ __launch_bounds__(256) void k_adapt_da(AdaptP<T> a) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.N) return;
   DAState<T> st{a.da_m[i], a.da_eps[i], a.da_mu[i], a.da_xbar[i], a.da_Hbar[i]};
-  if (a.do_da) da_step(st, a.alpha[i], a.delta, a.gamma, a.t0, a.kappa);
+  if (a.do_da) da_step(st, a.alpha[i], a.delta, a.gamma, a.t0, a.kappa, a.da_tab);
   if (a.da_reset) da_reset(st);
   if (a.da_finalize) st.eps = exp(st.xbar);  // finalize! (:55-62)
   a.da_m[i] = st.m; a.da_eps[i] = st.eps; a.da_mu[i] = st.mu; a.da_xbar[i] = st.xbar; a.da_Hbar[i] = st.Hbar;

@@ -744,7 +744,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           schedule(kt, do_push, do_update, wv_reset, dareset);
           if (ak->has_ss) {
             DAState<T> das{A_DAM, A_DAEPS, A_DAMU, A_DAXBAR, A_DAHBAR};
-            da_step(das, sa_tree / (T)na_tree, ak->delta, ak->gamma, ak->t0, ak->kappa);
+            da_step(das, sa_tree / (T)na_tree, ak->delta, ak->gamma, ak->t0, ak->kappa, ak->da_tab);
             if (dareset) da_reset(das);
             if (i == ak->n_adapts) das.eps = exp(das.xbar);  // finalize! (stepsize.jl:55-62)
             A_DAM = das.m; A_DAEPS = das.eps; A_DAMU = das.mu; A_DAXBAR = das.xbar; A_DAHBAR = das.Hbar;
