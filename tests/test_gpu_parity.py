@@ -652,6 +652,29 @@ def test_adaptation(hip, oracle, rng, kind):
     np.testing.assert_allclose(g2.get_stepsize(), o2.get_stepsize(), rtol=1e-7)
 
 
+def test_dual_averaging_table_and_its_end(hip, oracle, rng):
+    """adapt_stepsize! (src/adaptation/stepsize.jl:178-210) reads √m and m^(−κ) from a table built on the device for
+    m < 4 096 (k_da_table) and evaluates them beyond: a StepSizeAdaptor driven with the same α on the HIP engine and on the
+    oracle (which always evaluates them) agrees on both sides of the table's end and after finalize!"""
+    D, N, n_adapts = 4, 128, 4200
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.3))
+    g, o = pair(hip, oracle, h, N, np.float64, seed=3, lf=lf)
+    th = rng.normal(size=(D, N))
+    for e in (g, o):
+        e.set_position(th)
+        e.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+    base = rng.uniform(0.55, 0.95, size=N)  # per-chain mean acceptance: the chains settle on different step sizes
+    for i in range(1, n_adapts + 1):
+        alpha = np.clip(base + 0.05 * rng.standard_normal(N), 0.0, 1.0)
+        for e in (g, o):
+            e.adapt(i, n_adapts, th, alpha)
+        if i in (1, 2, 100, 4094, 4095, 4096, 4097, 4150, n_adapts - 1, n_adapts):
+            np.testing.assert_allclose(g.get_stepsize(), o.get_stepsize(), rtol=1e-12, err_msg=f"ϵ at i={i}")
+    assert len(np.unique(g.get_stepsize())) > N // 2
+
+
 def test_nutpie_var(hip, oracle, rng):
     """NutpieVar (src/adaptation/massmatrix.jl:160-250) on identical (θ, ∇, α) inputs: HIP == oracle; and as the
     estimator of a StanHMCAdaptor on a diagonal Gaussian it recovers σ² (test/adaptation.jl:183-192)"""
