@@ -753,7 +753,7 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
     if ((rc = dev_alloc(c, &c->da_xbar, (size_t)c->N))) return rc;
     if ((rc = dev_alloc(c, &c->da_Hbar, (size_t)c->N))) return rc;
     if ((rc = dev_alloc(c, &c->da_tab, (size_t)2 * DA_TAB_M))) return rc;
-    hipLaunchKernelGGL((k_da_table<T>), dim3(DA_TAB_M / 256), dim3(256), 0, c->stream, c->da_tab, T(0.75));  // κ of stepsize.jl:168-172
+    hipLaunchKernelGGL((k_da_table<T>), dim3(DA_TAB_M / 256), dim3(256), 0, c->stream, c->da_tab, T(DA_KAPPA));
     HIPCHK(hipGetLastError());
   }
   // NesterovDualAveraging(δ, ϵ) → DAState(ϵ) (src/adaptation/stepsize.jl:25-33): a reset with ϵ = nominal ϵ
@@ -847,7 +847,7 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     a.do_da = 1;
     a.da_reset = da_reset ? 1 : 0;
     a.da_finalize = (i == n_adapts) ? 1 : 0;
-    a.delta = (T)c->da_delta; a.gamma = T(0.05); a.t0 = T(10); a.kappa = T(0.75);  // stepsize.jl:168-172
+    a.delta = (T)c->da_delta; a.gamma = T(DA_GAMMA); a.t0 = T(DA_T0); a.kappa = T(DA_KAPPA);  // stepsize.jl:168-172
     a.da_m = c->da_m; a.da_eps = c->da_eps; a.da_mu = c->da_mu; a.da_xbar = c->da_xbar; a.da_Hbar = c->da_Hbar;
     a.alpha = c->st_accrate;
     a.da_tab = c->da_tab;
@@ -970,7 +970,7 @@ int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, in
   for (int s2 = 0; s2 < a.n_splits; ++s2) a.splits[s2] = c->windows.splits[(size_t)s2];
   a.wv_n0 = c->wv_n;
   a.wv_nmin = c->wv_nmin;
-  a.delta = (T)c->da_delta; a.gamma = T(0.05); a.t0 = T(10); a.kappa = T(0.75);  // stepsize.jl:168-172
+  a.delta = (T)c->da_delta; a.gamma = T(DA_GAMMA); a.t0 = T(DA_T0); a.kappa = T(DA_KAPPA);  // stepsize.jl:168-172
   a.da_m = c->da_m; a.da_eps = c->da_eps; a.da_mu = c->da_mu; a.da_xbar = c->da_xbar; a.da_Hbar = c->da_Hbar;
   a.wv_mu = c->wv_mu; a.wv_M = c->wv_M; a.wv_var = c->wv_var; a.wg_mu = c->wg_mu; a.wg_M = c->wg_M;
   a.minv = c->minv; a.sqrt_minv = c->sqrt_minv; a.eps_nom = c->eps_nom;

@@ -558,7 +558,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
       q2.adapt_ss = 1;
       q2.i0 = adapt_i0;
       q2.n_adapts = adapt_n;
-      q2.delta = (T)c->da_delta; q2.gamma = T(0.05); q2.t0 = T(10); q2.kappa = T(0.75);  // stepsize.jl:168-172
+      q2.delta = (T)c->da_delta; q2.gamma = T(DA_GAMMA); q2.t0 = T(DA_T0); q2.kappa = T(DA_KAPPA);  // stepsize.jl:168-172
       q2.da_m = c->da_m; q2.da_eps = c->da_eps; q2.da_mu = c->da_mu; q2.da_xbar = c->da_xbar; q2.da_Hbar = c->da_Hbar;
       q2.da_tab = c->da_tab;
     }

@@ -537,6 +537,8 @@ struct DAState {
 // transition that the warm-up instantiation of k_nuts issues beyond the sampling one, and its widest register peak).  Same bits:
 // the table holds what the functions return.
 constexpr int DA_TAB_M = 4096;
+// NesterovDualAveraging's constants (src/adaptation/stepsize.jl:168-172) — one definition: the table is built for THIS κ
+constexpr double DA_GAMMA = 0.05, DA_T0 = 10.0, DA_KAPPA = 0.75;
 template <class T>
 __global__ void k_da_table(T* __restrict__ tab, T kappa) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
