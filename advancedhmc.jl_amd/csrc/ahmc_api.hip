@@ -1191,14 +1191,26 @@ int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void*
       return reject("built for thread geometry (" + std::to_string(d->G) + "," + std::to_string(d->E) + "), the context uses (" + std::to_string(c->G) + "," +
                     std::to_string(c->E) + ")");
     if (d->n_params >= 0 && d->n_params != n_params) return reject("expects " + std::to_string(d->n_params) + " parameters");
-    if (c->tparams) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tparams)); c->tparams = nullptr; }
+    // (a HIP error from here on must not leave the library loaded: the checks close it before they return)
+    auto hip_ok = [&](hipError_t e, const char* what) {
+      if (e == hipSuccess) return true;
+      c->err = std::string(what) + ": " + hipGetErrorString(e);
+      dlclose(dl);
+      return false;
+    };
+    if (!hip_ok(hipStreamSynchronize(c->stream), "set_target_plugin: hipStreamSynchronize")) return AHMC_ERR_RUNTIME;
+    if (c->tparams) {
+      if (!hip_ok(hipFree(c->tparams), "set_target_plugin: hipFree")) return AHMC_ERR_RUNTIME;
+      c->tparams = nullptr;
+    }
     if (n_params > 0) {
       int rc = dev_alloc(c, &c->tparams, (size_t)n_params);
       if (rc) { dlclose(dl); return rc; }
-      HIPCHK(hipMemcpyAsync(c->tparams, params, sizeof(T) * n_params, hipMemcpyDefault, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      if (!hip_ok(hipMemcpyAsync(c->tparams, params, sizeof(T) * n_params, hipMemcpyDefault, c->stream), "set_target_plugin: hipMemcpyAsync") ||
+          !hip_ok(hipStreamSynchronize(c->stream), "set_target_plugin: hipStreamSynchronize"))
+        return AHMC_ERR_RUNTIME;
     }
-    if (c->plugin_dl) { HIPCHK(hipStreamSynchronize(c->stream)); dlclose(c->plugin_dl); }
+    if (c->plugin_dl) dlclose(c->plugin_dl);  // (the stream is idle: nothing of the previous plugin's code is running)
     c->plugin_dl = dl;
     c->plugin_ops = static_cast<const TargetOps<T>*>(d->ops);
     c->target_kind = AHMC_TARGET_PLUGIN;
