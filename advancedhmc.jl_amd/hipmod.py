@@ -43,3 +43,10 @@ class Module:
         if rc != 0:
             raise RuntimeError(f"hipModuleGetFunction({name}) failed with hipError {rc}")
         return fn.value
+
+    def close(self):
+        """hipModuleUnload — only once no engine holds a function of this module any more (the engine launches the
+        hipFunction_t it was given; it does not own the module)"""
+        if self._mod is not None and self._mod.value:
+            hip_runtime().hipModuleUnload(self._mod)
+        self._mod = None
