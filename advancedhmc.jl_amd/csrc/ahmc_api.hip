@@ -475,8 +475,32 @@ int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
   if (rc) return rc;
   p.scratch = c->scratch;
   p.n_lds_levels = n_lds_slots;
+#if AHMC_WAVE_TIMELINE
+  // measurement build only: one record of eight 64-bit words per wave of the MODE 0 / MODE 3 pass, written to
+  // $AHMC_WAVE_TIMELINE.<launch>.bin after the launch (synchronises)
+  static int tl_launch = 0;
+  unsigned long long* tl_buf = nullptr;
+  const char* tl_path = getenv("AHMC_WAVE_TIMELINE_OUT");
+  const size_t tl_words = (size_t)p.n_chunks * 8;
+  p.hmc_H = nullptr;
+  if (tl_path && (MODE == 0 || MODE == 3)) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&tl_buf), tl_words * 8));
+    HIPCHK(hipMemsetAsync(tl_buf, 0, tl_words * 8, c->stream));
+    p.hmc_H = reinterpret_cast<T*>(tl_buf);
+  }
+#endif
   if (const TargetOps<T>* o = ops_for(c)) o->nuts(c->G, c->E, MODE, (unsigned)blocks, wpb, smem, c->stream, p);
   HIPCHK(hipGetLastError());
+#if AHMC_WAVE_TIMELINE
+  if (tl_buf) {
+    std::vector<unsigned long long> h(tl_words);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(h.data(), tl_buf, tl_words * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(tl_buf));
+    const std::string fn = std::string(tl_path) + "." + std::to_string(tl_launch++) + ".mode" + std::to_string(MODE) + ".bin";
+    if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(h.data(), 8, tl_words, f); fclose(f); }
+  }
+#endif
   return AHMC_OK;
 }
 
@@ -1572,6 +1596,10 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
     // Dispatch order by measured work: a better predictor of a chain's tree sizes than its step size is what it
     // actually did — Σ n_steps per chain of the previous sampling call (still in the accumulators here) or of
     // this call's first batch (below).  Counting sort on the stream, no host synchronisation.
+    // (Round 3, measured and NOT taken: using the counts of the call before even when the ϵ order has been invalidated — i.e. the
+    // warm-up's Σ n_steps for the first launch of the draws, and then for all of them —: cfg2 draws 2.97e9 -> 2.41e9, cfg3
+    // 1.70e9 -> 1.58e9 (one launch: a clean comparison; cfg2's figure also contains that its later launches no longer switched to
+    // the first launch's counts).  What a chain did while it was still adapting predicts its sampling work worse than its final ϵ.)
     auto order_by_work = [&](bool refresh) -> int {
       if (!cfg->nuts || dense_engine(c) || !c->order_valid || (c->order_from_work && !refresh) || c->acc_ntrans < 4) return AHMC_OK;
       int rc2 = build_order(c, (int)std::min<int64_t>(c->acc_ntrans, 1 << 20));
@@ -1609,7 +1637,11 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         // (split the remaining transitions evenly: 50 = 13+13+12+12, not 16+16+16+2 — a short
         // last batch would pay the whole tree-size tail for two transitions)
         const int64_t left = n_samples - i + 1, nb_left = (left + batch - 1) / batch;
-        const int64_t k = (left + nb_left - 1) / nb_left;
+        int64_t k = (left + nb_left - 1) / nb_left;
+        // AHMC_NUTS_FIRST_BATCH=n (experiments; default off): a short first launch while the dispatch order is still the one by
+        // step size, so that everything after it is scheduled by measured work (order_by_work below)
+        static const int first_batch = getenv("AHMC_NUTS_FIRST_BATCH") ? atoi(getenv("AHMC_NUTS_FIRST_BATCH")) : 0;
+        if (first_batch >= 4 && !c->order_from_work && !c->eps_scalar && left > 2 * (int64_t)first_batch) k = std::min<int64_t>(k, first_batch);
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
         T* dst = so ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
         T* dev_dst = dst;

@@ -329,6 +329,12 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     A_WVN = wv_n;
   }
 
+#if AHMC_WAVE_TIMELINE
+  // measurement build only (scripts/wave_timeline.py): when did this wave run, how many leaf steps did it make, how many of its
+  // chains were still building in each of them, how many re-integration steps
+  const unsigned long long tl_t0 = wall_clock64();
+  unsigned long long tl_steps = 0, tl_alive = 0, tl_re = 0, tl_trans = 0;
+#endif
   for (int kt = 0; kt < p.n_trans; ++kt) {
     // Make the per-lane indices opaque once per transition: otherwise every address and every
     // constant derived from them is loop-invariant w.r.t. this loop, gets hoisted out of it and
@@ -413,6 +419,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       int na_c = 0, ck_c = 0;
       for (uint32_t leaf = 1; leaf <= nleaf; ++leaf) {
         if (!AHMC_ANY(alive)) break;
+#if AHMC_WAVE_TIMELINE
+        tl_steps += 1;
+        tl_alive += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive && lane == 0));
+#endif
         int merged = 0;
         // merges after this leaf: one per trailing zero bit of `leaf` (:649-673); the count is wave-uniform
         const int nm = __builtin_ctz(leaf);
@@ -709,6 +719,9 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       for (int s = 0;; ++s) {
         const bool go = AHMC_UNI(s < steps);
         if (!AHMC_ANY(go)) break;
+#if AHMC_WAVE_TIMELINE
+        tl_re += 1;
+#endif
         if (go) leapfrog_core<T, G, E, TK, GENERAL>(zc, minv, es, p.tp, p.lf, lane, d0);
       }
       if (on && redo) {
@@ -801,7 +814,18 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         }
       }
     }
+#if AHMC_WAVE_TIMELINE
+    tl_trans += 1;
+#endif
   }  // transitions of this launch
+#if AHMC_WAVE_TIMELINE
+  if (p.hmc_H && lane64 == 0) {  // (the static-HMC energy buffer is not used by NUTS: the measurement build borrows the field)
+    unsigned long long* tl = reinterpret_cast<unsigned long long*>(p.hmc_H) + (size_t)chunk * 8;
+    tl[0] = tl_t0; tl[1] = wall_clock64(); tl[2] = tl_steps; tl[3] = tl_alive; tl[4] = tl_re; tl[5] = tl_trans;
+    tl[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    tl[7] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+  }
+#endif
   if constexpr (ADAPT) {
     if (active) save_adapt_state();
   }
