@@ -662,21 +662,19 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
 
 template <class T>
 int64_t nuts_batch(Ctx<T>* c) {
-  // transitions per launch in the sampling phase: more = less tree-size tail per launch (cfg2:
-  // 8/16/32/64 -> 1.35/1.39/1.42/1.43e9 leapfrog/s); the pre-generated momentum normals take
-  // batch * D * N elements, kept under 4 GiB
+  // transitions per launch of k_nuts (sampling AND fused warm-up): more = less tree-size tail per launch (round 1, cfg2:
+  // 8/16/32/64 -> 1.35/1.39/1.42/1.43e9 leapfrog/s); the pre-generated momentum normals take batch * D * N elements — the
+  // caps and what they were measured against are at the two return statements below
   static const int batch_env = getenv("AHMC_NUTS_BATCH") ? atoi(getenv("AHMC_NUTS_BATCH")) : 0;
   if (batch_env > 0) return batch_env;
   if (dense_engine(c)) {
-    // dense engine: chains run asynchronously through the batch and only its end has idle chains, so longer
-    // is better; three (batch, D, N) arrays (normals, momenta, M⁻¹·momenta) kept under 8 GiB
-    // (round 2: 64 under 8 GiB -> 256 under 48 GiB of the 288: the end of a batch, where only the chains with the
-    // longest trees are left, is the part of it that runs below full occupancy)
-    // ... and under a quarter of what is free on THIS device now (several contexts on one GPU, a user log-density at large
-    // D·N, a part with less than 288 GB): the buffers already held by this context (dn_batch_elems) count as free
+    // dense engine: chains run asynchronously through the batch and only its end has idle chains, so longer is better.  Three
+    // (batch, D, N) arrays (normals, momenta, M⁻¹·momenta): up to 1 024 transitions under min(128 GiB, a third of what is free
+    // on THIS device now — several contexts on one GPU, a user log-density at large D·N, a part with less than 288 GB; the
+    // buffers this context already holds count as free).  History: round 1 64 under 8 GiB, round 2 256 under 48 GiB, round 3
+    // 1 024 under 128 GiB (with the step-size adaptation inside the tree kernel the warm-up runs in batches as well, and the idle
+    // tail of a batch is the same number of global steps however long the batch is).
     size_t free_b = 0, total_b = 0;
-    // (round 3: up to 1 024 transitions under 128 GiB — with the step-size adaptation inside the tree kernel the warm-up runs in
-    // batches as well, and the idle tail of a batch is the same number of global steps however long the batch is)
     size_t budget = 128ull << 30;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const size_t held = c->dn_batch_elems * 2 * sizeof(T) + c->znorm_elems * sizeof(T);
