@@ -93,3 +93,28 @@ def test_counters_are_refused_when_taken_on_other_kernels(tmp_path, monkeypatch)
     (prof / "counters_at_head.json").unlink()
     c, why = bench.counters_at_head("cfg2")
     assert c is None and "missing" in why
+
+
+def test_wave_timeline_analysis_on_a_synthetic_launch(tmp_path):
+    """scripts/wave_timeline.py (the per-wave records of a measurement build): a launch whose wave slots are exactly half
+    full, with every leaf step advancing two of a wave's four chains, must come out as fill 0.5 / lockstep 0.5"""
+    import importlib.util
+
+    import numpy as np
+
+    spec = importlib.util.spec_from_file_location("wave_timeline", os.path.join(ROOT, "scripts", "wave_timeline.py"))
+    wt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wt)
+    slots, n = 8, 8
+    rec = np.zeros((n, 8), dtype=np.uint64)
+    for w in range(n):  # eight waves on eight slots, each running for the first half of a 2-second launch … except one
+        rec[w] = [10**8, 2 * 10**8, 1000, 2000, 500, 10, w, w % 8]
+    rec[0, 1] = 3 * 10**8                              # … which runs to the end: the launch lasts 2 s
+    p = tmp_path / "tl.bin"
+    rec.tofile(p)
+    out = wt.analyse(str(p), cpw=4, slots=slots)
+    assert out["waves"] == n and abs(out["launch_s"] - 2.0) < 1e-9
+    assert abs(out["fill"] - (7 * 1.0 + 2.0) / (slots * 2.0)) < 1e-9
+    assert abs(out["lockstep"] - 0.5) < 1e-12
+    assert abs(out["longest_wave_share_of_launch"] - 1.0) < 1e-9
+    assert out["resident_waves_by_twentieth_of_the_launch"][0] == 8.0 and out["resident_waves_by_twentieth_of_the_launch"][-1] == 1.0
