@@ -437,3 +437,24 @@ def test_randomised_configurations_bit_for_bit(oracle):
             n_deep += stats[-1]["tree_depth"] == max_depth
         eng.close()
     assert n_div > 5 and n_deep > 5
+
+
+def test_resumable_one_leapfrog_per_step_machine_equals_the_recursion():
+    """experiments/r4/async_lockstep_model.py: the NUTS transition as a resumable state machine whose step() is exactly one
+    leapfrog (the iterative formulation of the HIP kernel with every loop counter a member — what a lane group of an
+    asynchronous kernel would carry) reproduces the recursive transcription bit for bit, divergent funnel trees included;
+    and the schedule model runs (it is what DESIGN §7 item 3 quotes)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("async_lockstep_model", os.path.join(ROOT, "experiments", "r4", "async_lockstep_model.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    assert M.check_machine(n_chains=4, n_transitions=10, D=8, eps=0.35, target="funnel") > 300
+    assert M.check_machine(n_chains=2, n_transitions=6, D=6, eps=1.2, target="funnel") > 10      # short, mostly divergent trees
+    assert M.check_machine(n_chains=3, n_transitions=8, D=16, eps=0.6, target="iso") > 100
+    h = R.Hamiltonian([1.0] * 8, R.funnel, 8)
+
+    def factory():
+        return [M.GroupMachine(7, g, h, 0.3, [0.1 * (g + 1)] * 8, 5) for g in range(4)]
+    r = M.simulate_wave(factory, 4, 0)
+    assert r["transitions"] == 5 and r["chain_leapfrogs"] > 0 and r["today"] > 0 and r["async_"] > 0
