@@ -128,6 +128,7 @@ struct Ctx : CtxBase {
   T *st_accrate = nullptr, *st_logdens = nullptr, *st_H = nullptr, *st_Herr = nullptr, *st_maxHerr = nullptr;
   // accumulators
   long long *acc_nsteps = nullptr, *acc_ndiv = nullptr;
+  long long *work_prev = nullptr, *work_last = nullptr;  // Σ n_steps before / of the last k_nuts launch (AHMC_NUTS_ORDER_REFRESH)
   T *acc_sum = nullptr, *acc_sumsq = nullptr;
   T* acc_energy = nullptr;  // (5, N): n, E_prev, Σ(ΔE)², mean(E), M2(E) over the kept transitions (EBFMI)
   int64_t acc_ntrans = 0;
@@ -229,7 +230,7 @@ struct Ctx : CtxBase {
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
                     dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C, ext_gstage, ext_lpstage,
-                    dn_P, dn_R, dn_S2, dn_ptcur, da_tab};
+                    dn_P, dn_R, dn_S2, dn_ptcur, da_tab, work_prev, work_last};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending, &ev_pending_warm})
@@ -504,15 +505,22 @@ int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
   return AHMC_OK;
 }
 
+__global__ __launch_bounds__(256) void k_work_since(const long long* __restrict__ acc, const long long* __restrict__ prev, long long* __restrict__ out,
+                                                    int64_t N) {  // Σ n_steps a chain has done since `prev` was taken
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = acc[i] - prev[i];
+}
+
 // chain dispatch order of k_nuts (see k_order_* in ahmc_kernels.hpp): asynchronous on the stream
 template <class T>
-int build_order(Ctx<T>* c, int by_work) {
+int build_order(Ctx<T>* c, int by_work, const long long* work = nullptr) {
+  if (!work) work = c->acc_nsteps;
   if (!c->order_hist) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->order_hist), 65536 * sizeof(unsigned)));
   HIPCHK(hipMemsetAsync(c->order_hist, 0, 65536 * sizeof(unsigned), c->stream));
   const unsigned grid = (unsigned)((c->N + 255) / 256);
-  hipLaunchKernelGGL((k_order_hist<T>), dim3(grid), dim3(256), 0, c->stream, c->eps_nom, c->acc_nsteps, by_work, c->order_hist, c->N);
+  hipLaunchKernelGGL((k_order_hist<T>), dim3(grid), dim3(256), 0, c->stream, c->eps_nom, work, by_work, c->order_hist, c->N);
   hipLaunchKernelGGL((k_order_scan<unsigned>), dim3(1), dim3(1024), 0, c->stream, c->order_hist);
-  hipLaunchKernelGGL((k_order_scatter<T>), dim3(grid), dim3(256), 0, c->stream, c->eps_nom, c->acc_nsteps, by_work, c->order_hist, c->order, c->N);
+  hipLaunchKernelGGL((k_order_scatter<T>), dim3(grid), dim3(256), 0, c->stream, c->eps_nom, work, by_work, c->order_hist, c->order, c->N);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -1650,9 +1658,30 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
           if (rc1) return rc1;
           dev_dst = c->stage[slot];
         }
+        // AHMC_NUTS_ORDER_REFRESH=1 (opt-in, round 4 experiment): the dispatch order of every launch from the
+        // work of the launch BEFORE it alone — a chain's tree sizes stay what they are for ≈ 50 transitions, so on heavy-tailed
+        // targets the last launch predicts the next one where a total over the whole run does not (trace model: cfg3 in 16 launches
+        // of 62 transitions 3.80 against 5.41 units, and 5.35 with the order of the first launch kept, which is what happens today)
+        const char* orf = getenv("AHMC_NUTS_ORDER_REFRESH");
+        const bool order_refresh = orf && atoi(orf) != 0 && !dense_engine(c) && !c->eps_scalar;
+        if (order_refresh) {
+          if (!c->work_prev) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->work_prev), sizeof(long long) * (size_t)c->N));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->work_last), sizeof(long long) * (size_t)c->N));
+          }
+          HIPCHK(hipMemcpyAsync(c->work_prev, c->acc_nsteps, sizeof(long long) * (size_t)c->N, hipMemcpyDeviceToDevice, c->stream));
+        }
         int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, true,
                                  (int)k, dev_dst);
         if (rc) return rc;
+        if (order_refresh && k >= 4) {
+          hipLaunchKernelGGL(k_work_since, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->acc_nsteps, c->work_prev, c->work_last, (int64_t)c->N);
+          HIPCHK(hipGetLastError());
+          rc = build_order(c, (int)k, c->work_last);
+          if (rc) return rc;
+          c->order_valid = true;
+          c->order_from_work = true;
+        }
         if (via_stage) {
           HIPCHK(hipEventRecord(c->stage_ready[slot], c->stream));
           // the PREVIOUS batch's draws go to the host while this batch computes (a copy to pageable memory blocks the

@@ -82,3 +82,27 @@ for name, key in (("true totals", -tot), ("eps", eps)):
         ww = np.concatenate([w1, w4])
         ms = makespan(ww, N // 16)
         print(f"heaviest {x:4.0%} by {name:11s} alone in their waves: makespan/ideal {ms / (Wd.sum() * 1.5 / 4 / (N // 16)):.2f}  fill {ww.sum() / (N // 16 * ms):.3f}")
+
+# several launches: which work orders launch b?  the first launch's (what the engine does today), everything so far, the launch before
+print()
+ideal = Wd.sum() * 1.5 / 4 / (N // 16)
+for k in (1, 2, 4, 8, 16, 32):
+    L = n_dr // k
+    res = {}
+    for mode in ("first launch's work (today)", "cumulative work", "the launch before"):
+        o = np.argsort(eps)
+        tot_ms = 0
+        cum = np.zeros(N)
+        for b in range(k):
+            W = Wd[b * L:(b + 1) * L]
+            tot_ms += makespan(wave_work(o, W), N // 16)
+            cum += W.sum(0)
+            if mode.startswith("first"):
+                if b == 0:
+                    o = np.argsort(-W.sum(0))
+            elif mode.startswith("cumulative"):
+                o = np.argsort(-cum)
+            else:
+                o = np.argsort(-W.sum(0))
+        res[mode] = tot_ms / ideal
+    print(f"{k:3d} launches of {L:4d}: " + "  ".join(f"{m}: {v:.2f}" for m, v in res.items()))
