@@ -1642,7 +1642,11 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         // launch (no per-transition barrier; see the note on tree-size tails in ahmc_nuts.hpp)
         // (split the remaining transitions evenly: 50 = 13+13+12+12, not 16+16+16+2 — a short
         // last batch would pay the whole tree-size tail for two transitions)
-        const int64_t left = n_samples - i + 1, nb_left = (left + batch - 1) / batch;
+        // AHMC_NUTS_DRAW_BATCH=n (experiments): transitions per launch of the SAMPLING phase only (AHMC_NUTS_BATCH also shortens the
+        // warm-up's launches, which on the funnel costs more than it gives: its tree sizes are still moving with the step sizes)
+        static const int64_t draw_batch_env = getenv("AHMC_NUTS_DRAW_BATCH") ? atoll(getenv("AHMC_NUTS_DRAW_BATCH")) : 0;
+        const int64_t dbatch = draw_batch_env > 0 ? draw_batch_env : batch;
+        const int64_t left = n_samples - i + 1, nb_left = (left + dbatch - 1) / dbatch;
         int64_t k = (left + nb_left - 1) / nb_left;
         // AHMC_NUTS_FIRST_BATCH=n (experiments; default off): a short first launch while the dispatch order is still the one by
         // step size, so that everything after it is scheduled by measured work (order_by_work below)
