@@ -11,7 +11,7 @@ import bench as B
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import build_oracle
 lib = A.CLib(build_oracle.build())
-cfg = B.CONFIGS["cfg3"]
+cfg = B.CONFIGS[os.environ.get("CFG", "cfg3")]  # CFG=cfg2: the iso Gaussian of the headline config
 N = int(os.environ.get("N", 4096)); n_ad = int(os.environ.get("ADAPT", 1000)); n_dr = int(os.environ.get("DRAWS", 1000))
 eng, kernel = B.build_engine(A, lib, cfg, N, cfg["seed"], 0)
 t = time.time()
