@@ -786,6 +786,18 @@ class Engine:
         buf = (C.c_char * capi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._call("ahmc_comm_init", buf, int(n_ranks), int(rank))
 
+    def comm_info(self) -> dict:
+        """what the communicator's own all-reduces reported when it was attached (ahmc_comm_info)"""
+        v = [C.c_int64() for _ in range(4)]
+        self._call("ahmc_comm_info", *[C.byref(x) for x in v])
+        return dict(zip(("ranks_seen", "chains_total", "chains_min", "chains_max"), (x.value for x in v)))
+
+    def reserve(self, kernel: "HMCKernel", n_samples: int):
+        """announce a sampling run of n_samples transitions: its launch buffers are reserved now (ahmc_sample_reserve)"""
+        if not self._external:
+            k = kernel.cfg()
+            self._call("ahmc_sample_reserve", C.byref(k), int(n_samples))
+
     def gather_moments(self) -> dict:
         mean, var = np.empty(self.D), np.empty(self.D)
         n, tot, ndiv = C.c_int64(), C.c_int64(), C.c_int64()

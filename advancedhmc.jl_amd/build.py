@@ -180,6 +180,30 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def _include_closure(source: str, dirs=()) -> bytes:
+    """The bytes of `source` and of every file it #includes with quotes, transitively (resolved next to the including file,
+    then in `dirs`): what a content-keyed cache of a user's density must cover — editing a header the user's file includes
+    has to rebuild the plugin / code object, not silently bind the stale one.  System headers (<…>) are the toolchain's."""
+    import re
+
+    seen, out, todo = set(), [], [os.path.abspath(source)]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.add(f)
+        data = open(f, "rb").read()
+        out.append(f.encode() + b"\0" + data)
+        for inc in re.findall(rb'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', data, flags=re.M):
+            name = inc.decode(errors="replace")
+            for base in (os.path.dirname(f), *dirs):
+                cand = os.path.abspath(os.path.join(base, name))
+                if os.path.exists(cand):
+                    todo.append(cand)
+                    break
+    return b"\0".join(sorted(out))
+
+
 def build_target_plugin(source: str, dtype, G: int, E: int, n_params: int = -1, force: bool = False, verbose: bool = False) -> str:
     """Compile a user log-density (a header defining `ahmc_user::logdensity<T, G, E>`, contract in include/ahmc_user_target.h)
     INTO the engine's trajectory kernels for one element type and one thread geometry: ahmc_inst.hip with TK = 4 → a shared
@@ -194,7 +218,7 @@ def build_target_plugin(source: str, dtype, G: int, E: int, n_params: int = -1, 
     tname = {"float32": "float", "float64": "double"}[np.dtype(dtype).name]
     kd = source_digest()
     h = hashlib.sha256()
-    for part in (open(source, "rb").read(), kd.encode(), tname.encode(), f"{G},{E},{n_params}".encode(), " ".join(FLAGS).encode(),
+    for part in (_include_closure(source, (INCLUDE, CSRC)), open(os.path.join(INCLUDE, "ahmc_user_target.h"), "rb").read(), kd.encode(), tname.encode(), f"{G},{E},{n_params}".encode(), " ".join(FLAGS).encode(),
                  open(os.path.join(CSRC, "ahmc_kernels.hpp"), "rb").read(), open(os.path.join(CSRC, "ahmc_inst.hpp"), "rb").read()):
         h.update(part)
     out_dir = os.path.join(OBJ, "plugins")
@@ -226,7 +250,7 @@ def build_code_object(source: str, force: bool = False) -> str:
     """hipcc --genco of a file of user KERNELS (ahmc_set_target_kernel) → a gfx950 code object for hipModuleLoad; cached
     outside the repository by content."""
     source = os.path.abspath(source)
-    h = hashlib.sha256(open(source, "rb").read()).hexdigest()[:20]
+    h = hashlib.sha256(_include_closure(source, (INCLUDE,))).hexdigest()[:20]
     out_dir = os.path.join(OBJ, "kernels")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, f"{os.path.splitext(os.path.basename(source))[0]}_{h}.hsaco")

@@ -142,6 +142,7 @@ struct Ctx : CtxBase {
   bool adapting = false;            // an adaptor is initialised and has not seen its last iteration yet
   T* znorm = nullptr;  // standard normals of the momentum draws of one k_nuts launch
   size_t znorm_elems = 0;
+  int64_t znorm_cap_trans = 0;  // > 0: the device could not hold the normals of a full batch; launches are capped at this many transitions
   int32_t* redo = nullptr;  // per-chain "redo in the log domain" flags of the NUTS fast pass
   int nuts_blocks = 0;
   // static multinomial
@@ -166,6 +167,7 @@ struct Ctx : CtxBase {
   void* comm = nullptr;
   bool comm_owned = false;
   int comm_ranks = 1, comm_rank = 0;
+  int64_t comm_seen = 1, comm_chains_total = 0, comm_chains_min = 0, comm_chains_max = 0;  // what the communicator's own all-reduces said (comm_probe)
   double* red = nullptr;  // device scratch of the cross-chain reductions
   size_t red_elems = 0;
   int n_cu = 256;
@@ -598,7 +600,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.n_trans = n_trans;
   p.znorm = c->znorm;
   p.samples_out = samples_dev;
-  static const bool no_order = getenv("AHMC_NUTS_NO_ORDER") != nullptr;
+  const bool no_order = getenv("AHMC_NUTS_NO_ORDER") != nullptr;  // (read per call: the tests toggle it)
   static const bool order_adapt = getenv("AHMC_NUTS_ORDER_ADAPT") ? atoi(getenv("AHMC_NUTS_ORDER_ADAPT")) != 0 : false;  // measured: no gain (a per-transition launch lasts as long as its longest tree)
   if ((n_trans > 1 || order_adapt) && !c->eps_scalar && !no_order) {
     // sampling phase: dispatch the chains in ascending step size (longest expected trees first); the
@@ -673,7 +675,7 @@ int64_t nuts_batch(Ctx<T>* c) {
   // transitions per launch of k_nuts (sampling AND fused warm-up): more = less tree-size tail per launch (round 1, cfg2:
   // 8/16/32/64 -> 1.35/1.39/1.42/1.43e9 leapfrog/s); the pre-generated momentum normals take batch * D * N elements — the
   // caps and what they were measured against are at the two return statements below
-  static const int batch_env = getenv("AHMC_NUTS_BATCH") ? atoi(getenv("AHMC_NUTS_BATCH")) : 0;
+  const int batch_env = getenv("AHMC_NUTS_BATCH") ? atoi(getenv("AHMC_NUTS_BATCH")) : 0;  // (read per call: the tests toggle it)
   if (batch_env > 0) return batch_env;
   if (dense_engine(c)) {
     // dense engine: chains run asynchronously through the batch and only its end has idle chains, so longer is better.  Three
@@ -701,8 +703,41 @@ int64_t nuts_batch(Ctx<T>* c) {
   // cfg3 (D = 32: 16 MiB of normals per transition; heavy-tailed funnel trees): 256 per launch 1.51e9, 512 1.63e9 — the count is
   // bounded by the bytes only (cfg2: 256, cfg3: 1 024, cfg5: 32 — where 50 / 100 per launch measured slower: 6.44 / 6.30e7
   // against 6.58e7, the dispatch order is re-sorted by measured work between launches).
-  const int64_t cap = (int64_t)(16ull << 30) / (int64_t)(sizeof(T) * c->D * c->N);
+  // Round 4: the 16 GiB are also bounded by what is free on THIS device now (half of it; the buffer this context already holds
+  // counts as free) — several contexts on one GPU or a part with less than 288 GB get shorter launches instead of an
+  // out-of-memory error — and by what reserve_normals could actually get (znorm_cap_trans).
+  size_t budget = 16ull << 30, free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<size_t>(budget, (free_b + c->znorm_elems * sizeof(T)) / 2);
+  (void)hipGetLastError();
+  int64_t cap = (int64_t)budget / (int64_t)(sizeof(T) * c->D * c->N);
+  if (c->znorm_cap_trans > 0) cap = std::min<int64_t>(cap, c->znorm_cap_trans);
   return std::max<int64_t>(1, std::min<int64_t>(1024, cap));
+}
+
+// The momentum normals of a launch of `n_trans` transitions: make sure the buffer holds them, BEFORE the launches of a run
+// (a 16 GiB hipMalloc inside the first launch of a timed run was seen to take up to a second).  Out of memory is not an
+// error: the launch length is halved until the buffer fits, and the context remembers the cap.
+template <class T>
+int reserve_normals(Ctx<T>* c, int64_t n_trans) {
+  if (n_trans < 1) n_trans = 1;
+  if (c->znorm_cap_trans > 0) n_trans = std::min<int64_t>(n_trans, c->znorm_cap_trans);
+  size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
+  if (need <= c->znorm_elems) return AHMC_OK;
+  if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
+  c->znorm = nullptr;
+  c->znorm_elems = 0;
+  for (;;) {
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->znorm), need * sizeof(T));
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    c->znorm = nullptr;
+    if (e != hipErrorOutOfMemory || n_trans <= 1) return fail(c, AHMC_ERR_RUNTIME, std::string("momentum normals: hipMalloc: ") + hipGetErrorString(e));
+    n_trans = (n_trans + 1) / 2;
+    c->znorm_cap_trans = n_trans;
+    need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
+  }
+  c->znorm_elems = need;
+  return AHMC_OK;
 }
 
 // nsteps(τ) for FixedIntegrationTime(λ) (src/trajectory.jl:241-243): max(1, floor(λ / nominal step size)).  Needs ONE
@@ -1178,6 +1213,8 @@ void* ahmc_stream(ahmc_ctx* ctx) {
 int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params) {
   FOR_CTX_MUT(ctx, {
     int64_t need = 0;
+    if (kind == AHMC_TARGET_PLUGIN || kind == AHMC_TARGET_KERNEL)
+      return fail(c, AHMC_ERR_ARGUMENT, "set_target: use ahmc_set_target_plugin / ahmc_set_target_kernel");
     switch (kind) {
       case AHMC_TARGET_ISO_GAUSS: case AHMC_TARGET_FUNNEL: case AHMC_TARGET_HIER_GAUSS: case AHMC_TARGET_EXTERNAL: need = 0; break;
       case AHMC_TARGET_DIAG_GAUSS: need = 2 * c->D; break;
@@ -1187,15 +1224,21 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
     if (kind == AHMC_TARGET_FUNNEL && c->D < 2) return fail(c, AHMC_ERR_ARGUMENT, "funnel needs D >= 2");
     if (kind == AHMC_TARGET_HIER_GAUSS && c->D < 3) return fail(c, AHMC_ERR_ARGUMENT, "hier_gauss needs D >= 3");
     if (n_params != need || (need > 0 && !params)) return fail(c, AHMC_ERR_ARGUMENT, "set_target: wrong parameter count for this family");
-    if (c->tparams) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tparams)); c->tparams = nullptr; }
+    // the new parameters go into a buffer of their own and replace the old ones only once they are on the device: a failure
+    // on the way leaves the context with its previous target intact
+    T* np_dev = nullptr;
     if (need > 0) {
-      int rc = dev_alloc(c, &c->tparams, (size_t)need);
+      int rc = dev_alloc(c, &np_dev, (size_t)need);
       if (rc) return rc;
-      HIPCHK(hipMemcpyAsync(c->tparams, params, sizeof(T) * need, hipMemcpyDefault, c->stream));
+      if (hipMemcpyAsync(np_dev, params, sizeof(T) * need, hipMemcpyDefault, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(np_dev);
+        return fail(c, AHMC_ERR_RUNTIME, std::string("set_target: copying the parameters failed: ") + hipGetErrorString(hipGetLastError()));
+      }
+    } else {
       HIPCHK(hipStreamSynchronize(c->stream));
     }
-    if (kind == AHMC_TARGET_PLUGIN || kind == AHMC_TARGET_KERNEL)
-      return fail(c, AHMC_ERR_ARGUMENT, "set_target: use ahmc_set_target_plugin / ahmc_set_target_kernel");
+    if (c->tparams) (void)hipFree(c->tparams);
+    c->tparams = np_dev;
     c->target_kind = kind;
     c->have_point = false;
     return dn_refresh_fused(c);
@@ -1229,17 +1272,18 @@ int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void*
       return false;
     };
     if (!hip_ok(hipStreamSynchronize(c->stream), "set_target_plugin: hipStreamSynchronize")) return AHMC_ERR_RUNTIME;
-    if (c->tparams) {
-      if (!hip_ok(hipFree(c->tparams), "set_target_plugin: hipFree")) return AHMC_ERR_RUNTIME;
-      c->tparams = nullptr;
-    }
+    T* np_dev = nullptr;  // (committed below, after everything that can fail: the previous target stays whole until then)
     if (n_params > 0) {
-      int rc = dev_alloc(c, &c->tparams, (size_t)n_params);
+      int rc = dev_alloc(c, &np_dev, (size_t)n_params);
       if (rc) { dlclose(dl); return rc; }
-      if (!hip_ok(hipMemcpyAsync(c->tparams, params, sizeof(T) * n_params, hipMemcpyDefault, c->stream), "set_target_plugin: hipMemcpyAsync") ||
-          !hip_ok(hipStreamSynchronize(c->stream), "set_target_plugin: hipStreamSynchronize"))
+      if (!hip_ok(hipMemcpyAsync(np_dev, params, sizeof(T) * n_params, hipMemcpyDefault, c->stream), "set_target_plugin: hipMemcpyAsync") ||
+          !hip_ok(hipStreamSynchronize(c->stream), "set_target_plugin: hipStreamSynchronize")) {
+        (void)hipFree(np_dev);
         return AHMC_ERR_RUNTIME;
+      }
     }
+    if (c->tparams) (void)hipFree(c->tparams);
+    c->tparams = np_dev;
     if (c->plugin_dl) dlclose(c->plugin_dl);  // (the stream is idle: nothing of the previous plugin's code is running)
     c->plugin_dl = dl;
     c->plugin_ops = static_cast<const TargetOps<T>*>(d->ops);
@@ -1514,19 +1558,6 @@ int32_t ahmc_adaptor_init(ahmc_ctx* ctx, int32_t kind, double delta, int32_t ini
     if (kind < AHMC_ADAPT_NONE || kind > AHMC_ADAPT_STAN) return fail(c, AHMC_ERR_ARGUMENT, "adaptor_init: unknown adaptor kind");
     int rc = adaptor_init(c, kind, delta, init_buffer, term_buffer, window_size);
     if (rc) return rc;
-    // An adaptor announces a sampling run: reserve the buffer of its momentum normals now (setup), not inside the first
-    // launch of the run — a 16 GiB hipMalloc was seen to take up to a second now and then (one of three bench runs at
-    // 2.06e9 instead of 2.65e9 with the whole second in the warm-up phase's wall time, none of it in the kernels).
-    if (kind != AHMC_ADAPT_NONE && !dense_engine(c) && c->target_kind != AHMC_TARGET_EXTERNAL) {
-      const size_t need = (size_t)nuts_batch(c) * (size_t)c->D * (size_t)c->N;
-      if (need > c->znorm_elems) {
-        if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
-        c->znorm = nullptr;
-        c->znorm_elems = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->znorm), need * sizeof(T)));
-        c->znorm_elems = need;
-      }
-    }
     return AHMC_OK;
   });
 }
@@ -1563,6 +1594,14 @@ int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t wind
 static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_first, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup,
                                 void* samples_out);
 
+int32_t ahmc_sample_reserve(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples) {
+  FOR_CTX_MUT(ctx, {
+    if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample_reserve: cfg is NULL");
+    if (n_samples < 1 || !cfg->nuts || dense_engine(c) || c->target_kind == AHMC_TARGET_EXTERNAL) return AHMC_OK;  // nothing to reserve ahead of time
+    return reserve_normals(c, std::min<int64_t>(nuts_batch(c), n_samples));
+  });
+}
+
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup, void* samples_out) {
   return sample_from_impl(ctx, cfg, 1, n_samples, n_adapts, drop_warmup, samples_out);
 }
@@ -1598,7 +1637,13 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
       so_on_device = hipPointerGetAttributes(&at, so) == hipSuccess && at.type == hipMemoryTypeDevice;
       (void)hipGetLastError();
     }
-    const int64_t batch = nuts_batch(c);
+    int64_t batch = nuts_batch(c);
+    if (cfg->nuts && !dense_engine(c) && c->target_kind != AHMC_TARGET_EXTERNAL && n_samples >= i_first) {
+      // the normals of this call's longest launch (lazily, bounded by the call's own length; ahmc_sample_reserve does it ahead of time)
+      int rc0 = reserve_normals(c, std::min<int64_t>(batch, n_samples - i_first + 1));
+      if (rc0) return rc0;
+      if (c->znorm_cap_trans > 0) batch = std::min<int64_t>(batch, c->znorm_cap_trans);
+    }
     // Dispatch order by measured work: a better predictor of a chain's tree sizes than its step size is what it
     // actually did — Σ n_steps per chain of the previous sampling call (still in the accumulators here) or of
     // this call's first batch (below).  Counting sort on the stream, no host synchronisation.
@@ -1644,13 +1689,13 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         // last batch would pay the whole tree-size tail for two transitions)
         // AHMC_NUTS_DRAW_BATCH=n (experiments): transitions per launch of the SAMPLING phase only (AHMC_NUTS_BATCH also shortens the
         // warm-up's launches, which on the funnel costs more than it gives: its tree sizes are still moving with the step sizes)
-        static const int64_t draw_batch_env = getenv("AHMC_NUTS_DRAW_BATCH") ? atoll(getenv("AHMC_NUTS_DRAW_BATCH")) : 0;
+        const int64_t draw_batch_env = getenv("AHMC_NUTS_DRAW_BATCH") ? atoll(getenv("AHMC_NUTS_DRAW_BATCH")) : 0;
         const int64_t dbatch = draw_batch_env > 0 ? draw_batch_env : batch;
         const int64_t left = n_samples - i + 1, nb_left = (left + dbatch - 1) / dbatch;
         int64_t k = (left + nb_left - 1) / nb_left;
         // AHMC_NUTS_FIRST_BATCH=n (experiments; default off): a short first launch while the dispatch order is still the one by
         // step size, so that everything after it is scheduled by measured work (order_by_work below)
-        static const int first_batch = getenv("AHMC_NUTS_FIRST_BATCH") ? atoi(getenv("AHMC_NUTS_FIRST_BATCH")) : 0;
+        const int first_batch = getenv("AHMC_NUTS_FIRST_BATCH") ? atoi(getenv("AHMC_NUTS_FIRST_BATCH")) : 0;
         if (first_batch >= 4 && !c->order_from_work && !c->eps_scalar && left > 2 * (int64_t)first_batch) k = std::min<int64_t>(k, first_batch);
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
         T* dst = so ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
@@ -1729,7 +1774,7 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         i += k;
         continue;
       }
-      static const int dense_pool_env = getenv("AHMC_DENSE_POOL") ? atoi(getenv("AHMC_DENSE_POOL")) : 1;
+      const int dense_pool_env = getenv("AHMC_DENSE_POOL") ? atoi(getenv("AHMC_DENSE_POOL")) : 1;  // (per call, as dn_nuts_transition reads it)
       if (adapting && fused_adapt && dense_pool_env != 0 && cfg->nuts && dense_engine(c) && c->adapt_kind == AHMC_ADAPT_STEPSIZE &&
           cfg->criterion == AHMC_TC_GENERALISED && (cfg->sampler == AHMC_TS_MULTINOMIAL || cfg->sampler == AHMC_TS_SLICE) &&
           c->integ_kind != AHMC_INTEGRATOR_TEMPERED && cfg->refresh_alpha == 0 && c->target_kind != AHMC_TARGET_EXTERNAL &&
@@ -1913,6 +1958,17 @@ int32_t ahmc_comm_init(ahmc_ctx* ctx, const void* id, int32_t n_ranks, int32_t r
 
 int32_t ahmc_set_comm(ahmc_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank) {
   FOR_CTX_MUT(ctx, { return set_comm(c, nccl_comm, (int)n_ranks, (int)rank); });
+}
+
+int32_t ahmc_comm_info(ahmc_ctx* ctx, int64_t* ranks_seen, int64_t* chains_total, int64_t* chains_min, int64_t* chains_max) {
+  FOR_CTX(ctx, {
+    const bool multi = c->comm && c->comm_ranks > 1;
+    if (ranks_seen) *ranks_seen = multi ? c->comm_seen : 1;
+    if (chains_total) *chains_total = multi ? c->comm_chains_total : c->N;
+    if (chains_min) *chains_min = multi ? c->comm_chains_min : c->N;
+    if (chains_max) *chains_max = multi ? c->comm_chains_max : c->N;
+    return AHMC_OK;
+  });
 }
 
 int32_t ahmc_gather_moments(ahmc_ctx* ctx, double* mean, double* var, int64_t* n_draws, int64_t* total_n_steps, int64_t* n_divergent) {

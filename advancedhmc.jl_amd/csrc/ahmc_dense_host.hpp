@@ -504,6 +504,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");
   if (adapt_i0 >= 0 && !(criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED && refresh_alpha == 0))
     return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: the in-kernel StepSizeAdaptor needs the point-pool kernel (GeneralisedNoUTurn, untempered, full refreshment)");
+  if (adapt_i0 >= 0 && getenv("AHMC_DENSE_POOL") && atoi(getenv("AHMC_DENSE_POOL")) == 0)  // (the caller decides from the same variable; checked again here
+    return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: AHMC_DENSE_POOL=0 selects the copying tree kernel, which has no in-kernel StepSizeAdaptor");  // because a silent unadapted warm-up is the alternative)
   if (refresh_alpha != 0 && n_trans > 1) {
     // a partially refreshed momentum depends on the momentum the previous transition ended with, so the batch's
     // momenta cannot be drawn up front: one transition per batch
@@ -628,7 +630,9 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     h.active = 0;
     if (NP == 1) { h.list = nullptr; h.n_list = c->N; }
     else {
-      const int64_t lo = (int64_t)k * (c->N / NP), n = k == NP - 1 ? c->N - lo : c->N / NP;
+      // (no pipeline takes more than `per` chains — the capacity of its two ping-pong lists: with floor(N / NP) each and the
+      // remainder on the last one, N % NP >= 2 overflowed the last pipeline's list into its own other half)
+      const int64_t lo = std::min<int64_t>((int64_t)k * per, c->N), n = std::min<int64_t>(per, c->N - lo);
       hipLaunchKernelGGL((k_d_iota<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, h.lists + per, (int)lo, n);  // (second buffer: the first compaction writes the first)
       h.list = h.lists + per;
       h.n_list = n;

@@ -75,6 +75,40 @@ int comm_release(Ctx<T>* c) {
   return AHMC_OK;
 }
 
+// device scratch of `n` doubles for the reductions below
+template <class T>
+int red_buf(Ctx<T>* c, size_t n) {
+  if (n <= c->red_elems) return AHMC_OK;
+  if (c->red) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->red)); c->red = nullptr; c->red_elems = 0; }
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->red), n * sizeof(double)));
+  c->red_elems = n;
+  return AHMC_OK;
+}
+
+// What the communicator itself says about the world (ahmc_comm_info): Σ 1 and Σ N over the ranks (one all-reduce, sum) and the
+// largest / smallest N (one all-reduce of (N, −N), max).  Run when a communicator is attached: it proves every rank joined, and
+// tells ahmc_gather_state (equal counts only) and the pooled estimator what they are dealing with before any data moves.
+template <class T>
+int comm_probe(Ctx<T>* c) {
+  c->comm_seen = 1; c->comm_chains_total = c->comm_chains_min = c->comm_chains_max = c->N;
+  if (!c->comm || c->comm_ranks <= 1) return AHMC_OK;
+  int rc = red_buf(c, 4);
+  if (rc) return rc;
+  double v[4] = {1.0, (double)c->N, (double)c->N, -(double)c->N};
+  HIPCHK(hipMemcpyAsync(c->red, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(rccl_api().AllReduce(c->red, c->red, 2, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));
+  NCCLCHK(rccl_api().AllReduce(c->red + 2, c->red + 2, 2, ncclDouble, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream));
+  HIPCHK(hipMemcpyAsync(v, c->red, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->comm_seen = (int64_t)(v[0] + 0.5);
+  c->comm_chains_total = (int64_t)(v[1] + 0.5);
+  c->comm_chains_max = (int64_t)(v[2] + 0.5);
+  c->comm_chains_min = (int64_t)(-v[3] + 0.5);
+  if (c->comm_seen != c->comm_ranks)
+    return fail(c, AHMC_ERR_RUNTIME, "communicator: " + std::to_string(c->comm_seen) + " rank(s) answered the all-reduce, " + std::to_string(c->comm_ranks) + " were announced");
+  return AHMC_OK;
+}
+
 template <class T>
 int comm_init(Ctx<T>* c, const void* id, int n_ranks, int rank) {
   if (!id) return fail(c, AHMC_ERR_ARGUMENT, "comm_init: id is NULL");
@@ -91,7 +125,7 @@ int comm_init(Ctx<T>* c, const void* id, int n_ranks, int rank) {
   c->comm_owned = true;
   c->comm_ranks = n_ranks;
   c->comm_rank = rank;
-  return AHMC_OK;
+  return comm_probe(c);
 }
 
 template <class T>
@@ -103,17 +137,7 @@ int set_comm(Ctx<T>* c, void* comm, int n_ranks, int rank) {
   c->comm = comm;
   c->comm_ranks = comm ? n_ranks : 1;
   c->comm_rank = comm ? rank : 0;
-  return AHMC_OK;
-}
-
-// device scratch of `n` doubles for the reductions below
-template <class T>
-int red_buf(Ctx<T>* c, size_t n) {
-  if (n <= c->red_elems) return AHMC_OK;
-  if (c->red) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->red)); c->red = nullptr; c->red_elems = 0; }
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->red), n * sizeof(double)));
-  c->red_elems = n;
-  return AHMC_OK;
+  return comm_probe(c);
 }
 
 // ---- moments_reduce (SURVEY §7 kernel list): per-dimension Σ_c Σθ, Σ_c Σθ² and the counters, in double ----------
@@ -189,16 +213,11 @@ int gather_state(Ctx<T>* c, void* theta_all) {
   if (!theta_all) return fail(c, AHMC_ERR_ARGUMENT, "gather_state: theta_all is NULL");
   const size_t n = (size_t)c->D * (size_t)c->N;
   if (c->comm && c->comm_ranks > 1) {
-    // every rank must contribute the same count (ncclAllGather with unequal counts hangs or corrupts): one all-reduce of
-    // (N, −N) with max tells every rank the largest and the smallest N of the communicator
-    int rc = red_buf(c, 2);
-    if (rc) return rc;
-    double nn[2] = {(double)c->N, -(double)c->N};
-    HIPCHK(hipMemcpyAsync(c->red, nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(rccl_api().AllReduce(c->red, c->red, 2, ncclDouble, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream));
-    HIPCHK(hipMemcpyAsync(nn, c->red, sizeof(nn), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (nn[0] != -nn[1]) return fail(c, AHMC_ERR_ARGUMENT, "gather_state: the ranks hold different numbers of chains (all ranks must hold the same N)");
+    // every rank must contribute the same count (ncclAllGather with unequal counts hangs or corrupts): the largest and the
+    // smallest N of the communicator were measured when it was attached (comm_probe)
+    if (c->comm_chains_min != c->comm_chains_max)
+      return fail(c, AHMC_ERR_ARGUMENT, "gather_state: the ranks hold different numbers of chains (" + std::to_string(c->comm_chains_min) + " … " +
+                                            std::to_string(c->comm_chains_max) + "; all ranks must hold the same N)");
     NCCLCHK(rccl_api().AllGather(c->th, theta_all, n, sizeof(T) == 8 ? ncclDouble : ncclFloat, static_cast<ncclComm_t>(c->comm), c->stream));
   } else {
     HIPCHK(hipMemcpyAsync(theta_all, c->th, n * sizeof(T), hipMemcpyDefault, c->stream));

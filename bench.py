@@ -99,7 +99,7 @@ def counters_at_head(config):
     return c, d.get("source", "profiles/counters_at_head.json")
 
 
-def build_engine(A, lib, cfg, N, seed, chain_offset, stream=0, device=0, dtype=np.float64):
+def build_engine(A, lib, cfg, N, seed, chain_offset, stream=0, device=0, dtype=np.float64, n_reserve=0):
     """sample_init + find_good_stepsize + adaptor: the untimed setup of the reference's call sequence
     (src/abstractmcmc.jl:131-166: make_step_size → find_good_stepsize, make_adaptor, sample_init)"""
     D = cfg["D"]
@@ -128,6 +128,8 @@ def build_engine(A, lib, cfg, N, seed, chain_offset, stream=0, device=0, dtype=n
     else:
         eng.adaptor_init(A.StepSizeAdaptor(0.8, lf))
     kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+    if n_reserve > 0:
+        eng.reserve(kernel, n_reserve)   # setup: the launch buffers of the announced run (ahmc_sample_reserve), not inside its first launch
     return eng, kernel
 
 
@@ -277,7 +279,7 @@ def main():
     dev = f"cuda:{local_rank}"
 
     def make():
-        return build_engine(A, lib, cfg, N, seed, rank * N, stream=stream.cuda_stream, device=local_rank, dtype=np_dtype)
+        return build_engine(A, lib, cfg, N, seed, rank * N, stream=stream.cuda_stream, device=local_rank, dtype=np_dtype, n_reserve=max(n_adapts, n_draws))
 
     def barrier_for(eng):
         def f():

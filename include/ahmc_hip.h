@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHMC_ABI_VERSION 4
+#define AHMC_ABI_VERSION 5
 
 typedef struct ahmc_ctx ahmc_ctx;
 
@@ -332,6 +332,14 @@ int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples
 int32_t ahmc_sample_from(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_first, int64_t n_samples,
                          int64_t n_adapts, int32_t drop_warmup, void* samples_out);
 
+/* Announce a sampling run (no reference counterpart; the reference allocates inside `sample`, src/sampler.jl:159-181):
+ * reserve ahead of time what ahmc_sample / ahmc_sample_from would otherwise allocate inside their first launch — the
+ * momentum normals of a launch of min(AHMC_INFO_NUTS_BATCH, n_samples) NUTS transitions (up to 16 GiB, bounded by half of
+ * the device memory that is free; if even that cannot be had the launch length is halved until it fits and
+ * AHMC_INFO_NUTS_BATCH reports the shorter one).  Optional: without it the first call of a run reserves lazily, for its
+ * own length.  Static-HMC kernels, the step-synchronous engine and ask / tell runs reserve nothing here.         */
+int32_t ahmc_sample_reserve(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples);
+
 /* running accumulators over kept transitions: Σ n_steps (all chains), number of kept
  * transitions, number of divergent transitions, per-chain Σθ and Σθ² (D,N) (may be NULL)     */
 int32_t ahmc_get_accum(ahmc_ctx* ctx, int64_t* total_n_steps, int64_t* n_transitions,
@@ -405,6 +413,12 @@ int32_t ahmc_ext_cancel(ahmc_ctx* ctx);
 int32_t ahmc_comm_unique_id(void* id_out /* AHMC_UNIQUE_ID_BYTES */);
 int32_t ahmc_comm_init(ahmc_ctx* ctx, const void* id, int32_t n_ranks, int32_t rank); /* owned by ctx */
 int32_t ahmc_set_comm(ahmc_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank);  /* caller's; NULL detaches */
+/* What the communicator itself reports — measured by two small all-reduces when the communicator was attached
+ * (ahmc_comm_init / ahmc_set_comm), not taken from the arguments: the number of ranks that joined (Σ 1), the chains of all
+ * ranks (Σ N) and the smallest / largest N of any rank.  A run's record can so prove that n_ranks processes took part;
+ * ahmc_gather_state needs min == max.  Without a communicator: 1, N, N, N.  Any pointer may be NULL.             */
+int32_t ahmc_comm_info(ahmc_ctx* ctx, int64_t* ranks_seen, int64_t* chains_total, int64_t* chains_min,
+                       int64_t* chains_max);
 /* Pooled moments of the kept draws of ALL ranks (the accumulators of ahmc_sample): a device reduction over the
  * chains, one ncclAllReduce of 2·D + 3 doubles, then mean[D], var[D] (host doubles, may be NULL), the number of
  * draws, Σ n_steps and the number of divergent transitions.  Every rank receives the same values.              */

@@ -316,6 +316,8 @@ function sample_device(seed::Integer, h::Hamiltonian, κ::HMCKernel, θ::Matrix{
     cfg = Ref(kernel_cfg(κ))
     n_keep = n_samples - (drop_warmup ? n_adapts : 0)
     out = Array{T}(undef, D, N, n_keep)
+    # ABI v5: announce the run, so that the buffers of its launches are reserved here and not inside the first launch
+    check(z.ctx, ccall((:ahmc_sample_reserve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), z.ctx, cfg, n_samples))
     check(z.ctx, ccall((:ahmc_sample, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{T}),
                        z.ctx, cfg, n_samples, n_adapts, drop_warmup, out))
     check(z.ctx, ccall((:ahmc_sync, LIB), Cint, (Ptr{Cvoid},), z.ctx))
@@ -381,6 +383,13 @@ comm_init!(z::MI355XChains, id::Vector{UInt8}, n_ranks::Integer, rank::Integer) 
 "an ncclComm_t the host already owns (its entry points are resolved from the RCCL copy loaded in this process)"
 set_comm!(z::MI355XChains, comm::Ptr{Cvoid}, n_ranks::Integer, rank::Integer) =
     check(z.ctx, ccall((:ahmc_set_comm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), z.ctx, comm, n_ranks, rank))
+
+"ABI v5: what the communicator itself measured when it was attached — ranks that answered, Σ / min / max of their chain counts."
+function comm_info(z::MI355XChains)
+    seen, tot, lo, hi = Ref{Int64}(0), Ref{Int64}(0), Ref{Int64}(0), Ref{Int64}(0)
+    check(z.ctx, ccall((:ahmc_comm_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), z.ctx, seen, tot, lo, hi))
+    return (ranks_seen=seen[], chains_total=tot[], chains_min=lo[], chains_max=hi[])
+end
 
 "Pooled per-dimension mean / variance of the kept draws of ALL ranks (one ncclAllReduce of 2D+3 doubles)."
 function gather_moments(z::MI355XChains)

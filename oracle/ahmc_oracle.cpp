@@ -2061,6 +2061,14 @@ int32_t ahmc_stan_windows(int32_t init_buffer, int32_t term_buffer, int32_t wind
 static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_first, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup,
                                 void* samples_out);
 
+int32_t ahmc_sample_reserve(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples) {
+  FOR_CTX_MUT(ctx, {
+    (void)n_samples;
+    if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample_reserve: cfg is NULL");
+    return AHMC_OK;  // the CPU checker draws its normals as it goes: nothing to reserve
+  });
+}
+
 int32_t ahmc_sample(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples, int64_t n_adapts, int32_t drop_warmup, void* samples_out) {
   return sample_from_impl(ctx, cfg, 1, n_samples, n_adapts, drop_warmup, samples_out);
 }
@@ -2228,6 +2236,17 @@ int32_t ahmc_set_comm(ahmc_ctx* ctx, void* comm, int32_t n_ranks, int32_t rank) 
 int32_t ahmco_set_allgather(ahmc_ctx* ctx, int (*fn)(const double*, double*, int64_t, void*), void* user, int32_t n_ranks, int32_t rank) {
   FOR_CTX_MUT(ctx, {
     c->xgather = fn; c->xgather_user = user; c->x_ranks = fn ? n_ranks : 1; c->x_rank = fn ? rank : 0;
+    return AHMC_OK;
+  });
+}
+
+int32_t ahmc_comm_info(ahmc_ctx* ctx, int64_t* ranks_seen, int64_t* chains_total, int64_t* chains_min, int64_t* chains_max) {
+  FOR_CTX(ctx, {
+    // (the CPU checker's multi-rank world is the test harness's hook: it reports what it was told, for equal shards)
+    if (ranks_seen) *ranks_seen = c->x_ranks;
+    if (chains_total) *chains_total = c->N * (int64_t)c->x_ranks;
+    if (chains_min) *chains_min = c->N;
+    if (chains_max) *chains_max = c->N;
     return AHMC_OK;
   });
 }
