@@ -222,6 +222,14 @@ __device__ __forceinline__ double leaf_weight_exp(double x) {
 template <bool UNIFORM>
 __device__ __forceinline__ float leaf_weight_exp(float x) { return exp(x); }
 
+// exp(min(0, ℓw)) for the log-domain kernels, through leaf_weight_exp: min(1, W) of the linear-domain kernels, bit for bit
+// (ℓw > 0 gives exactly 1 there as well: W >= 1).  NaN propagates (Julia's min): the compare fails and exp(NaN) = NaN.
+template <class T, bool UNIFORM>
+__device__ __forceinline__ T alpha_from_logweight(T lw) {
+  const T w = leaf_weight_exp<UNIFORM>(lw > T(0) ? T(0) : lw);
+  return w >= T(1) ? T(1) : w;
+}
+
 template <class T> __device__ __forceinline__ T maxabs(T a, T b) { return fabs(a) > fabs(b) ? a : b; }  // :526
 
 // ------------------------------------------------------------------------------------------------

@@ -461,7 +461,12 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           pos_cur += v;
           const T ne = (GENERAL || (FUSE_M0 && nm > 0)) ? cur.lp + cur.lk : ne_leaf;  // neg_energy(z′)
           const T dH = -ne - H0;
-          if constexpr (!LINW) sa_c = exp(jl_min(T(0), -dH));
+          // α′ = exp(min(0, −ΔH)) (:641-643).  Evaluated by the SAME function as the linear-domain kernels' min(1, W) — which is
+          // this value bit for bit there — so that a chain the log-domain redo pass carries through the rest of a launch keeps the
+          // acceptance rates, and with them the dual averaging, of the launch lengths that never hand it over (round 4: a warm-up of
+          // 60 transitions in one launch left the per-iteration path on every chain that had met −ΔH > 600 once — the device
+          // library's exp and the table form differ in the last bit now and then, and dual averaging doubles that every iteration)
+          if constexpr (!LINW) sa_c = alpha_from_logweight<T, (CPW == 1)>(H0 + ne);
           na_c = 1;
           dh_c = dH;
           ck_c = pos_cur;
