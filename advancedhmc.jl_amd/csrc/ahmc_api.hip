@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>  // types only: the entry points are resolved at run time (ahmc_multi_host.hpp)
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -137,6 +138,16 @@ struct Ctx : CtxBase {
   size_t scratch_bytes = 0;
   int* order = nullptr;       // chain order for k_nuts (ascending step size), valid while order_valid
   bool order_valid = false, order_from_work = false;
+  // Launch length of the sampling phase, found by measurement (sample_from_impl): phase 0 nothing measured yet, 1 the start
+  // length is measured, 2 going down, 3 going up, 4 settled.  Reset whenever the step sizes change (the trees change with them).
+  // A length is timed over a GROUP of launches (>= 64 transitions, one host synchronisation at each end).
+  struct DrawSched {
+    int phase = 0; int64_t len = 0, best_len = 0; double best_thr = 0;
+    bool primed = false;            // one unmeasured launch has put the dispatch order on measured work
+    int64_t g_len = 0; int g_left = 0; std::chrono::steady_clock::time_point g_t0;  // the group being timed
+  } sched;
+  long long* work_grp = nullptr;  // the accumulators' Σ n_steps per chain at the start of the group being timed
+  long long* work_sum = nullptr;  // Σ over chains of the group's work (one device word)
   unsigned* order_hist = nullptr;
   AdaptK<T>* adaptk_dev = nullptr;  // k_nuts MODE 3 arguments
   bool adapting = false;            // an adaptor is initialised and has not seen its last iteration yet
@@ -232,7 +243,7 @@ struct Ctx : CtxBase {
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
                     dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C, ext_gstage, ext_lpstage,
-                    dn_P, dn_R, dn_S2, dn_ptcur, da_tab, work_prev, work_last};
+                    dn_P, dn_R, dn_S2, dn_ptcur, da_tab, work_prev, work_last, work_sum, work_grp};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending, &ev_pending_warm})
@@ -511,6 +522,13 @@ __global__ __launch_bounds__(256) void k_work_since(const long long* __restrict_
                                                     int64_t N) {  // Σ n_steps a chain has done since `prev` was taken
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) out[i] = acc[i] - prev[i];
+}
+
+__global__ __launch_bounds__(256) void k_work_sum(const long long* __restrict__ acc, const long long* __restrict__ prev, long long* __restrict__ out, int64_t N) {
+  long long s = 0;  // Σ over chains of the n_steps done since `prev` was taken
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) s += acc[i] - prev[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)s);
 }
 
 // chain dispatch order of k_nuts (see k_order_* in ahmc_kernels.hpp): asynchronous on the stream
@@ -925,7 +943,7 @@ int adapt(Ctx<T>* c, int64_t i, int64_t n_adapts, const T* th_ext = nullptr, con
     hipLaunchKernelGGL((k_adapt_da<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     c->eps_scalar = false;
-    c->order_valid = false;
+    c->order_valid = false; c->sched = {};
   }
   if (has_cov && (do_push || wv_reset)) {
     const T* th = c->th;
@@ -1060,7 +1078,7 @@ int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, in
       c->wv_n += 1;
     }
   }
-  if (has_ss) { c->eps_scalar = false; c->order_valid = false; }
+  if (has_ss) { c->eps_scalar = false; c->order_valid = false; c->sched = {}; }
   if (i + k - 1 >= n_adapts) c->adapting = false;
   return AHMC_OK;
 }
@@ -1289,7 +1307,7 @@ int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void*
     c->plugin_ops = static_cast<const TargetOps<T>*>(d->ops);
     c->target_kind = AHMC_TARGET_PLUGIN;
     c->have_point = false;
-    c->order_valid = false;
+    c->order_valid = false; c->sched = {};
     return dn_refresh_fused(c);
   });
 }
@@ -1341,7 +1359,7 @@ int32_t ahmc_set_stepsize(ahmc_ctx* ctx, const void* eps, int64_t n) {
     HIPCHK(hipMemcpyAsync(c->eps_cur, c->eps_nom, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->eps_scalar = (n == 1);
-    c->order_valid = false;
+    c->order_valid = false; c->sched = {};
     return AHMC_OK;
   });
 }
@@ -1548,7 +1566,7 @@ int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->eps_nom, c->eps_cur, sizeof(T) * c->N, hipMemcpyDeviceToDevice, c->stream));
     c->eps_scalar = false;
-    c->order_valid = false;
+    c->order_valid = false; c->sched = {};
     return AHMC_OK;
   });
 }
@@ -1687,16 +1705,66 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         // launch (no per-transition barrier; see the note on tree-size tails in ahmc_nuts.hpp)
         // (split the remaining transitions evenly: 50 = 13+13+12+12, not 16+16+16+2 — a short
         // last batch would pay the whole tree-size tail for two transitions)
-        // AHMC_NUTS_DRAW_BATCH=n (experiments): transitions per launch of the SAMPLING phase only (AHMC_NUTS_BATCH also shortens the
-        // warm-up's launches, which on the funnel costs more than it gives: its tree sizes are still moving with the step sizes)
+        // Launch length of the sampling phase (round 4).  Two things pull in opposite directions: a launch cannot end before its
+        // slowest wave (the tail is paid once per launch: long launches), and the dispatch order — heaviest chains first, lockstep
+        // neighbours with similar trees — is only as good as the prediction of a chain's work, which on heavy-tailed targets is its
+        // work in the launch just finished and fades within tens of transitions (short launches).  Measured whole sampling phase,
+        // every launch ordered by the work of the one before it: cfg3 (funnel) 250 / 62 / 16 / 8 / 4 per launch 1.83 / 2.06 / 2.42 /
+        // 2.56 / 2.73e9 leapfrog/s (one launch of 1 000 ordered by step size: 1.69e9); cfg2 (iso Gaussian) 250 / 64 / 16 / 8 2.94 /
+        // 2.89 / 2.80 / 2.58e9.  Neither the imbalance nor the launch-to-launch correlation at one length separates the two cases
+        // ahead of time, so the engine MEASURES: starting from 32 it times groups of launches (>= 64 transitions: leapfrogs of the
+        // group ÷ wall time, the stream synchronised at both ends — only while it searches), halves while that gains > 2 %; if the
+        // first halving does not, the tails decide and it takes the longest launch unless that loses > 1.5 % (then one doubling
+        // at a time from the start length).  Then it stays at the best length, asynchronous again (cfg3 settles at 4, cfg2 at 256).  The
+        // length is kept until the step sizes change.  AHMC_NUTS_DRAW_BATCH=n fixes it; AHMC_NUTS_SCHED=0 = one length for all
+        // (AHMC_INFO_NUTS_BATCH), as before round 4.  The chains do not depend on any of it (tests/test_pipeline_parity.py).
         const int64_t draw_batch_env = getenv("AHMC_NUTS_DRAW_BATCH") ? atoll(getenv("AHMC_NUTS_DRAW_BATCH")) : 0;
-        const int64_t dbatch = draw_batch_env > 0 ? draw_batch_env : batch;
-        const int64_t left = n_samples - i + 1, nb_left = (left + dbatch - 1) / dbatch;
-        int64_t k = (left + nb_left - 1) / nb_left;
+        const int sched_env = getenv("AHMC_NUTS_SCHED") ? atoi(getenv("AHMC_NUTS_SCHED")) : 1;
+        const char* orf = getenv("AHMC_NUTS_ORDER_REFRESH");
+        // the dispatch order of every launch from the work of the launch BEFORE it alone (default since round 4; =0: from the run's totals)
+        const bool order_refresh = (orf ? atoi(orf) != 0 : true) && !dense_engine(c) && !c->eps_scalar && !getenv("AHMC_NUTS_NO_ORDER");
+        const int64_t left = n_samples - i + 1;
+        constexpr int64_t SCHED_MIN = 4, SCHED_START = 32, SCHED_GROUP = 64;
+        int64_t k;
+        bool probing = false;   // this launch belongs to a group that is being timed
+        auto& sc = c->sched;
+        if (draw_batch_env <= 0 && sched_env != 0 && order_refresh && sc.phase != 4 && batch >= 2 * SCHED_MIN) {
+          if (sc.g_left > 0) {                       // inside a group
+            k = sc.g_len; probing = true;
+          } else if (!sc.primed && !c->order_from_work && left >= 4 * SCHED_START) {
+            k = 2 * SCHED_MIN; sc.primed = true;     // (untimed: the first launch of a run is still ordered by step size)
+          } else {
+            const int64_t L = sc.phase == 0 ? std::min<int64_t>(SCHED_START, batch)
+                            : sc.phase == 3 ? batch                     // shorter did not pay: the tails decide, so the longest launch next
+                            : sc.phase == 5 ? std::min<int64_t>(sc.len * 2, batch)   // … and only if THAT loses, up one doubling at a time
+                            : std::max<int64_t>(sc.len / 2, SCHED_MIN);   // phase 1: the shorter neighbour first; phase 2: further down
+            const int64_t n_g = std::max<int64_t>(1, SCHED_GROUP / L);
+            if (left >= L * n_g + L) {               // (worth timing, and something left to use the answer on)
+              sc.primed = true;
+              sc.g_len = L; sc.g_left = (int)n_g;
+              k = L; probing = true;
+              if (!c->work_grp) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->work_grp), sizeof(long long) * (size_t)c->N));
+              if (!c->work_sum) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->work_sum), sizeof(long long)));
+              HIPCHK(hipMemcpyAsync(c->work_grp, c->acc_nsteps, sizeof(long long) * (size_t)c->N, hipMemcpyDeviceToDevice, c->stream));
+              HIPCHK(hipStreamSynchronize(c->stream));  // (the clock starts on an empty stream)
+              sc.g_t0 = std::chrono::steady_clock::now();
+            } else {
+              const int64_t dbatch = sc.best_len > 0 ? sc.best_len : batch;   // too little left to learn from: the best length known
+              const int64_t nb_left = (left + dbatch - 1) / dbatch;
+              k = (left + nb_left - 1) / nb_left;
+            }
+          }
+        } else {
+          const int64_t dbatch = draw_batch_env > 0 ? draw_batch_env : (sc.phase == 4 && sched_env != 0 && order_refresh ? sc.best_len : batch);
+          // (split the remaining transitions evenly: 50 = 13+13+12+12, not 16+16+16+2 — a short last batch would pay the whole
+          // tree-size tail for two transitions)
+          const int64_t nb_left = (left + dbatch - 1) / dbatch;
+          k = (left + nb_left - 1) / nb_left;
+        }
         // AHMC_NUTS_FIRST_BATCH=n (experiments; default off): a short first launch while the dispatch order is still the one by
         // step size, so that everything after it is scheduled by measured work (order_by_work below)
         const int first_batch = getenv("AHMC_NUTS_FIRST_BATCH") ? atoi(getenv("AHMC_NUTS_FIRST_BATCH")) : 0;
-        if (first_batch >= 4 && !c->order_from_work && !c->eps_scalar && left > 2 * (int64_t)first_batch) k = std::min<int64_t>(k, first_batch);
+        if (first_batch >= 4 && !c->order_from_work && !c->eps_scalar && left > 2 * (int64_t)first_batch && !probing) k = std::min<int64_t>(k, first_batch);
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
         T* dst = so ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
         T* dev_dst = dst;
@@ -1707,12 +1775,6 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
           if (rc1) return rc1;
           dev_dst = c->stage[slot];
         }
-        // AHMC_NUTS_ORDER_REFRESH=1 (opt-in, round 4 experiment): the dispatch order of every launch from the
-        // work of the launch BEFORE it alone — a chain's tree sizes stay what they are for ≈ 50 transitions, so on heavy-tailed
-        // targets the last launch predicts the next one where a total over the whole run does not (trace model: cfg3 in 16 launches
-        // of 62 transitions 3.80 against 5.41 units, and 5.35 with the order of the first launch kept, which is what happens today)
-        const char* orf = getenv("AHMC_NUTS_ORDER_REFRESH");
-        const bool order_refresh = orf && atoi(orf) != 0 && !dense_engine(c) && !c->eps_scalar;
         if (order_refresh) {
           if (!c->work_prev) {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->work_prev), sizeof(long long) * (size_t)c->N));
@@ -1723,13 +1785,43 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, true,
                                  (int)k, dev_dst);
         if (rc) return rc;
-        if (order_refresh && k >= 4) {
+        if (order_refresh && k >= 2) {
           hipLaunchKernelGGL(k_work_since, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->acc_nsteps, c->work_prev, c->work_last, (int64_t)c->N);
           HIPCHK(hipGetLastError());
           rc = build_order(c, (int)k, c->work_last);
           if (rc) return rc;
           c->order_valid = true;
           c->order_from_work = true;
+        }
+        if (probing && --sc.g_left == 0) {
+          // leapfrogs of the group ÷ its wall time (everything it needed: normals, both passes, the re-sorts)
+          HIPCHK(hipMemsetAsync(c->work_sum, 0, sizeof(long long), c->stream));
+          hipLaunchKernelGGL(k_work_sum, dim3(64), dim3(256), 0, c->stream, c->acc_nsteps, c->work_grp, c->work_sum, (int64_t)c->N);
+          HIPCHK(hipGetLastError());
+          long long w = 0;
+          HIPCHK(hipMemcpyAsync(&w, c->work_sum, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));
+          const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - sc.g_t0).count();
+          const double thr = dt > 0 ? (double)w / dt : 0.0;
+          static const bool dbg_s = getenv("AHMC_DEBUG") != nullptr;
+          if (dbg_s) fprintf(stderr, "[ahmc] sched: phase %d, %lld transitions per launch: %.4e leapfrog/s (best so far %lld: %.4e)\n", sc.phase, (long long)k, thr, (long long)sc.best_len, sc.best_thr);
+          if (sc.phase == 0) { sc.best_len = sc.len = k; sc.best_thr = thr; sc.phase = k / 2 >= SCHED_MIN ? 1 : 3; }
+          else if (sc.phase == 1 || sc.phase == 2) {  // tried the shorter neighbour of the best
+            if (thr > sc.best_thr * 1.02) {
+              sc.best_len = sc.len = k; sc.best_thr = thr;
+              sc.phase = k / 2 >= SCHED_MIN ? 2 : 4;
+            } else if (sc.phase == 1) { sc.len = sc.best_len; sc.phase = sc.best_len * 2 <= batch ? 3 : 4; }  // shorter does not pay: look the other way
+            else sc.phase = 4;
+          } else if (sc.phase == 3) {                 // tried the longest launch
+            if (thr >= sc.best_thr * 0.985) { sc.best_len = sc.len = k; sc.best_thr = std::max(sc.best_thr, thr); sc.phase = 4; }
+            else sc.phase = sc.best_len * 4 <= batch ? 5 : 4;   // (something between the start length and the longest is left to try)
+          } else if (sc.phase == 5) {                 // tried the longer neighbour
+            if (thr >= sc.best_thr * 0.985) {
+              sc.best_len = sc.len = k; sc.best_thr = std::max(sc.best_thr, thr);
+              sc.phase = k * 4 <= batch ? 5 : 4;
+            } else sc.phase = 4;
+          }
+          if (dbg_s && sc.phase == 4) fprintf(stderr, "[ahmc] sched: settled at %lld transitions per launch\n", (long long)sc.best_len);
         }
         if (via_stage) {
           HIPCHK(hipEventRecord(c->stage_ready[slot], c->stream));
@@ -1752,6 +1844,9 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
           (!so || !keep || so_on_device) &&
           !(c->var_estimator == AHMC_VAR_POOLED && c->adapt_kind != AHMC_ADAPT_STAN && c->adapt_kind != AHMC_ADAPT_STEPSIZE)) {
         // warm-up in batches too: adapt! runs inside the kernel (k_nuts MODE 3), no per-transition launch
+        // (round 4, measured and dropped: the warm-up in launches of 8 / 32 / 64 transitions, each ordered by the work of the one before
+        // it — cfg3 1.98 / 2.00e9 against 1.98e9 for one launch ordered by step size, cfg2 2.27e9 against 2.39e9: while the step
+        // sizes still move a launch's work does not predict the next one's any better than ϵ does, and every launch pays its tail)
         const int64_t left = std::min(n_adapts, n_samples) - i + 1, nb_left = (left + batch - 1) / batch;  // (a run may end mid-warm-up)
         int64_t k = (left + nb_left - 1) / nb_left;
         if (c->var_estimator == AHMC_VAR_POOLED && c->adapt_kind == AHMC_ADAPT_STAN && c->metric_kind == AHMC_METRIC_DIAG) {
@@ -1871,6 +1966,7 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
       case AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES: *out = c->dn_gemm_small; break;
       case AHMC_INFO_DENSE_PIPELINES: *out = c->dn_last_pipelines; break;
       case AHMC_INFO_DENSE_POOL: *out = c->dn_last_pool; break;
+      case AHMC_INFO_NUTS_DRAW_BATCH: *out = c->sched.phase == 4 ? c->sched.best_len : 0; break;
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
     }
     return AHMC_OK;

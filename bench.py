@@ -216,20 +216,274 @@ def launch_check(args):
     return 0 if seen == world == args.gpus else 1
 
 
+def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0, chains=0):
+    """One bench line for one config: W untimed transitions on a throw-away engine, then the timed sample loop (median of
+    `repeats` runs on fresh engines), the final gather, the roofline of the dominant kernel and — rank 0 of a one-GPU run — the CPU
+    baseline on a bounded sample of the same loop.  Returns the JSON object on rank 0, None elsewhere."""
+    A, lib, torch, dist, args = ctx["A"], ctx["lib"], ctx["torch"], ctx["dist"], ctx["args"]
+    rank, local_rank, world, stream = ctx["rank"], ctx["local_rank"], ctx["world"], ctx["stream"]
+    cfg = dict(CONFIGS[cfg_name])
+    if dim:
+        cfg["D"] = dim
+    D, N = cfg["D"], (chains or cfg["N"])
+    seed = args.seed or cfg["seed"]
+    n_total = steps * T
+    n_adapts = int(round(n_total * args.adapt_fraction))
+    n_draws = n_total - n_adapts
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    itemsize = 4 if args.dtype == "f32" else 8
+    dev = f"cuda:{local_rank}"
+
+    def make():
+        return build_engine(A, lib, cfg, N, seed, rank * N, stream=stream.cuda_stream, device=local_rank, dtype=np_dtype, n_reserve=max(n_adapts, n_draws))
+
+    def barrier_for(eng):
+        def f():
+            eng.sync()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+        return f
+
+    # the draws of the timed region: θ after every post-warm-up transition of every chain, (D, N, n_draws) in HBM — what the
+    # reference's `sample` returns (src/sampler.jl:224-227); written by the trajectory kernel inside the timed region
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    draws = None if args.no_draws_out else torch.empty((n_draws, N, D), dtype=tdt, device=dev)
+
+    # W untimed warm-up transitions of the same loop (code objects, allocator, clocks, first touch of the draws buffer) on a throw-away engine
+    if warm_trans > 0:
+        eng, kernel = make()
+        nwa = int(round(warm_trans * args.adapt_fraction))
+        nwd = max(1, warm_trans - nwa)
+        sample_loop(eng, kernel, nwa, nwd, barrier_for(eng), draws_ptr=draws.data_ptr() if (draws is not None and nwd <= n_draws) else None)
+        eng.close()
+
+    want_ess = draws is not None and (args.ess > 0 or (args.ess < 0 and D <= 256)) and n_draws >= 8
+    ess_buf = torch.empty((N, D), dtype=tdt, device=dev) if want_ess else None
+
+    runs = []
+    eng = None
+    while True:
+        if eng is not None:
+            eng.close()
+        eng, kernel = make()                      # untimed setup: create, θ0, find_good_stepsize, adaptor
+        r = sample_loop(eng, kernel, n_adapts, n_draws, barrier_for(eng), draws_ptr=draws.data_ptr() if draws is not None else None)
+        if want_ess:
+            # ESS of THIS run's draws (all chains, all dimensions), reduced on the device through the C ABI (ahmc_ess):
+            # per (dimension, chain) series Geyer's initial monotone sequence; per dimension the mean over chains; min over dimensions
+            eng._call("ahmc_ess", ctypes.c_void_p(draws.data_ptr()), int(n_draws), ctypes.c_void_p(ess_buf.data_ptr()))
+            eng.sync()
+            r["ess_per_draw"] = float(ess_buf.mean(dim=0).min().item()) / n_draws
+        tt = torch.tensor([r["dt"], r["dt_adapt"], r["dt_draw"]], dtype=torch.float64, device=dev)
+        tn = torch.tensor([float(r["leap_adapt"]), float(r["leap_draw"]), float(r["acc"]["n_divergent"]), float(r["div_adapt"]), r.get("ess_per_draw", 0.0)],
+                          dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        r["dt_max"], r["dt_adapt_max"], r["dt_draw_max"] = (float(x) for x in tt.tolist())
+        r["leap_adapt_all"], r["leap_draw_all"], r["div_all"], r["div_adapt_all"], ess_sum = (float(x) for x in tn.tolist())
+        r["ess_per_draw_all"] = ess_sum / world
+        r["value"] = (r["leap_adapt_all"] + r["leap_draw_all"]) / r["dt_max"]
+        r["draw_launch_length"] = eng.info("nuts_draw_batch")
+        runs.append(r)
+        spent = sum(x["dt_max"] for x in runs)
+        want = repeats if repeats > 0 else (3 if runs[0]["dt_max"] < 4.0 else 1)
+        # every rank takes the same decision: dt_max is the all-reduced time
+        if len(runs) >= want and (repeats > 0 or spent >= 1.0):
+            break
+        if len(runs) >= 50:
+            break
+    order = sorted(range(len(runs)), key=lambda i: runs[i]["value"])
+    med = runs[order[len(order) // 2]]   # median run (the engine of the LAST run is still open for the gather)
+
+    # final gather of the pooled per-dimension moments of the last run's draws through the C ABI (RCCL all-reduce inside)
+    from ahmc_amd.shard import EngineComm
+
+    comm = EngineComm(eng, dist, dev)
+    g = comm.gather_moments()
+    ci = eng.comm_info()               # what the communicator's own all-reduces counted when it was attached
+    mean, var = g["mean"], g["var"]
+
+    ess_info = None
+    if want_ess:
+        e1 = med["ess_per_draw_all"]
+        ess_info = {"ess_per_sec": e1 * n_draws * N * world / med["dt_max"],
+                    "ess_per_sec_sampling_phase_only": e1 * n_draws * N * world / med["dt_draw_max"],
+                    "ess_per_draw_min_over_dims": e1, "estimated_on_draws_per_chain": n_draws, "chains_used": N * world,
+                    "estimator": "Geyer initial monotone sequence on the autocovariances of every (dimension, chain) series (ahmc_ess, device "
+                                 "reduction over ALL chains); per dimension the mean over chains, then the min over dimensions; "
+                                 "the reference computes no ESS (MCMCChains.jl does): parity unpinned",
+                    "definition": "ESS of the timed run's own post-warm-up draws (the buffer the timed region filled) / wall time of its whole sample loop"}
+    del draws, ess_buf
+    torch.cuda.empty_cache()
+
+    out = None
+    if rank == 0:
+        B_lf = algorithmic_bytes_per_leapfrog(D, cfg["metric"], itemsize)
+        info = med["info"]
+        G, E = eng.info("group_lanes"), eng.info("elems_per_lane")
+        tname = "double" if args.dtype == "f64" else "float"
+        counters, counters_src = counters_at_head(cfg_name) if (args.dtype == "f64" and not dim and not chains) else (None, "counters are per config at its default size and f64")
+        # what the leapfrog itself needs (src/integrator.jl:231-243 on E elements per lane): r −= ϵ/2·g, θ += ϵ·(M⁻¹r), the density's
+        # gradient and value, r −= ϵ/2·g′, ℓκ — ≈ 7 f64 VALU instructions per element; everything above that is the tree
+        # (reductions, weights, merges, U-turn tests, RNG) and the kernel's bookkeeping
+        useful_floor = 7.0 * E
+
+        def kernel_roof(label, mode, launches, kns, leap):
+            """VALU-issue roof of one instantiation of k_nuts from this run's launches (HIP events) and the counters at HEAD"""
+            if launches <= 0 or kns <= 0:
+                return None
+            per_launch_s = kns / 1e9 / launches
+            lf_per_s = leap / (kns / 1e9)
+            o = {"kernel": f"k_nuts<{tname},{G},{E},mode {mode}>", "phase": label, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
+                 "leapfrogs_per_launch": leap / launches, "leapfrogs_per_s_in_kernel": lf_per_s,
+                 "hbm_model_bytes_per_leapfrog": B_lf, "hbm_model_frac": lf_per_s * B_lf / 1e9 / HBM_PEAK_GBS}
+            c = (counters or {}).get(f"mode{mode}")
+            if c:
+                cpw = max(1, 64 // G)   # chains per wave: the counters are per CHAIN-leapfrog, a wave instruction serves cpw chains
+                o["valu_instructions_per_leapfrog"] = c["valu_per_leapfrog"]
+                o["useful_valu_floor_per_leapfrog"] = useful_floor / cpw
+                o["valu_efficiency"] = useful_floor / cpw / c["valu_per_leapfrog"]
+                o["achieved"] = lf_per_s * c["valu_per_leapfrog"] / 1e9
+                o["peak"] = c.get("valu_peak_mix_gwave_instr_per_s") or VALU_PEAK_GINSTR
+                o["peak_is_mix_weighted"] = bool(c.get("valu_peak_mix_gwave_instr_per_s"))
+                o["frac"] = o["achieved"] / o["peak"]
+                o["frac_of_uniform_4_cycle_peak"] = o["achieved"] / VALU_PEAK_GINSTR
+                o["valu_mix"] = c.get("valu_peak_mix")
+                o["traffic"] = c.get("hbm_bytes_per_leapfrog") and c["hbm_bytes_per_leapfrog"] * leap / launches
+                o["hbm_measured_frac"] = c.get("hbm_bytes_per_leapfrog") and lf_per_s * c["hbm_bytes_per_leapfrog"] / 1e9 / HBM_PEAK_GBS
+                o["valu_busy_fraction_under_rocprof"] = c.get("valu_busy")
+            else:
+                o["achieved"] = o["frac"] = o["traffic"] = None
+            return o
+
+        roof = None
+        if cfg["metric"] != "dense":
+            rd = kernel_roof("draws", 0, info["nuts_launches"], info["nuts_kernel_ns"], med["leap_draw"])
+            rw = kernel_roof("warm-up (adapt! inside the kernel)", 3, info["nuts_warm_launches"], info["nuts_warm_kernel_ns"], med["leap_adapt"])
+            both = [x for x in (rd, rw) if x]
+            both.sort(key=lambda x: -x["launches"] * x["avg_launch_ms"])  # dominant = more device time in the timed region
+            if both:
+                dom = both[0]
+                roof = {"bound": "valu", "unit": "Gwave-instr/s", "peak": dom.get("peak", VALU_PEAK_GINSTR), "achieved": dom["achieved"], "frac": dom["frac"],
+                        "traffic": dom["traffic"], "kernel": dom["kernel"], "counters": counters_src,
+                        "useful_valu_floor_per_leapfrog": dom.get("useful_valu_floor_per_leapfrog"), "valu_efficiency": dom.get("valu_efficiency"),
+                        "peak_definition": ("mix-weighted VALU issue peak of this kernel: N / sum_c n_c * cycles_c over its dynamic instruction classes at 2.4 GHz x "
+                                            "1024 SIMDs, cycles_c in {2,4,8,16} per wave64 instruction = the class of each instruction type by its MEASURED rate "
+                                            "on the MI355X (scripts/probe/valu_rate.hip, profiles/r3_valu_rate.json; scripts/valu_mix.py)"
+                                            if dom.get("peak_is_mix_weighted") else
+                                            "uncalibrated: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (no class mix for this kernel)"),
+                        "dominant": dom, "other": both[1] if len(both) > 1 else None,
+                        "device_time_share_of_timed_region": sum(x["launches"] * x["avg_launch_ms"] for x in both) / 1e3 / med["dt"]}
+        else:
+            F_lf = 4 * D * D
+            tf = (med["leap_adapt"] + med["leap_draw"]) * F_lf / med["dt"] / 1e12
+            peak = F64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else F32_MFMA_PEAK_TFLOPS
+            roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": tf, "frac": tf / peak, "traffic": None,
+                    "kernel": "k_dgemm (both products of a global step) + k_d_tree, whole timed region",
+                    "algorithmic_flops_per_leapfrog": F_lf,
+                    "note": "useful leapfrogs x 4 D^2 / wall time of the whole loop (tree kernel, momenta and adaptation included)"}
+        out = {
+            "metric": "leapfrog-steps/sec (whole node) at n_chains x D",
+            "value": med["value"],
+            "unit": "leapfrog-steps/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": med["dt_max"] / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{cfg['text']}, {N} chains/GPU, D={D}; timed = the whole sample loop: {n_adapts} adapting transitions + {n_draws} draws "
+                            f"(find_good_stepsize and the initial H2D are setup, untimed)",
+                "chains_per_gpu": N, "D": D, "parallelism": f"chain-shard x{world}",
+                "ranks_seen": ci["ranks_seen"], "chains_total_seen": ci["chains_total"],
+                "transitions_per_step": T, "n_adapts": n_adapts, "n_draws": n_draws,
+                "untimed_warmup_transitions": warm_trans,
+                "leapfrogs": {"adapt": med["leap_adapt_all"], "draw": med["leap_draw_all"]},
+                "fits_quoted_config": world == cfg["quoted_gpus"],
+                "runs": [x["value"] for x in runs], "reported": "median run",
+                "draw_launch_length_found_by_the_engine": med.get("draw_launch_length"),
+                "warmup_phase": {"value": med["leap_adapt_all"] / med["dt_adapt_max"] if n_adapts else None,
+                                 "ms_per_transition": med["dt_adapt_max"] / max(n_adapts, 1) * 1e3,
+                                 "mean_leapfrogs_per_transition": med["leap_adapt_all"] / max(n_adapts * N * world, 1),
+                                 "divergent": med["div_adapt_all"]},
+                "post_adaptation": {"value": med["leap_draw_all"] / med["dt_draw_max"],
+                                    "ms_per_transition": med["dt_draw_max"] / n_draws * 1e3,
+                                    "mean_leapfrogs_per_transition": med["leap_draw_all"] / (n_draws * N * world),
+                                    "divergent": med["div_all"]},
+                "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()) if cfg["target"] == "iso" else None,
+                "gathered_draws": g["n_draws"], "gather": g["how"],
+                "draws_materialised_in_timed_region": (None if args.no_draws_out else
+                                                       {"shape_D_N_K": [D, N, n_draws], "gib": D * N * n_draws * itemsize / 2**30, "where": "device (HBM)"}),
+                "ess": ess_info,
+            },
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1 and cpu_budget_s > 0:  # (the contract: rank 0 at N = 1 only)
+            try:
+                cores = usable_cores()
+                cpu_chains = args.cpu_chains or min(N, 256 * cores)
+                # sized for ~cpu_budget_s: the oracle does ≈1.3e6 leapfrog/s per core on cfg2 (scales with 128 / D; the dense engine's
+                # oracle pays 2 D² flops per leapfrog: ≈ 2e9 flop/s per core), ≈35 leapfrogs per transition
+                lpt = max(out["config"]["post_adaptation"]["mean_leapfrogs_per_transition"], out["config"]["warmup_phase"]["mean_leapfrogs_per_transition"] or 0)
+                # (leapfrog/s per core, measured on this image's hosts: D <= 512 Diag ≈ 1.3e6·128/D; the multi-thousand-D hierarchical
+                # target ≈ 2.8e4·2048/D — its warm-up trees are 200–300 leaves —; the dense target / metric pair ≈ 435·(512/D)²)
+                rate = 435.0 * (512.0 / D) ** 2 if cfg["metric"] == "dense" else (2.8e4 * 2048.0 / D if D > 512 else 1.3e6 * 128.0 / D)
+                if cfg["metric"] == "dense":
+                    cpu_chains = args.cpu_chains or min(N, 16 * cores)
+                if args.cpu_transitions:
+                    cpu_T = args.cpu_transitions
+                else:
+                    cpu_T = int(max(20 if cfg["metric"] == "dense" or D > 512 else 40, min(n_total, cpu_budget_s * rate * cores / (cpu_chains * lpt))))
+                    if cpu_T * cpu_chains * lpt / (rate * cores) > 2.0 * cpu_budget_s:   # still too long at the minimum transitions: fewer chains
+                        cpu_chains = max(cores, int(cpu_budget_s * rate * cores / (cpu_T * lpt)))
+                ca = int(round(cpu_T * args.adapt_fraction))
+                v, v_draw, cdt, cores = cpu_baseline(A, cfg, ca, cpu_T - ca, seed, cpu_chains, cores)
+                out["cpu_baseline"] = {
+                    "value": v, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+                    "sample": f"{cpu_chains} chains x D={D}, the same sample loop ({ca} adapting transitions + {cpu_T - ca} draws, same kernel / adaptor), "
+                              f"{cdt:.1f} s; C++ restatement of the reference (oracle/), OpenMP over chains, {cores} threads = the container's "
+                              f"CPU quota ({os.cpu_count()} logical CPUs visible), not Julia",
+                    "post_adaptation_value": v_draw,
+                }
+                if ctx.get("single_thread_leg", True):
+                    # single thread: what the reference's broadcast path uses (SURVEY §8d (i)); a smaller sample of the same loop
+                    c1 = max(8, cpu_chains // (8 * cores))
+                    t1n = max(20, cpu_T // 4)
+                    v1, _, cdt1, _ = cpu_baseline(A, cfg, int(round(t1n * args.adapt_fraction)), t1n - int(round(t1n * args.adapt_fraction)), seed, c1, 1)
+                    out["cpu_baseline"]["single_thread"] = {"value": v1, "cores": 1, "sample": f"{c1} chains, {t1n} transitions of the same loop, {cdt1:.1f} s"}
+            except Exception as ex:  # the baseline leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+    comm.close()
+    eng.close()
+    return out
+
+
+# the default run reports the other single-GPU BASELINE configs beside the headline (config.secondary): (steps, transitions per
+# step, untimed warm-up transitions, timed runs, seconds of CPU baseline) — sized so that the whole default invocation stays
+# well under two minutes: cfg3 1 000 + 1 000, cfg5 and cfg4 100 + 100 on one GPU's shard
+SECONDARY = {"cfg3": (20, 100, 100, 1, 5.0), "cfg5": (2, 100, 10, 1, 5.0), "cfg4": (2, 100, 10, 1, 5.0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="K timed steps; a step = --transitions-per-step transitions of all chains")
     ap.add_argument("--warmup", type=int, default=2, help="W untimed steps of the same loop on a throw-away engine")
     ap.add_argument("--transitions-per-step", type=int, default=100)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: cfg2 (the headline) with the other one-GPU configs as config.secondary")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only")
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (0 = the config's)")
     ap.add_argument("--dim", type=int, default=0, help="D (0 = the config's)")
     ap.add_argument("--adapt-fraction", type=float, default=0.5, help="share of the K steps that adapt (SURVEY 8d: 1000 of 2000)")
     ap.add_argument("--repeats", type=int, default=0, help="timed runs (0 = until >= 1 s of timed work, at least 3 when a run is < 4 s)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-chains", type=int, default=0, help="0 = 256 per usable host core, capped at --chains")
-    ap.add_argument("--cpu-transitions", type=int, default=0, help="transitions of the CPU sample (0 = sized for ~15 s)")
+    ap.add_argument("--cpu-transitions", type=int, default=0, help="transitions of the CPU sample (0 = sized for ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64", help="f64 = the reference default and the headline; f32 = what the "
                     "reference's CUDA smoke test uses (test/CUDA/cuda.jl:18), reported for information")
@@ -264,231 +518,34 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     lib = A.load_hip_library()  # raises if the HIP engine is not built: no fallback
-    cfg = dict(CONFIGS[args.config])
-    if args.dim:
-        cfg["D"] = args.dim
-    D, N = cfg["D"], (args.chains or cfg["N"])
-    seed = args.seed or cfg["seed"]
+    ctx = {"A": A, "lib": lib, "torch": torch, "dist": dist, "args": args, "rank": rank, "local_rank": local_rank, "world": world,
+           "stream": torch.cuda.Stream(device=local_rank)}
+    headline = args.config or "cfg2"
     T = args.transitions_per_step
-    n_total = args.steps * T
-    n_adapts = int(round(n_total * args.adapt_fraction))
-    n_draws = n_total - n_adapts
-    stream = torch.cuda.Stream(device=local_rank)
-    np_dtype = np.float32 if args.dtype == "f32" else np.float64
-    itemsize = 4 if args.dtype == "f32" else 8
-    dev = f"cuda:{local_rank}"
-
-    def make():
-        return build_engine(A, lib, cfg, N, seed, rank * N, stream=stream.cuda_stream, device=local_rank, dtype=np_dtype, n_reserve=max(n_adapts, n_draws))
-
-    def barrier_for(eng):
-        def f():
-            eng.sync()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-        return f
-
-    # the draws of the timed region: θ after every post-warm-up transition of every chain, (D, N, n_draws) in HBM — what the
-    # reference's `sample` returns (src/sampler.jl:224-227); written by the trajectory kernel inside the timed region
-    tdt = torch.float64 if args.dtype == "f64" else torch.float32
-    draws = None if args.no_draws_out else torch.empty((n_draws, N, D), dtype=tdt, device=dev)
-
-    # W untimed warm-up steps of the same loop (code objects, allocator, clocks, first touch of the draws buffer) on a throw-away engine
-    if args.warmup > 0:
-        eng, kernel = make()
-        nw = args.warmup * T
-        nwa = int(round(nw * args.adapt_fraction))
-        nwd = max(1, nw - nwa)
-        sample_loop(eng, kernel, nwa, nwd, barrier_for(eng), draws_ptr=draws.data_ptr() if (draws is not None and nwd <= n_draws) else None)
-        eng.close()
-
-    want_ess = draws is not None and (args.ess > 0 or (args.ess < 0 and D <= 256)) and n_draws >= 8
-    ess_buf = torch.empty((N, D), dtype=tdt, device=dev) if want_ess else None
-
-    runs = []
-    eng = None
-    while True:
-        if eng is not None:
-            eng.close()
-        eng, kernel = make()                      # untimed setup: create, θ0, find_good_stepsize, adaptor
-        r = sample_loop(eng, kernel, n_adapts, n_draws, barrier_for(eng), draws_ptr=draws.data_ptr() if draws is not None else None)
-        if want_ess:
-            # ESS of THIS run's draws (all chains, all dimensions), reduced on the device through the C ABI (ahmc_ess):
-            # per (dimension, chain) series Geyer's initial monotone sequence; per dimension the mean over chains; min over dimensions
-            eng._call("ahmc_ess", ctypes.c_void_p(draws.data_ptr()), int(n_draws), ctypes.c_void_p(ess_buf.data_ptr()))
-            eng.sync()
-            r["ess_per_draw"] = float(ess_buf.mean(dim=0).min().item()) / n_draws
-        tt = torch.tensor([r["dt"], r["dt_adapt"], r["dt_draw"]], dtype=torch.float64, device=dev)
-        tn = torch.tensor([float(r["leap_adapt"]), float(r["leap_draw"]), float(r["acc"]["n_divergent"]), float(r["div_adapt"]), r.get("ess_per_draw", 0.0)],
-                          dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tn, op=dist.ReduceOp.SUM)
-        r["dt_max"], r["dt_adapt_max"], r["dt_draw_max"] = (float(x) for x in tt.tolist())
-        r["leap_adapt_all"], r["leap_draw_all"], r["div_all"], r["div_adapt_all"], ess_sum = (float(x) for x in tn.tolist())
-        r["ess_per_draw_all"] = ess_sum / world
-        r["value"] = (r["leap_adapt_all"] + r["leap_draw_all"]) / r["dt_max"]
-        runs.append(r)
-        spent = sum(x["dt_max"] for x in runs)
-        want = args.repeats if args.repeats > 0 else (3 if runs[0]["dt_max"] < 4.0 else 1)
-        # every rank takes the same decision: dt_max is the all-reduced time
-        if len(runs) >= want and (args.repeats > 0 or spent >= 1.0):
-            break
-        if len(runs) >= 50:
-            break
-    order = sorted(range(len(runs)), key=lambda i: runs[i]["value"])
-    med = runs[order[len(order) // 2]]   # median run (the engine of the LAST run is still open for the gather)
-
-    # final gather of the pooled per-dimension moments of the last run's draws through the C ABI (RCCL all-reduce inside)
-    acc = runs[-1]["acc"]
-    from ahmc_amd.shard import EngineComm
-
-    comm = EngineComm(eng, dist, dev)
-    g = comm.gather_moments()
-    mean, var = g["mean"], g["var"]
-
-    ess_info = None
-    if want_ess:
-        e1 = med["ess_per_draw_all"]
-        ess_info = {"ess_per_sec": e1 * n_draws * N * world / med["dt_max"],
-                    "ess_per_sec_sampling_phase_only": e1 * n_draws * N * world / med["dt_draw_max"],
-                    "ess_per_draw_min_over_dims": e1, "estimated_on_draws_per_chain": n_draws, "chains_used": N * world,
-                    "estimator": "Geyer initial monotone sequence on the autocovariances of every (dimension, chain) series (ahmc_ess, device "
-                                 "reduction over ALL chains); per dimension the mean over chains, then the min over dimensions; "
-                                 "the reference computes no ESS (MCMCChains.jl does): parity unpinned",
-                    "definition": "ESS of the timed run's own post-warm-up draws (the buffer the timed region filled) / wall time of its whole sample loop"}
-    del draws
-
-    if rank == 0:
-        B_lf = algorithmic_bytes_per_leapfrog(D, cfg["metric"], itemsize)
-        info = med["info"]
-        G, E = eng.info("group_lanes"), eng.info("elems_per_lane")
-        tname = "double" if args.dtype == "f64" else "float"
-        counters, counters_src = counters_at_head(args.config) if (args.dtype == "f64" and not args.dim and not args.chains) else (None, "counters are per config at its default size and f64")
-
-        def kernel_roof(label, mode, launches, kns, leap):
-            """VALU-issue roof of one instantiation of k_nuts from this run's launches (HIP events) and the counters at HEAD"""
-            if launches <= 0 or kns <= 0:
-                return None
-            per_launch_s = kns / 1e9 / launches
-            lf_per_s = leap / (kns / 1e9)
-            o = {"kernel": f"k_nuts<{tname},{G},{E},mode {mode}>", "phase": label, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
-                 "leapfrogs_per_launch": leap / launches, "leapfrogs_per_s_in_kernel": lf_per_s,
-                 "hbm_model_bytes_per_leapfrog": B_lf, "hbm_model_frac": lf_per_s * B_lf / 1e9 / HBM_PEAK_GBS}
-            c = (counters or {}).get(f"mode{mode}")
-            if c:
-                o["valu_instructions_per_leapfrog"] = c["valu_per_leapfrog"]
-                o["achieved"] = lf_per_s * c["valu_per_leapfrog"] / 1e9
-                o["peak"] = c.get("valu_peak_mix_gwave_instr_per_s") or VALU_PEAK_GINSTR
-                o["peak_is_mix_weighted"] = bool(c.get("valu_peak_mix_gwave_instr_per_s"))
-                o["frac"] = o["achieved"] / o["peak"]
-                o["frac_of_uniform_4_cycle_peak"] = o["achieved"] / VALU_PEAK_GINSTR
-                o["valu_mix"] = c.get("valu_peak_mix")
-                o["traffic"] = c.get("hbm_bytes_per_leapfrog") and c["hbm_bytes_per_leapfrog"] * leap / launches
-                o["hbm_measured_frac"] = c.get("hbm_bytes_per_leapfrog") and lf_per_s * c["hbm_bytes_per_leapfrog"] / 1e9 / HBM_PEAK_GBS
-                o["valu_busy_fraction_under_rocprof"] = c.get("valu_busy")
-            else:
-                o["achieved"] = o["frac"] = o["traffic"] = None
-            return o
-
-        roof = None
-        if cfg["metric"] != "dense":
-            rd = kernel_roof("draws", 0, info["nuts_launches"], info["nuts_kernel_ns"], med["leap_draw"])
-            rw = kernel_roof("warm-up (adapt! inside the kernel)", 3, info["nuts_warm_launches"], info["nuts_warm_kernel_ns"], med["leap_adapt"])
-            both = [x for x in (rd, rw) if x]
-            both.sort(key=lambda x: -x["launches"] * x["avg_launch_ms"])  # dominant = more device time in the timed region
-            if both:
-                dom = both[0]
-                roof = {"bound": "valu", "unit": "Gwave-instr/s", "peak": dom.get("peak", VALU_PEAK_GINSTR), "achieved": dom["achieved"], "frac": dom["frac"],
-                        "traffic": dom["traffic"], "kernel": dom["kernel"], "counters": counters_src,
-                        "peak_definition": ("mix-weighted VALU issue peak of this kernel: N / sum_c n_c * cycles_c over its dynamic instruction classes at 2.4 GHz x "
-                                            "1024 SIMDs, cycles_c in {2,4,8,16} per wave64 instruction = the class of each instruction type by its MEASURED rate "
-                                            "on the MI355X (scripts/probe/valu_rate.hip, profiles/r3_valu_rate.json; scripts/valu_mix.py)"
-                                            if dom.get("peak_is_mix_weighted") else
-                                            "uncalibrated: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (no class mix for this kernel)"),
-                        "dominant": dom, "other": both[1] if len(both) > 1 else None,
-                        "device_time_share_of_timed_region": sum(x["launches"] * x["avg_launch_ms"] for x in both) / 1e3 / med["dt"]}
-        else:
-            F_lf = 4 * D * D
-            tf = (med["leap_adapt"] + med["leap_draw"]) * F_lf / med["dt"] / 1e12
-            peak = F64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else F32_MFMA_PEAK_TFLOPS
-            roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": tf, "frac": tf / peak, "traffic": None,
-                    "kernel": "k_dgemm (both products of a global step) + k_d_tree, whole timed region",
-                    "algorithmic_flops_per_leapfrog": F_lf,
-                    "note": "useful leapfrogs x 4 D^2 / wall time of the whole loop (tree kernel, momenta and adaptation included)"}
-        out = {
-            "metric": "leapfrog-steps/sec (whole node) at n_chains x D",
-            "value": med["value"],
-            "unit": "leapfrog-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": med["dt_max"] / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": f"{cfg['text']}, {N} chains/GPU, D={D}; timed = the whole sample loop: {n_adapts} adapting transitions + {n_draws} draws "
-                            f"(find_good_stepsize and the initial H2D are setup, untimed)",
-                "chains_per_gpu": N, "D": D, "parallelism": f"chain-shard x{world}",
-                "transitions_per_step": T, "n_adapts": n_adapts, "n_draws": n_draws,
-                "leapfrogs": {"adapt": med["leap_adapt_all"], "draw": med["leap_draw_all"]},
-                "fits_quoted_config": world == cfg["quoted_gpus"],
-                "runs": [x["value"] for x in runs], "reported": "median run",
-                "warmup_phase": {"value": med["leap_adapt_all"] / med["dt_adapt_max"] if n_adapts else None,
-                                 "ms_per_transition": med["dt_adapt_max"] / max(n_adapts, 1) * 1e3,
-                                 "mean_leapfrogs_per_transition": med["leap_adapt_all"] / max(n_adapts * N * world, 1),
-                                 "divergent": med["div_adapt_all"]},
-                "post_adaptation": {"value": med["leap_draw_all"] / med["dt_draw_max"],
-                                    "ms_per_transition": med["dt_draw_max"] / n_draws * 1e3,
-                                    "mean_leapfrogs_per_transition": med["leap_draw_all"] / (n_draws * N * world),
-                                    "divergent": med["div_all"]},
-                "max_abs_mean": float(np.abs(mean).max()), "max_abs_var_minus_1": float(np.abs(var - 1).max()) if cfg["target"] == "iso" else None,
-                "gathered_draws": g["n_draws"], "gather": g["how"],
-                "draws_materialised_in_timed_region": (None if args.no_draws_out else
-                                                       {"shape_D_N_K": [D, N, n_draws], "gib": D * N * n_draws * itemsize / 2**30, "where": "device (HBM)"}),
-                "ess": ess_info,
-            },
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1:  # (the contract: rank 0 at N = 1 only)
+    out = run_config(ctx, headline, args.steps, T, args.warmup * T, args.repeats, 12.0, dim=args.dim, chains=args.chains)
+    # The other BASELINE configs a single GPU holds, each with its own value / roofline / cpu_baseline, beside the headline — in
+    # the default invocation only (what the driver runs).  At N > 1: the configs BASELINE.json quotes on exactly N GPUs.
+    if args.config is None and not args.no_secondary and not args.dim and not args.chains and args.dtype == "f64":
+        sec = {}
+        ctx["single_thread_leg"] = False
+        for name, (st, t2, wt, rp, cpu_s) in SECONDARY.items():
+            if world > 1 and CONFIGS[name]["quoted_gpus"] != world:
+                continue
             try:
-                cores = usable_cores()
-                cpu_chains = args.cpu_chains or min(N, 256 * cores)
-                # sized for ~15 s: the oracle does ≈1.3e6 leapfrog/s per core on cfg2 (scales with 128 / D), ≈35 leapfrogs per transition
-                if args.cpu_transitions:
-                    cpu_T = args.cpu_transitions
-                else:
-                    rate = 1.3e6 * cores * 128.0 / D
-                    lpt = max(out["config"]["post_adaptation"]["mean_leapfrogs_per_transition"], out["config"]["warmup_phase"]["mean_leapfrogs_per_transition"] or 0)
-                    cpu_T = int(max(40, min(n_total, 15.0 * rate / (cpu_chains * lpt))))
-                ca = int(round(cpu_T * args.adapt_fraction))
-                v, v_draw, cdt, cores = cpu_baseline(A, cfg, ca, cpu_T - ca, seed, cpu_chains, cores)
-                # single thread: what the reference's broadcast path uses (SURVEY §8d (i)); a smaller sample of the same loop
-                c1 = max(8, cpu_chains // (8 * cores))
-                t1n = max(20, cpu_T // 4)
-                v1, _, cdt1, _ = cpu_baseline(A, cfg, int(round(t1n * args.adapt_fraction)), t1n - int(round(t1n * args.adapt_fraction)), seed, c1, 1)
-                out["cpu_baseline"] = {
-                    "value": v, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
-                    "sample": f"{cpu_chains} chains x D={D}, the same sample loop ({ca} adapting transitions + {cpu_T - ca} draws, same kernel / adaptor), "
-                              f"{cdt:.1f} s; C++ restatement of the reference (oracle/), OpenMP over chains, {cores} threads = the container's "
-                              f"CPU quota ({os.cpu_count()} logical CPUs visible), not Julia",
-                    "post_adaptation_value": v_draw,
-                    "single_thread": {"value": v1, "cores": 1, "sample": f"{c1} chains, {t1n} transitions of the same loop, {cdt1:.1f} s"},
-                }
-            except Exception as ex:  # the baseline leg must never take the GPU number down with it
-                out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+                o = run_config(ctx, name, st, t2, wt, rp, cpu_s)
+            except Exception as ex:  # a secondary config must never take the headline down with it
+                o = {"error": repr(ex)} if rank == 0 else None
+            if rank == 0:
+                sec[name] = o
+        if rank == 0:
+            out["config"]["secondary"] = sec
+    if rank == 0:
         try:  # RCCL writes its version banner to the C stdout when the first communicator is made: push it out first, so
             ctypes.CDLL(None).fflush(None)  # that the JSON line is the LAST line of stdout whatever the buffering
         except Exception:
             pass
         print(json.dumps(out), flush=True)  # flushed NOW: with a process group alive the interpreter's exit path (RCCL / c10d
         sys.stdout.flush()                  # teardown) was seen to drop a block-buffered stdout — the line must not depend on it
-    comm.close()
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 
