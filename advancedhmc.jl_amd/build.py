@@ -40,7 +40,12 @@ def _cache_dir() -> str:
 OBJ = _cache_dir()
 OUT = os.path.join(CSRC, "libahmc_hip.so")
 INCLUDE = os.path.join(_HERE, "..", "include")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+# -ffp-contract=on (round 4): a*b+c fuses where the SOURCE writes it in one expression, and nowhere else.  hipcc's default
+# (`fast`) lets the optimiser fuse across statements, and it decided differently in different instantiations of the same
+# template: the warm-up kernel (MODE 3) and the sampling kernel (MODE 0) of the geometries with E >= 4 differed in the last bit
+# of a leaf's energy now and then — harmless for one transition, doubled by every dual-averaging step after it, so a warm-up
+# run in one launch was not bit-identical to the same warm-up run one iteration per call (scripts/sweep_inst.py).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
          "-Wno-unused-parameter"]
 
 

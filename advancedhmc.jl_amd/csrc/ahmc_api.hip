@@ -835,8 +835,8 @@ int adaptor_init(Ctx<T>* c, int kind, double delta, int ib, int tb, int ws) {
     if ((rc = dev_alloc(c, &c->da_mu, (size_t)c->N))) return rc;
     if ((rc = dev_alloc(c, &c->da_xbar, (size_t)c->N))) return rc;
     if ((rc = dev_alloc(c, &c->da_Hbar, (size_t)c->N))) return rc;
-    if ((rc = dev_alloc(c, &c->da_tab, (size_t)2 * DA_TAB_M))) return rc;
-    hipLaunchKernelGGL((k_da_table<T>), dim3(DA_TAB_M / 256), dim3(256), 0, c->stream, c->da_tab, T(DA_KAPPA));
+    if ((rc = dev_alloc(c, &c->da_tab, (size_t)4 * DA_TAB_M))) return rc;
+    hipLaunchKernelGGL((k_da_table<T>), dim3(DA_TAB_M / 256), dim3(256), 0, c->stream, c->da_tab, T(DA_KAPPA), T(DA_GAMMA), T(DA_T0));
     HIPCHK(hipGetLastError());
   }
   // NesterovDualAveraging(δ, ϵ) → DAState(ϵ) (src/adaptation/stepsize.jl:25-33): a reset with ϵ = nominal ϵ

@@ -539,24 +539,30 @@ struct DAState {
 constexpr int DA_TAB_M = 4096;
 // NesterovDualAveraging's constants (src/adaptation/stepsize.jl:168-172) — one definition: the table is built for THIS κ
 constexpr double DA_GAMMA = 0.05, DA_T0 = 10.0, DA_KAPPA = 0.75;
+// Round 4: also the two DIVISIONS whose operands are the same for every chain, η_H = 1 / (m + t0) and √m / γ (an f64 division is
+// a quarter-rate reciprocal and a Newton iteration, ≈ 70 issue cycles each, once per chain and transition): four entries per m.
 template <class T>
-__global__ void k_da_table(T* __restrict__ tab, T kappa) {
+__global__ void k_da_table(T* __restrict__ tab, T kappa, T gamma, T t0) {
+#pragma clang fp contract(off)
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= DA_TAB_M) return;
-  tab[2 * m] = sqrt((T)m);
-  tab[2 * m + 1] = m > 0 ? pow((T)m, -kappa) : T(0);
+  const T sq = sqrt((T)m);
+  tab[4 * m] = sq;
+  tab[4 * m + 1] = m > 0 ? pow((T)m, -kappa) : T(0);
+  tab[4 * m + 2] = T(1) / ((T)m + t0);
+  tab[4 * m + 3] = sq / gamma;
 }
 // adapt_stepsize! (src/adaptation/stepsize.jl:178-210)
 template <class T>
 __device__ __forceinline__ void da_step(DAState<T>& s, T alpha, T delta, T gamma, T t0, T kappa, const T* __restrict__ tab = nullptr) {
 #pragma clang fp contract(off)
   const int32_t m = s.m + 1;
-  const T eta_H = T(1) / ((T)m + t0);
+  const bool tabulated = tab != nullptr && m < DA_TAB_M && m >= 0;  // (the table was built for THESE γ, t0, κ: DA_GAMMA, DA_T0, DA_KAPPA)
+  const T eta_H = tabulated ? tab[4 * m + 2] : T(1) / ((T)m + t0);
   const T Hbar = (T(1) - eta_H) * s.Hbar + eta_H * (delta - jl_min(T(1), alpha));
-  const bool tabulated = tab != nullptr && m < DA_TAB_M;
-  const T sqrt_m = tabulated ? tab[2 * m] : sqrt((T)m);
-  const T x = s.mu - Hbar * (sqrt_m / gamma);
-  const T eta_x = tabulated ? tab[2 * m + 1] : pow((T)m, -kappa);
+  const T sqrt_m_over_gamma = tabulated ? tab[4 * m + 3] : sqrt((T)m) / gamma;
+  const T x = s.mu - Hbar * sqrt_m_over_gamma;
+  const T eta_x = tabulated ? tab[4 * m + 1] : pow((T)m, -kappa);
   const T xbar = (T(1) - eta_x) * s.xbar + eta_x * x;
   const T eps = exp(x);
   if (is_finite(eps)) {  // otherwise the previous (m, ϵ, x̄, H̄) are kept (:199-203)

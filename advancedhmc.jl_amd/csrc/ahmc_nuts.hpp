@@ -27,6 +27,14 @@
 #define AHMC_SCALAR_ANY 1      // loop-control predicates of a wave-owning chain are tested directly instead of through a ballot (0: ballot)
 #endif
 
+#ifndef AHMC_RUNNING_STATS
+// 1: Σα, nα and ΔH_max of the subtree a doubling builds are RUNNING values over its leaves in build order — the statistics the
+// reference carries through every `combine` (src/trajectory.jl:533-542) are a sum, a count and a maximum of |·| over the same
+// leaves, so only the order of the additions changes (acceptance_rate in the last bit; no decision depends on it): no per-level
+// Σα / nα / ΔH_max in LDS, nothing to fold in at a merge, at a park or when a subtree ends early.  0: through every merge.
+#define AHMC_RUNNING_STATS 1
+#endif
+
 #include <type_traits>
 
 #include "ahmc_kernels.hpp"
@@ -356,7 +364,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     const T eps = chain_eps_from(p, rng, eps_nom_t);
     momentum_from_normals<T, E>(p, p.znorm + (int64_t)kt * p.D * p.N, cc, d0, cur.r);
     fill_caches<T, G, E, TK>(cur, minv, p.tp, lane, d0);
-    if (on && kt > 0) store_vec<T, E>(cur.th, p.th(), cc * p.D, d0, p.D);  // θ0 of this transition (re-integration, redo)
+    // (θ0 of this transition — what the epilogue's re-integration and the redo pass start from — is already in p.th(): the
+    // launch's start point at kt = 0, the previous transition's store_point after it.  Round 4: the redundant `if (on && kt > 0)`
+    // store that stood here was also where the register allocator parked the spills of the chain index and of the lane's first
+    // dimension in two instantiations — under the block's narrowed exec mask, skipped altogether at kt = 0: a memory fault on
+    // the MI355X, now also what isa_check's second pass looks for.)
     const T H0 = -(cur.lp + cur.lk);
     DrawStreamT<(G >= 64)> ds;
     ds.init(rng);
@@ -466,9 +478,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           // acceptance rates, and with them the dual averaging, of the launch lengths that never hand it over (round 4: a warm-up of
           // 60 transitions in one launch left the per-iteration path on every chain that had met −ΔH > 600 once — the device
           // library's exp and the table form differ in the last bit now and then, and dual averaging doubles that every iteration)
-          if constexpr (!LINW) sa_c = alpha_from_logweight<T, (CPW == 1)>(H0 + ne);
-          na_c = 1;
-          dh_c = dH;
+          T sa_leaf = 0;
+          if constexpr (!LINW) sa_leaf = alpha_from_logweight<T, (CPW == 1)>(H0 + ne);
           ck_c = pos_cur;
           if (slice) {
             w_c = (lu <= ne) ? T(1) : T(0);
@@ -482,7 +493,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               // chain that meets -ΔH > 600 is flagged and redone by the log-domain kernel.
               const T lw = H0 + ne;
               w_c = leaf_weight_exp<(CPW == 1)>(lw);
-              sa_c = w_c >= T(1) ? T(1) : w_c;  // exp(min(0, ℓw)) = min(1, W), NaN-propagating like Julia's min
+              sa_leaf = w_c >= T(1) ? T(1) : w_c;  // exp(min(0, ℓw)) = min(1, W), NaN-propagating like Julia's min
               redo = redo || AHMC_UNI(lw > (sizeof(T) == 4 ? T(60) : T(LINW_LIMIT)));
             } else {
               w_c = H0 + ne;
@@ -490,6 +501,15 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             sub_term = AHMC_UNI(!(-H0 < p.delta_max + ne));  // Termination(::MultinomialTS, ...) (:503-507)
           }
           numerical = numerical || sub_term;
+#if AHMC_RUNNING_STATS
+          sa_c = sa_c + sa_leaf;                                     // over the leaves of this doubling, in build order
+          na_c = na_c + 1;
+          dh_c = v > 0 ? maxabs(dh_c, dH) : maxabs(dH, dh_c);        // (maxabs keeps the right-hand one on a tie, :526)
+#else
+          sa_c = sa_leaf;
+          na_c = 1;
+          dh_c = dH;
+#endif
           // a one-leaf subtree has ρ = r (Classic: θ) and first-built r = r of this leaf.  The general kernel copies
           // them into A_c / RF_c here; the fast kernels read cur.r in their place until the first merge (below)
           if constexpr (GENERAL) {
@@ -520,10 +540,12 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             if (keep_first) ck_c = S_CK(lvl);
             w_c = w_new;
             // combine(treeleft, treeright) (:533-542); position order matters for maxabs only
+#if !AHMC_RUNNING_STATS
             sa_c = S_SA(lvl) + sa_c;
             na_c = S_NA(lvl) + na_c;
             const T dh_p = S_DH(lvl);
             dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+#endif
             // isterminated(tc, h, tree′, tleft, tright) on the merged subtree (:551-617)
             if (classic) {
               // ends: first-built leaf (A_p, RF_p) and the current leaf; Δθ = θ_right − θ_left
@@ -602,6 +624,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         if (alive && sub_term) {
           // enclosing unfinished subtrees still absorb the statistics of their first halves
           // (tree′ = combine(treeleft, treeright) at every level that is a second half, :666)
+#if !AHMC_RUNNING_STATS
           const uint32_t pend = ((leaf - 1u) >> merged) << merged;
           for (int q = merged; (pend >> q) != 0u; ++q) {
             if ((pend >> q) & 1u) {
@@ -611,6 +634,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
               dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
             }
           }
+#endif
           alive = false;
         } else if (alive && leaf < nleaf) {
           // park the finished level-nm subtree until its sibling is built
@@ -622,9 +646,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           }
           if (strict) sl.store(NV * nm + 2, cur.r);  // r of its last-built leaf
           S_W(nm) = w_c;
+#if !AHMC_RUNNING_STATS
           S_SA(nm) = sa_c;
           S_DH(nm) = dh_c;
           S_NA(nm) = na_c;
+#endif
           S_CK(nm) = ck_c;
         }
       }

@@ -133,10 +133,79 @@ def scan(text, label, quiet=False):
             if d < r and outside and all(all_stores.get(off, [True])) and straight:
                 bad.append((kernel, i + 1, t + f"   [value defined {i - d} instructions earlier, region opened {i - r} earlier]", len(outside)))
 
+    def flush_nested():
+        """Second pass (round 4), for what the straight-line pass cannot see: regions NESTED inside the narrowed one (a store
+        behind an inner `s_and_saveexec … s_or_b64 exec` pair is still under the outer mask) and regions with branches in them.
+        Regions are taken from their skip branches — `s_and(n2)_saveexec_b64 D, S ; s_cbranch_execz L` narrows exec for the
+        ADDRESS RANGE up to L, whatever is nested or branches inside it — so no stack has to survive the control flow.  A spill
+        SLOT is reported when every store to it in the whole kernel lies inside such a range, one of those stores saves a value
+        that was made BEFORE its range opened (all lanes hold it, only the active ones reach the slot), and a reload of the slot
+        lies outside the ranges the stores are in.  Found on the MI355X as a memory fault of k_nuts<double,8,2,3,1>: the spills
+        of the chain index and of the lane's first dimension landed at the end of the `if (on && kt > 0)` block of the prologue —
+        at kt = 0 no lane enters it and the epilogue reloads uninitialised scratch."""
+        if not kernel:
+            return
+        regions = []          # (index of the saveexec, first index after the range)
+        idx_of = {a: i for i, a in enumerate(addrs) if a >= 0}
+        for i, t in enumerate(lines[:-1]):
+            if re.match(r"s_and(n2)?_saveexec_b64", t) and re.match(r"s_cbranch_execz", lines[i + 1]):
+                mt = re.search(r"<[^>]*\+0x([0-9a-f]+)>", lines[i + 1])
+                if mt and (kbase + int(mt.group(1), 16)) in idx_of:
+                    j = idx_of[kbase + int(mt.group(1), 16)]
+                    # (the branch lands on or before the `s_or_b64 exec, exec, D` that restores the mask: spills the allocator
+                    # puts between the two still run under the narrowed — or empty — mask)
+                    dreg = re.match(r"s_and(?:n2)?_saveexec_b64 (\S+),", t).group(1)
+                    k = next((q for q in range(j, min(j + 40, len(lines))) if re.match(r"s_or_b64 exec, exec, " + re.escape(dreg), lines[q])), j)
+                    if k > i:
+                        regions.append((i, k))
+
+        def inside(i):
+            return tuple(r for r in regions if r[0] < i < r[1])
+
+        def writes(t, lo, hi):
+            mm = re.match(r"(v_\w+|scratch_load_\w+|global_load_\w+|flat_load_\w+|ds_read\w*|buffer_load_\w+)\s+v\[?(\d+)(?::(\d+))?\]?", t)
+            if not mm or mm.group(1).startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                return False
+            a, b = int(mm.group(2)), int(mm.group(3) or mm.group(2))
+            return a <= hi and b >= lo
+
+        stores, loads = {}, {}
+        for i, t in enumerate(lines):
+            op = t.split("//")[0].strip()
+            m = re.match(r"scratch_store_\w+ off, v\[?(\d+)(?::(\d+))?\]?, off(?: offset:(\d+))?$", op)
+            if m:
+                stores.setdefault(int(m.group(3) or 0), []).append((i, inside(i), int(m.group(1)), int(m.group(2) or m.group(1))))
+                continue
+            m = re.match(r"scratch_load_\w+ v\S+, off, off(?: offset:(\d+))?$", op)
+            if m:
+                loads.setdefault(int(m.group(1) or 0), []).append((i, inside(i)))
+        def innermost(ins):
+            return min(ins, key=lambda r: r[1] - r[0]) if ins else None
+
+        for off, st in stores.items():
+            # a reload is in danger when NO store of the slot runs under a mask that covers the reload's lanes: every store's
+            # innermost narrowed range must exclude the reload (a store outside all ranges covers everything)
+            inner = [innermost(ins) for _, ins, _, _ in st]
+            if any(r is None for r in inner):
+                continue
+            out = [i for i, _ in loads.get(off, []) if all(not (r[0] < i < r[1]) for r in inner)]
+            if not out:
+                continue
+            live_in = []
+            for (i, ins, lo, hi), r in zip(st, inner):
+                d = next((j for j in range(i - 1, -1, -1) if writes(lines[j], lo, hi)), -1)
+                if d < r[0]:
+                    live_in.append(i)
+            if not live_in and not os.environ.get("AHMC_ISA_STRICT"):
+                continue
+            i0 = (live_in or [st[0][0]])[0]
+            bad.append((kernel, i0 + 1, lines[i0].split("//")[0].strip() + f"   [slot {off}: none of its {len(st)} store(s) runs under a mask that covers the reload(s); nested regions followed]", len(out)))
+
     for raw in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", raw.strip())
         if m:
             flush()
+            flush_nested()
             kernel, lines, addrs, targets = m.group(1), [], [], set()
             kbase = int(raw.strip().split()[0], 16)
             continue
@@ -149,6 +218,7 @@ def scan(text, label, quiet=False):
             if mt:
                 targets.add(int(mt.group(1), 16))
     flush()
+    flush_nested()
     names = subprocess.run(["c++filt"], input="\n".join(b[0] for b in bad), capture_output=True, text=True).stdout.splitlines() if bad else []
     for (k, ln, t, n), nm in zip(bad, names):
         if quiet:
