@@ -49,11 +49,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
          "-Wno-unused-parameter"]
 
 
+PART_B_FLAGS = ["-mllvm", "-disable-machine-licm"]
+
+
 def _units():
     units = [("api", "ahmc_api.hip", [])]
     for tname, tdef in (("f32", "float"), ("f64", "double")):
         for tk in range(4):
-            units.append((f"inst_{tname}_t{tk}", "ahmc_inst.hip", [f"-DAHMC_INST_T={tdef}", f"-DAHMC_INST_TK={tk}"]))
+            # part A: everything but …; part B: the warm-up instantiations of k_nuts and all of the multi-wave geometries', with the
+            # machine-level LICM off (ahmc_inst.hpp: nuts_in_part_b — they are at their register cap and spill what it hoists)
+            units.append((f"inst_{tname}_t{tk}", "ahmc_inst.hip", [f"-DAHMC_INST_T={tdef}", f"-DAHMC_INST_TK={tk}", "-DAHMC_INST_PART=0"]))
+            units.append((f"inst_{tname}_t{tk}b", "ahmc_inst.hip", [f"-DAHMC_INST_T={tdef}", f"-DAHMC_INST_TK={tk}", "-DAHMC_INST_PART=1", *PART_B_FLAGS]))
     return units
 
 
@@ -64,7 +70,7 @@ def _sources_digest() -> str:
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(INCLUDE, "ahmc_hip.h"), "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + PART_B_FLAGS).encode())
     return h.hexdigest()
 
 

@@ -29,48 +29,80 @@ void Inst<T, TK>::find_eps(int G, int E, unsigned grid, hipStream_t s, const KP<
   GEO_LAUNCH(k_find_eps, p, eps_out);
 }
 
-template <class T, int TK>
-int Inst<T, TK>::nuts_occupancy(int G, int E, int mode, size_t smem) {
-  int occ = 0;
-  hipError_t err = hipErrorInvalidValue;
+// k_nuts of one (geometry, mode): the three things the host does with it.  PART_B selects which half of the instantiations this
+// function body may name (nuts_in_part_b): the other half is compiled in the other translation unit.
+template <class T, int TK, bool PART_B, class F>
+static void with_nuts_kernel(int G, int E, int mode, F&& f) {
   with_geometry(G, E, [&](auto g, auto e) {
     constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    if (mode == 0) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 0, TK>, (GG > 64 ? GG : 64), smem);
-    else if (mode == 1) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 1, TK>, (GG > 64 ? GG : 64), smem);
-    else if (mode == 3) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 3, TK>, (GG > 64 ? GG : 64), smem);
-    else if (mode == 4) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 4, TK>, (GG > 64 ? GG : 64), smem);
-    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_nuts<T, GG, EE, 2, TK>, (GG > 64 ? GG : 64), smem);
+    auto one = [&](auto m) {
+      constexpr int M = decltype(m)::value;
+      if constexpr (nuts_in_part_b(GG, M) == PART_B) f(reinterpret_cast<const void*>(&k_nuts<T, GG, EE, M, TK>), std::integral_constant<int, GG>{});
+    };
+    if (mode == 0) one(std::integral_constant<int, 0>{});
+    else if (mode == 1) one(std::integral_constant<int, 1>{});
+    else if (mode == 3) one(std::integral_constant<int, 3>{});
+    else if (mode == 4) one(std::integral_constant<int, 4>{});
+    else one(std::integral_constant<int, 2>{});
+  });
+}
+template <class T, int TK, bool PART_B>
+static int nuts_occupancy_impl(int G, int E, int mode, size_t smem) {
+  int occ = 0;
+  hipError_t err = hipErrorInvalidValue;
+  with_nuts_kernel<T, TK, PART_B>(G, E, mode, [&](const void* f, auto gg) {
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, f, (decltype(gg)::value > 64 ? decltype(gg)::value : 64), smem);
   });
   return err == hipSuccess ? occ : 0;
 }
-
-template <class T, int TK>
-void Inst<T, TK>::nuts_set_smem(int G, int E, int mode, size_t smem) {
-  with_geometry(G, E, [&](auto g, auto e) {
-    constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    const void* f = mode == 0   ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 0, TK>)
-                    : mode == 1 ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 1, TK>)
-                    : mode == 3 ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 3, TK>)
-                    : mode == 4 ? reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 4, TK>)
-                                : reinterpret_cast<const void*>(&k_nuts<T, GG, EE, 2, TK>);
-    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  });
+template <class T, int TK, bool PART_B>
+static void nuts_set_smem_impl(int G, int E, int mode, size_t smem) {
+  with_nuts_kernel<T, TK, PART_B>(G, E, mode, [&](const void* f, auto) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
   (void)hipGetLastError();
 }
-
-template <class T, int TK>
-void Inst<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
-  with_geometry(G, E, [&](auto g, auto e) {
-    constexpr int GG = decltype(g)::value, EE = decltype(e)::value;
-    if (mode == 0) hipLaunchKernelGGL((k_nuts<T, GG, EE, 0, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
-    else if (mode == 1) hipLaunchKernelGGL((k_nuts<T, GG, EE, 1, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
-    else if (mode == 3) hipLaunchKernelGGL((k_nuts<T, GG, EE, 3, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
-    else if (mode == 4) hipLaunchKernelGGL((k_nuts<T, GG, EE, 4, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
-    else hipLaunchKernelGGL((k_nuts<T, GG, EE, 2, TK>), dim3(grid), dim3(64 * wpb), smem, s, p);
+template <class T, int TK, bool PART_B>
+static void nuts_impl(int G, int E, int mode, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
+  with_nuts_kernel<T, TK, PART_B>(G, E, mode, [&](const void* f, auto) {
+    KP<T> arg = p;
+    void* args[] = {&arg};
+    (void)hipLaunchKernel(f, dim3(grid), dim3(64 * wpb), args, smem, s);
   });
 }
 
+#if !defined(AHMC_INST_PART) || AHMC_INST_PART == 0
+template <class T, int TK>
+int Inst<T, TK>::nuts_occupancy(int G, int E, int mode, size_t smem) {
+  return nuts_in_part_b(G, mode) ? InstB<T, TK>::nuts_occupancy(G, E, mode, smem) : nuts_occupancy_impl<T, TK, false>(G, E, mode, smem);
+}
+template <class T, int TK>
+void Inst<T, TK>::nuts_set_smem(int G, int E, int mode, size_t smem) {
+  if (nuts_in_part_b(G, mode)) InstB<T, TK>::nuts_set_smem(G, E, mode, smem);
+  else nuts_set_smem_impl<T, TK, false>(G, E, mode, smem);
+}
+template <class T, int TK>
+void Inst<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
+  if (nuts_in_part_b(G, mode)) InstB<T, TK>::nuts(G, E, mode, grid, wpb, smem, s, p);
+  else nuts_impl<T, TK, false>(G, E, mode, grid, wpb, smem, s, p);
+}
+#endif
+#if !defined(AHMC_INST_PART) || AHMC_INST_PART == 1
+template <class T, int TK>
+int InstB<T, TK>::nuts_occupancy(int G, int E, int mode, size_t smem) { return nuts_occupancy_impl<T, TK, true>(G, E, mode, smem); }
+template <class T, int TK>
+void InstB<T, TK>::nuts_set_smem(int G, int E, int mode, size_t smem) { nuts_set_smem_impl<T, TK, true>(G, E, mode, smem); }
+template <class T, int TK>
+void InstB<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
+  nuts_impl<T, TK, true>(G, E, mode, grid, wpb, smem, s, p);
+}
+template struct InstB<AHMC_INST_T, AHMC_INST_TK>;
+#endif
+
+#if !defined(AHMC_INST_PART) || AHMC_INST_PART == 0
+#if defined(AHMC_INST_PART)
+extern template struct InstB<AHMC_INST_T, AHMC_INST_TK>;   // (the other translation unit of this (T, TK))
+#endif
 template struct Inst<AHMC_INST_T, AHMC_INST_TK>;
+#endif
 
 #if AHMC_INST_TK == 4
 // ---- target plugin: the user's log-density (AHMC_USER_TARGET_HEADER, see include/ahmc_user_target.h) compiled into every

@@ -46,6 +46,21 @@ struct Inst {
   static void nuts(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
 };
 
+// The NUTS kernels come in two PARTS that are compiled with different optimiser settings (round 4, build.py): part B — the
+// warm-up instantiations (MODE 3 / 4, adapt! inside the kernel) of every geometry and every instantiation of the multi-wave
+// geometries (G > 64) — is built with the machine-level loop-invariant code motion off.  Those kernels are at their register cap,
+// and what LICM hoists out of their transition loop (the f64 constants of exp / log in the adaptor's arithmetic, addresses) it then
+// has to spill and reload in every transition: k_nuts<double,64,2,3,0> 240 → 48 B of scratch per lane, <double,256,8,3,3> 596 →
+// 380; cfg5 9.6e7 → 1.12e8 leapfrog/s, cfg2's warm-up +1.6 %.  The sampling kernels of the single-wave geometries lose by it
+// (cfg2 draws −1.5 %, cfg3 −4 %: their hot loop re-materialises what was hoisted), so they stay in part A.
+constexpr bool nuts_in_part_b(int G, int mode) { return mode >= 3 || G > 64; }
+template <class T, int TK>
+struct InstB {
+  static int nuts_occupancy(int G, int E, int mode, size_t smem);
+  static void nuts_set_smem(int G, int E, int mode, size_t smem);
+  static void nuts(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
+};
+
 // The launch table of one Inst<T, TK> as plain function pointers: what the host API calls.  The four built-in families
 // fill it from the instantiations linked into the library; a user log-density compiled INTO the trajectory kernels
 // (TK = AHMC_TK_PLUGIN, `ahmc_set_target_plugin`) fills it from the plugin .so's own Inst<T, 4> behind dlopen.

@@ -27,6 +27,9 @@
 #define AHMC_SCALAR_ANY 1      // loop-control predicates of a wave-owning chain are tested directly instead of through a ballot (0: ballot)
 #endif
 
+#ifndef AHMC_ADAPT_REREAD
+#define AHMC_ADAPT_REREAD 1   // the warm-up kernels re-read the adaptor's argument block in every epilogue instead of carrying it (below)
+#endif
 #ifndef AHMC_RUNNING_STATS
 // 1: Σα, nα and ΔH_max of the subtree a doubling builds are RUNNING values over its leaves in build order — the statistics the
 // reference carries through every `combine` (src/trajectory.jl:533-542) are a sum, a count and a maximum of |·| over the same
@@ -298,7 +301,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   T th_cur[E];  // the chain's position, carried in registers from one transition to the next
   load_vec<T, E>(th_cur, p.th(), cc * p.D, d0, p.D, T(0));
   // in-kernel adaptation state (MODE 3): dual averaging of this chain, its nominal step size, the Welford count
-  const AdaptK<T>* ak = ADAPT ? static_cast<const AdaptK<T>*>(p.adaptk) : nullptr;
+  const AdaptK<T>* ak0 = ADAPT ? static_cast<const AdaptK<T>*>(p.adaptk) : nullptr;
+  const AdaptK<T>* ak = ak0;
 
   // what adapt! does at batch-local transition kt2 (the same for every chain): push / update / reset of the variance
   // estimator and reset of the dual averaging — `adapt` in ahmc_api.hip, stan_adaptor.jl:137-159
@@ -781,6 +785,14 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         if (p.samples_out) store_vec<T, E>(zc.th, p.samples_out + (int64_t)kt * p.D * p.N, ce * p.D, d0, p.D);
         copy_vec(th_cur, zc.th);
         if constexpr (ADAPT) {
+#if AHMC_ADAPT_REREAD
+          // The adaptor's argument block is read HERE, once per transition, through a pointer the optimiser cannot see through: its
+          // fourteen array pointers and its schedule are loop-invariant, were hoisted out of the transition loop and — with the
+          // scalar registers full — lived in per-lane registers that were spilled to scratch and reloaded in every epilogue (30
+          // 64-bit spills, 54 reloads per transition in k_nuts<double,64,2,3,0>); scalar loads from the constant cache cost less
+          const AdaptK<T>* ak = ak0;
+          asm volatile("" : "+s"(ak));
+#endif
           // adapt!(h, κ, adaptor, i, n_adapts, z, α) + update(h/κ, adaptor) (src/sampler.jl:72-90, :3-22) for this chain —
           // the same decisions and the same arithmetic as the host path (`adapt` in ahmc_api.hip, k_adapt_da / k_adapt_wv)
           const int64_t i = ak->i0 + kt + 1;
