@@ -1028,21 +1028,36 @@ int stage_acquire(Ctx<T>* c, int slot, size_t need) {
   return AHMC_OK;
 }
 
+// the chain-independent part of adapt!'s state after one more adapting transition (what the kernel's `schedule` mirrors)
 template <class T>
-int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, int64_t n_adapts, bool accum, T* samples_dev) {
-  const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
-  const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
-  if (c->adapt_kind == AHMC_ADAPT_STAN && (i == 1 || c->windows_n_adapts != n_adapts)) {  // initialize!
-    c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);
-    c->windows_n_adapts = n_adapts;
+int advance_adapt_host(Ctx<T>* c, bool has_mm, bool pooled) {
+  if (c->adapt_kind == AHMC_ADAPT_STAN) {
+    c->stan_i += 1;
+    const bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
+    const bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
+    if (in_window && has_mm) c->wv_n += 1;
+    if (window_end && has_mm) {
+      if (pooled) {  // (ahmc_sample ends a pooled batch at every split, so this is the batch's last transition)
+        if (in_window && c->wv_n >= c->wv_nmin) { int rc2 = pooled_update(c); if (rc2) return rc2; }
+        HIPCHK(hipMemsetAsync(c->wv_mu, 0, sizeof(T) * c->D * c->N, c->stream));
+        HIPCHK(hipMemsetAsync(c->wv_M, 0, sizeof(T) * c->D * c->N, c->stream));
+      }
+      c->wv_n = 0;
+    }
+  } else if (has_mm) {
+    c->wv_n += 1;
   }
+  return AHMC_OK;
+}
+
+template <class T>
+AdaptK<T> make_adaptk(Ctx<T>* c, int64_t i, int64_t n_adapts, bool has_ss, bool has_mm, bool pooled) {
   AdaptK<T> a;
   memset(&a, 0, sizeof(a));
   a.kind = c->adapt_kind;
   a.has_ss = has_ss ? 1 : 0;
   a.has_mm = has_mm ? 1 : 0;
   a.nutpie = c->var_estimator == AHMC_VAR_NUTPIE ? 1 : 0;
-  const bool pooled = has_mm && c->var_estimator == AHMC_VAR_POOLED;
   a.pooled = pooled ? 1 : 0;
   a.i0 = i - 1;
   a.n_adapts = n_adapts;
@@ -1058,25 +1073,24 @@ int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, in
   a.wv_mu = c->wv_mu; a.wv_M = c->wv_M; a.wv_var = c->wv_var; a.wg_mu = c->wg_mu; a.wg_M = c->wg_M;
   a.minv = c->minv; a.sqrt_minv = c->sqrt_minv; a.eps_nom = c->eps_nom;
   a.da_tab = c->da_tab;
+  return a;
+}
+
+template <class T>
+int nuts_adapt_batch(Ctx<T>* c, const ahmc_kernel_cfg* cfg, int k, int64_t i, int64_t n_adapts, bool accum, T* samples_dev) {
+  const bool has_ss = c->adapt_kind != AHMC_ADAPT_MASSMATRIX;
+  const bool has_mm = c->adapt_kind != AHMC_ADAPT_STEPSIZE && c->metric_kind == AHMC_METRIC_DIAG;
+  if (c->adapt_kind == AHMC_ADAPT_STAN && (i == 1 || c->windows_n_adapts != n_adapts)) {  // initialize!
+    c->windows = stan_windows(c->stan_init, c->stan_term, c->stan_window, n_adapts);
+    c->windows_n_adapts = n_adapts;
+  }
+  const bool pooled = has_mm && c->var_estimator == AHMC_VAR_POOLED;
+  const AdaptK<T> a = make_adaptk(c, i, n_adapts, has_ss, has_mm, pooled);
   int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, accum, k, samples_dev, &a);
   if (rc) return rc;
   for (int kt = 0; kt < k; ++kt) {  // the chain-independent part of adapt!'s state
-    if (c->adapt_kind == AHMC_ADAPT_STAN) {
-      c->stan_i += 1;
-      const bool in_window = c->stan_i >= c->windows.window_start && c->stan_i <= c->windows.window_end;
-      const bool window_end = std::find(c->windows.splits.begin(), c->windows.splits.end(), c->stan_i) != c->windows.splits.end();
-      if (in_window && has_mm) c->wv_n += 1;
-      if (window_end && has_mm) {
-        if (pooled) {  // (ahmc_sample ends a pooled batch at every split, so this is the batch's last transition)
-          if (in_window && c->wv_n >= c->wv_nmin) { int rc2 = pooled_update(c); if (rc2) return rc2; }
-          HIPCHK(hipMemsetAsync(c->wv_mu, 0, sizeof(T) * c->D * c->N, c->stream));
-          HIPCHK(hipMemsetAsync(c->wv_M, 0, sizeof(T) * c->D * c->N, c->stream));
-        }
-        c->wv_n = 0;
-      }
-    } else if (has_mm) {
-      c->wv_n += 1;
-    }
+    rc = advance_adapt_host(c, has_mm, pooled);
+    if (rc) return rc;
   }
   if (has_ss) { c->eps_scalar = false; c->order_valid = false; c->sched = {}; }
   if (i + k - 1 >= n_adapts) c->adapting = false;
@@ -1863,6 +1877,10 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         }
         const int64_t j = i - (drop_warmup ? n_adapts : 0);
         T* dst = (so && keep) ? so + (size_t)(j - 1) * c->D * c->N : nullptr;
+        // (round 4, measured and dropped: the warm-up as 2 / 4 interleaved groups of chains, each a sequence of launches of 8 … 125
+        // transitions on its own stream, so that the slots one group's launch leaves empty at its end would be filled by the others'
+        // — cfg3 warm-up 1.81 / 1.10e9 (launches of 32) against 1.94e9 for the one launch, cfg2 2.31–2.38e9 against 2.59e9: the
+        // queues do not interleave at workgroup granularity, a group's launch only under-fills the chip)
         int rc = nuts_adapt_batch(c, cfg, (int)k, i, n_adapts, keep, dst);
         if (rc) return rc;
         if (keep) c->acc_ntrans += k;
