@@ -571,13 +571,19 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
     if constexpr (TK == 1) {  // AHMC_TARGET_DIAG_GAUSS: params = m[D], s[D]
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        bool ok = d0 + e < D;
-        T m = ok ? tp.params[d0 + e] : T(0);
-        T s = ok ? tp.params[D + d0 + e] : T(1);
-        T diff = m - th[e];
-        T s2 = s * s;
-        part += ok ? -(log2pi + 2 * log(s) + diff * diff / s2) / 2 : T(0);
-        grad[e] = ok ? -(diff / s2) : T(0);
+        // branch-free on purpose: padded elements (d >= D) read the last valid parameters and are zeroed by a select at the end.
+        // (With `ok ? load : 0` the loads, the log and the divisions sat in exec-masked blocks — which is where the register
+        // allocator then parked spills of values the other lanes need too: isa_check.py, round 4.)
+        const bool ok = d0 + e < D;
+        const int d = ok ? d0 + e : D - 1;
+        const T m = tp.params[d];
+        const T s = tp.params[D + d];
+        const T diff = m - th[e];
+        const T s2 = s * s;
+        const T val = -(log2pi + 2 * log(s) + diff * diff / s2) / 2;
+        const T gv = -(diff / s2);
+        part += ok ? val : T(0);
+        grad[e] = ok ? gv : T(0);
       }
 
     }

@@ -398,6 +398,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     int depth = 0;
     bool done = !on;
 
+    // (round 4, measured and dropped: a wave raising its issue priority — s_setprio 3 — from doubling 5 / 7 / 9 of a tree to the end of
+    // the transition, so that the deep trees every launch waits for would step faster: cfg3 2.47 / 2.52 / 2.56e9 against 2.49e9
+    // without, cfg2 and cfg5 unchanged — within the run-to-run spread.  A lone deep tree is bound by the latency of its own chain of
+    // dependent reductions, not by the issue slots it shares.)
     for (int jw = 0; jw < p.max_depth; ++jw) {  // doubling loop (:691-723), wave-uniform
       if (!AHMC_ANY(!done)) break;
       // ---- direction (:693) and edge selection ----

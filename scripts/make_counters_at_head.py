@@ -18,8 +18,8 @@ from ahmc_amd import isa_check  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import valu_mix  # noqa: E402
 
-ROUND = os.environ.get("AHMC_ROUND", "r3")
-RATES = os.path.join(ROOT, "profiles", f"{ROUND}_valu_rate.json")   # scripts/probe/valu_rate.hip on the MI355X
+ROUND = os.environ.get("AHMC_ROUND", "r4")
+RATES = os.path.join(ROOT, "profiles", "r3_valu_rate.json")   # scripts/probe/valu_rate.hip on the MI355X
 
 
 def kernel_text(kernel_name):
@@ -29,7 +29,9 @@ def kernel_text(kernel_name):
     m = re.search(r"k_nuts<(double|float), (\d+), (\d+), (\d+), (\d+)>", kernel_name)
     if not m:
         return None
-    unit = os.path.join(OBJ, f"inst_{'f64' if m.group(1) == 'double' else 'f32'}_t{m.group(5)}.o")
+    # (round 4: the warm-up instantiations and the multi-wave geometries are built in the unit's part B, ahmc_inst.hpp: nuts_in_part_b)
+    part_b = int(m.group(4)) >= 3 or int(m.group(2)) > 64
+    unit = os.path.join(OBJ, f"inst_{'f64' if m.group(1) == 'double' else 'f32'}_t{m.group(5)}{'b' if part_b else ''}.o")
     if not os.path.exists(unit):
         return None
     with tempfile.TemporaryDirectory(prefix="ahmc_isa_") as tmp:
