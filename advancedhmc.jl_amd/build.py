@@ -108,13 +108,48 @@ def kernel_digest() -> str:
     return h.hexdigest()
 
 
+def unit_digests() -> dict:
+    """digest of the device code of every instantiation unit, by unit name (`inst_f64_t0`, `inst_f64_t0b`, …): what PMC counters
+    of ONE config are keyed on — the config's log-density family lives in two units (parts A and B), and an edit that changes
+    another family's code does not invalidate them.  From the object cache, else from the stamp next to the .so."""
+    import json
+
+    out = {}
+    for name, _, _ in _units():
+        if not name.startswith("inst_"):
+            continue
+        f = os.path.join(OBJ, name + ".o.isa")
+        if not os.path.exists(f):
+            try:
+                return json.load(open(OUT + ".kdigests"))
+            except (OSError, ValueError):
+                return {}
+        out[name] = hashlib.sha256(open(f).read().strip().encode()).hexdigest()
+    return out
+
+
+def config_digest(tk: int, dtype: str = "f64", digests=None) -> str:
+    """digest of the two units that hold the kernels of log-density family `tk` (0 iso, 1 diag, 2 funnel, 3 hier) for `dtype`"""
+    d = unit_digests() if digests is None else digests
+    a, b = d.get(f"inst_{dtype}_t{tk}"), d.get(f"inst_{dtype}_t{tk}b")
+    return hashlib.sha256(f"{a}|{b}".encode()).hexdigest() if a and b else ""
+
+
+def _write_stamps():
+    import json
+
+    with open(OUT + ".kdigest", "w") as f:  # (travels with the .so: the GPU box never sees a stale pairing)
+        f.write(kernel_digest())
+    with open(OUT + ".kdigests", "w") as f:
+        json.dump(unit_digests(), f)
+
+
 def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     digest = _sources_digest()
     stamp = OUT + ".digest"  # next to the .so (the object cache is outside the repo and does not travel to the GPU box)
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == digest:
-        if not os.path.exists(OUT + ".kdigest"):
-            with open(OUT + ".kdigest", "w") as f:
-                f.write(kernel_digest())
+        if not os.path.exists(OUT + ".kdigest") or not os.path.exists(OUT + ".kdigests"):
+            _write_stamps()
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -184,8 +219,7 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
             os.remove(os.path.join(CSRC, f))
     with open(stamp, "w") as f:
         f.write(digest)
-    with open(OUT + ".kdigest", "w") as f:  # (travels with the .so: the GPU box never sees a stale pairing)
-        f.write(kernel_digest())
+    _write_stamps()
     if verbose:
         print("linked", OUT)
     return OUT

@@ -75,12 +75,19 @@ def algorithmic_bytes_per_leapfrog(D, metric, itemsize):
     return (6 * D + (D if metric == "diag" else 0)) * itemsize + 4 * itemsize
 
 
-def sources_digest():
-    """digest of the DEVICE code of the trajectory kernels + compiler flags the shipped libahmc_hip.so was built from
-    (advancedhmc.jl_amd/build.py: kernel_digest)"""
+CONFIG_FAMILY = {"cfg2": 0, "cfg3": 2, "cfg5": 3}   # the log-density family (TK) whose instantiation units hold a config's k_nuts
+
+
+def sources_digest(config="cfg2"):
+    """digest of the DEVICE code of the two instantiation units that hold `config`'s trajectory kernels in the shipped
+    libahmc_hip.so (advancedhmc.jl_amd/build.py: config_digest — the stamp libahmc_hip.so.kdigests travels with the library)"""
+    import hashlib
     try:
-        return open(os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.kdigest")).read().strip()
-    except OSError:
+        d = json.load(open(os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.kdigests")))
+        tk = CONFIG_FAMILY[config]
+        a, b = d[f"inst_f64_t{tk}"], d[f"inst_f64_t{tk}b"]
+        return hashlib.sha256(f"{a}|{b}".encode()).hexdigest()
+    except (OSError, ValueError, KeyError):
         return None
 
 
@@ -91,11 +98,11 @@ def counters_at_head(config):
             d = json.load(f)
     except Exception:
         return None, "profiles/counters_at_head.json is missing"
-    if d.get("sources_digest") != sources_digest():
-        return None, "profiles/counters_at_head.json was taken on other kernel sources (digest mismatch): stale, not used"
     c = d.get("configs", {}).get(config)
     if not c:
         return None, f"profiles/counters_at_head.json has no counters for {config}"
+    if c.get("unit_digest") != sources_digest(config):
+        return None, f"profiles/counters_at_head.json: the counters of {config} were taken on other device code (digest mismatch): stale, not used"
     return c, d.get("source", "profiles/counters_at_head.json")
 
 

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ahmc_amd as A  # noqa: E402
-from ahmc_amd.build import kernel_digest, OBJ  # noqa: E402
+from ahmc_amd.build import kernel_digest, config_digest, OBJ  # noqa: E402
 from ahmc_amd import isa_check  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import valu_mix  # noqa: E402
@@ -51,22 +51,23 @@ head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=Tr
 path = os.path.join(ROOT, "profiles", "counters_at_head.json")
 try:
     out = json.load(open(path))
-    if out.get("sources_digest") != kd:
-        out = None
 except Exception:
-    out = None
-if out is None:
-    out = {"sources_digest": kd, "configs": {}}
+    out = {"configs": {}}
+out["sources_digest"] = kd   # (informational: validity is per config, `unit_digest` below)
+FAMILY = {"cfg2": 0, "cfg3": 2, "cfg5": 3}
 out["source"] = ("rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* | SQ_ACTIVE_* | GRBM_*; --kernel-trace only) over "
                  "`python bench.py --config <cfg> --warmup 0 --repeats 1 --ess 0 --no-cpu-baseline` (scripts/profile_head.sh), "
                  "distilled by scripts/profile_counters.py; valid for the device code with this digest only")
 out["taken_at_commit_after"] = head
 for cfg in sys.argv[1:]:
     s = json.load(open(os.path.join(ROOT, "gpurun_out", f"prof_{cfg}", "summary.json")))
-    if s.get("kernel_digest") != kd:
-        print(f"{cfg}: counters were taken on kernel digest {s.get('kernel_digest')}, the tree has {kd}: NOT used")
+    # valid if the two units that hold this config's kernels are the ones the counters were taken on
+    ud_then = config_digest(FAMILY[cfg], "f64", s.get("unit_digests") or {}) if cfg in FAMILY else ""
+    ud_now = config_digest(FAMILY[cfg]) if cfg in FAMILY else ""
+    if not ud_then or ud_then != ud_now:
+        print(f"{cfg}: counters were taken on other device code (units of family {FAMILY.get(cfg)}: {ud_then[:12]} then, {ud_now[:12]} now): NOT used")
         continue
-    c = {}
+    c = {"unit_digest": ud_now}
     for mode, r in s["counters"].items():
         c[mode] = {k: r.get(k) for k in ("valu_per_leapfrog", "salu_per_leapfrog", "lds_per_leapfrog", "vmem_per_leapfrog", "mfma_f64_per_leapfrog",
                                           "hbm_bytes_per_leapfrog", "valu_busy", "mean_waves_per_simd", "valu_mix_per_leapfrog")}

@@ -19,6 +19,7 @@ out = {"config": CFG}
 try:  # the device-code digest of the library these counters were taken on (advancedhmc.jl_amd/build.py: kernel_digest)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out["kernel_digest"] = open(os.path.join(root, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.kdigest")).read().strip()
+    out["unit_digests"] = json.load(open(os.path.join(root, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.kdigests")))
     out["command"] = open(os.path.join(O, "cmd.txt")).read().strip()
 except OSError:
     pass

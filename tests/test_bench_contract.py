@@ -75,18 +75,18 @@ def test_counters_are_refused_when_taken_on_other_kernels(tmp_path, monkeypatch)
     import importlib
 
     bench = importlib.import_module("bench")
-    real = bench.sources_digest()
+    real = bench.sources_digest("cfg2")
     prof = tmp_path / "profiles"
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    monkeypatch.setattr(bench, "sources_digest", lambda: real or "d" * 64)
-    good = {"sources_digest": real or "d" * 64, "source": "test", "configs": {"cfg2": {"mode0": {"valu_per_leapfrog": 190.0}}}}
+    monkeypatch.setattr(bench, "sources_digest", lambda config="cfg2": real or "d" * 64)
+    good = {"source": "test", "configs": {"cfg2": {"unit_digest": real or "d" * 64, "mode0": {"valu_per_leapfrog": 190.0}}}}
     (prof / "counters_at_head.json").write_text(json.dumps(good))
     c, why = bench.counters_at_head("cfg2")
     assert c["mode0"]["valu_per_leapfrog"] == 190.0 and why == "test"
     c, why = bench.counters_at_head("cfg3")
     assert c is None and "cfg3" in why
-    good["sources_digest"] = "0" * 64
+    good["configs"]["cfg2"]["unit_digest"] = "0" * 64
     (prof / "counters_at_head.json").write_text(json.dumps(good))
     c, why = bench.counters_at_head("cfg2")
     assert c is None and "stale" in why
