@@ -580,6 +580,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
                   dots[0] += A_c[e] * (minv[e] * RF_p[e]);
                   dots[1] += A_c[e] * (minv[e] * cur.r[e]);
                 }
+                // (round 4, measured and dropped: the signs of the two sums from a single-precision all-reduce — the lane partials made in
+                // double, converted, four values in one float reduction with DPP-fused adds, 27 instructions instead of 34 — with
+                // the double reduction only inside an error band of 2⁻¹⁹ Σ(|p₀| + |p₁|): decisions identical, every GPU test green,
+                // and not faster: cfg2 draws 3.228e9 against 3.243e9 in-kernel, cfg3 2.41e9 against 2.54e9 whole loop.  The chain of
+                // dependent stages is as long as before and the DPP hazards leave wait states where the double version has work.)
                 group_allsum<G>(dots);
               }
               sub_term = AHMC_UNI(dots[0] <= 0) || AHMC_UNI(dots[1] <= 0);  // generalised_uturn_criterion (:619-621)
