@@ -1860,7 +1860,10 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         // warm-up in batches too: adapt! runs inside the kernel (k_nuts MODE 3), no per-transition launch
         // (round 4, measured and dropped: the warm-up in launches of 8 / 32 / 64 transitions, each ordered by the work of the one before
         // it — cfg3 1.98 / 2.00e9 against 1.98e9 for one launch ordered by step size, cfg2 2.27e9 against 2.39e9: while the step
-        // sizes still move a launch's work does not predict the next one's any better than ϵ does, and every launch pays its tail)
+        // sizes still move a launch's work does not predict the next one's any better than ϵ does, and every launch pays its tail.
+        // Nor does a PILOT: the first 50 / 100 / 200 transitions as a launch of their own and the rest ordered by the work measured
+        // in it — cfg3 warm-up 1.99 / 1.96 / 1.90e9 against 2.05e9, cfg2 2.54e9 against 2.57e9.  The one launch's wave timeline
+        // (profiles/r4_cfg3_wave_timeline_warmup_launch.json): fill 0.65, the longest wave 0.48 of the launch)
         const int64_t left = std::min(n_adapts, n_samples) - i + 1, nb_left = (left + batch - 1) / batch;  // (a run may end mid-warm-up)
         int64_t k = (left + nb_left - 1) / nb_left;
         if (c->var_estimator == AHMC_VAR_POOLED && c->adapt_kind == AHMC_ADAPT_STAN && c->metric_kind == AHMC_METRIC_DIAG) {

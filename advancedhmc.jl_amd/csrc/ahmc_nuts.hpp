@@ -797,8 +797,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #if AHMC_ADAPT_REREAD
           // The adaptor's argument block is read HERE, once per transition, through a pointer the optimiser cannot see through: its
           // fourteen array pointers and its schedule are loop-invariant, were hoisted out of the transition loop and — with the
-          // scalar registers full — lived in per-lane registers that were spilled to scratch and reloaded in every epilogue (30
-          // 64-bit spills, 54 reloads per transition in k_nuts<double,64,2,3,0>); scalar loads from the constant cache cost less
+          // scalar registers full — lived in per-lane registers that were spilled to scratch and reloaded in every epilogue.
+          // (Measured: the scratch footprint did not change — what is spilled there turned out to be the f64 constants of exp / log,
+          // which the build now keeps inside the loop by compiling these kernels without machine LICM, build.py PART_B_FLAGS.  Kept:
+          // without it the allocator parks a spill under a narrowed exec mask in k_nuts<float,32,4,4,1>, which isa_check refuses.)
           const AdaptK<T>* ak = ak0;
           asm volatile("" : "+s"(ak));
 #endif
