@@ -624,6 +624,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         } else if (nm > 0) {
           // first merge peeled: the completed half is the single leaf `cur` (its vector work was done with the leaf);
           // later merges carry A_c / RF_c
+          // (round 4, measured and dropped: TWO merge levels per all-reduce — the ρ of level l + 1 is a vector sum, known without
+          // the reduction, so the four dot products of a leaf's first two merges can be reduced together (45 VALU and one chain of
+          // dependent stages instead of 2 × 30 and two), the scalar work then run in the reference's order.  Bit-identical, and
+          // slower: the four vectors live across the reduction push k_nuts<double,64,2,0,0> from 12 to 128 B of scratch per
+          // lane, inside the leaf loop — cfg2 2.89e9 → 2.41e9, cfg3 2.49e9 → 2.25e9.)
           bool m = AHMC_UNI(alive && !sub_term);
           if (AHMC_ANY(m)) {
             if (m) merge_level(0, cur.r, cur.r, std::bool_constant<FUSE_M0>{});
