@@ -7,7 +7,8 @@ hands every other lane stale memory.  It is what made the (128,8) multi-wave ins
 and fault on the MI355X when its leaf used the single-value reduction (the spilled value was the chain index, reloaded to
 address the chain's vectors): DESIGN.md §7.3, advancedhmc.jl_amd/isa_check.py.  The scan is part of the BUILD (`build.py` runs it on
 every unit it compiles and fails on a finding); here: the build is wired to it, the scanner flags the known-bad shape, and
-the tree that travels to the GPU box stays small."""
+the tree that travels to the GPU box stays small.  Round 4: the second pass of the scan (regions nested inside the narrowed
+one, followed by the address range of their skip branch) on the shape that faulted k_nuts<double,8,2,3,1> on the MI355X."""
 import os
 import subprocess
 import sys
@@ -83,3 +84,49 @@ def test_scanner_flags_the_known_bad_pattern(tmp_path):
     rg = subprocess.run([sys.executable, script, str(fg)], capture_output=True, text=True)
     assert rb.returncode == 1 and "offset:252" in rb.stdout, rb.stdout + rb.stderr
     assert rg.returncode == 0, rg.stdout + rg.stderr
+
+
+# the shape that faulted on the MI355X in round 4, reduced: an `if (on && kt > 0)` block of the transition prologue — a narrowed
+# region with a skip branch, a NESTED narrowed region inside it (the aligned / unaligned store paths), and at its very end, still
+# under the outer mask, the spills of two values every lane needs later.  At kt = 0 no lane enters the block.
+_MASKED = """
+0000000000001000 <_ZN4ahmc6k_testEv>:
+	v_mov_b32_e32 v24, v1                                      // 000000001000: 7E300301
+	v_mov_b32_e32 v25, v2                                      // 000000001004: 7E320302
+	s_and_saveexec_b64 s[10:11], s[0:1]                        // 000000001008: BE8A2000
+	s_cbranch_execz 9                                          // 00000000100C: BF880009 <_ZN4ahmc6k_testEv+0x34>
+	v_lshl_add_u64 v[6:7], v[6:7], 3, s[94:95]                 // 000000001010: D2080006 01790706
+	s_and_saveexec_b64 s[2:3], vcc                             // 000000001018: BE82206A
+	s_cbranch_execz 2                                          // 00000000101C: BF880002 <_ZN4ahmc6k_testEv+0x28>
+	global_store_dwordx2 v[6:7], v[86:87], off                 // 000000001020: DC748000 007F5606
+	s_or_b64 exec, exec, s[2:3]                                // 000000001028: 87FE027E
+	global_store_dwordx4 v[6:7], v[86:89], off                 // 00000000102C: DC7C8000 007F5606
+	s_mov_b64 s[92:93], s[56:57]                               // 000000001034: BEDC0138
+	scratch_store_dwordx2 off, v[24:25], off offset:24         // 000000001038: DC744018 007F1800
+	s_or_b64 exec, exec, s[10:11]                              // 000000001040: 87FE0A7E
+	v_mov_b32_e32 v24, 0                                       // 000000001044: 7E300280
+	v_mov_b32_e32 v25, 0                                       // 000000001048: 7E320280
+	scratch_load_dwordx2 v[8:9], off, off offset:24            // 00000000104C: DC544018 087F0000
+	s_waitcnt vmcnt(0)                                         // 000000001054: BF8C0F70
+	global_load_dwordx2 v[38:39], v[8:9], off                  // 000000001058: DC548000 267F0008
+	s_endpgm                                                   // 000000001060: BF810000
+"""
+
+
+def test_nested_region_scan_flags_the_shape_that_faulted_on_the_gpu():
+    from ahmc_amd import isa_check
+
+    assert isa_check.scan(_MASKED, "reduced", quiet=True) == 1
+    # the same code with the spill BEFORE the block (under the kernel's own mask) is what a correct allocation looks like
+    lines = _MASKED.splitlines()
+    spill = next(i for i, l in enumerate(lines) if "scratch_store_dwordx2" in l)
+    first = next(i for i, l in enumerate(lines) if "s_and_saveexec_b64 s[10:11]" in l)
+    moved = lines[:first] + [lines[spill]] + lines[first:spill] + lines[spill + 1:]
+    assert isa_check.scan("\n".join(moved), "reduced-ok", quiet=True) == 0
+    # … and a spill stored AND reloaded inside the same narrowed region (a temporary of the block) is not a finding either
+    inner = _MASKED.replace("	v_mov_b32_e32 v24, 0                                       // 000000001044: 7E300280\n", "")
+    lines = inner.splitlines()
+    load = next(i for i, l in enumerate(lines) if "scratch_load_dwordx2" in l)
+    close = next(i for i, l in enumerate(lines) if "s_or_b64 exec, exec, s[10:11]" in l)
+    inside = lines[:close] + [lines[load]] + lines[close:load] + lines[load + 1:]
+    assert isa_check.scan("\n".join(inside), "reduced-inside", quiet=True) == 0
