@@ -838,7 +838,7 @@ class Engine:
 
     INFO = {"group_lanes": 0, "elems_per_lane": 1, "nuts_launches": 2, "nuts_batch": 3, "iteration": 4, "nuts_kernel_ns": 5,
             "nuts_warm_launches": 6, "nuts_warm_kernel_ns": 7, "dense_gemm_launches": 8, "dense_gemm_small_launches": 9, "dense_pipelines": 10,
-            "dense_pool": 11, "nuts_draw_batch": 12}
+            "dense_pool": 11, "nuts_draw_batch": 12, "dense_epoch_launches": 13}
 
     def info(self, key):
         """engine introspection (ahmc_get_info): thread geometry, NUTS launch count / batch, iteration"""

@@ -211,6 +211,8 @@ struct Ctx : CtxBase {
   // WelfordCov of the shared dense metric: μ (D) [+ batch mean + column-sum partials], M, batch scatter, estimate
   T *wc_mu = nullptr, *wc_M = nullptr, *wc_S = nullptr, *wc_cov = nullptr;
   T* dn_C = nullptr;   // M⁻¹·P (dense metric + dense target), see dn_refresh_fused
+  T* dn_Asw = nullptr; // P and M⁻¹·P in MFMA-fragment order (k_dense_swizzle), refreshed at the start of every batch
+  int64_t dn_epoch_launches = 0;
   bool dn_fused_ok = false;
   // ahmc_sample(samples_out = host buffer): two device stages; the D2H copy of one batch's draws runs on copy_stream
   // while k_nuts fills the other stage
@@ -243,7 +245,7 @@ struct Ctx : CtxBase {
     void* bufs[] = {vbase, tbase, ibase, lbase, tparams, minv, sqrt_minv, scratch, order, order_hist, adaptk_dev, hmc_H, da_m, da_eps, da_mu, da_xbar,
                     da_Hbar, wv_mu, wv_M, wv_var, ext_th, ext_alpha, redo, znorm, dn_minv, dn_uinv, dn_W, dn_es, dn_RB, dn_VB,
                     dn_S, dn_active, dn_list, wg_mu, wg_M, ext_g, wc_mu, wc_M, wc_S, wc_cov, stage[0], stage[1], dn_C, ext_gstage, ext_lpstage,
-                    dn_P, dn_R, dn_S2, dn_ptcur, da_tab, work_prev, work_last, work_sum, work_grp};
+                    dn_P, dn_R, dn_S2, dn_ptcur, dn_Asw, da_tab, work_prev, work_last, work_sum, work_grp};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
     for (auto* v : {&ev_pool, &ev_pending, &ev_pending_warm})
@@ -1987,6 +1989,7 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
       case AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES: *out = c->dn_gemm_small; break;
       case AHMC_INFO_DENSE_PIPELINES: *out = c->dn_last_pipelines; break;
       case AHMC_INFO_DENSE_POOL: *out = c->dn_last_pool; break;
+      case AHMC_INFO_DENSE_EPOCH_LAUNCHES: *out = c->dn_epoch_launches; break;
       case AHMC_INFO_NUTS_DRAW_BATCH: *out = c->sched.phase == 4 ? c->sched.best_len : 0; break;
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
     }
@@ -2079,7 +2082,7 @@ int32_t ahmc_set_comm(ahmc_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t r
 
 int32_t ahmc_comm_info(ahmc_ctx* ctx, int64_t* ranks_seen, int64_t* chains_total, int64_t* chains_min, int64_t* chains_max) {
   FOR_CTX(ctx, {
-    const bool multi = c->comm && c->comm_ranks > 1;
+    const bool multi = c->comm != nullptr;   // (what comm_probe measured; without a communicator: a world of one)
     if (ranks_seen) *ranks_seen = multi ? c->comm_seen : 1;
     if (chains_total) *chains_total = multi ? c->comm_chains_total : c->N;
     if (chains_min) *chains_min = multi ? c->comm_chains_min : c->N;

@@ -428,21 +428,42 @@ inline int dt_threads_for(int64_t D) {
 // such sums or on per-chain scalars, so all threads follow the same control flow and reach the barriers together)
 template <int DT, class T>
 __device__ __forceinline__ void block_allsum2(T& a, T& b) {
-  if constexpr (DT == 64) {  // one wave per chain: no cross-wave exchange, no barrier
+  if constexpr (DT <= 64) {  // a chain inside one wave (DT = 16 / 32: several chains per wave, k_dense_epoch): no cross-wave exchange, no barrier
+    wave_allsum2<DT>(a, b);
+  } else {
+    __shared__ double xb[DT / 64][2];
     wave_allsum2<64>(a, b);
-    return;
-  }
-  __shared__ double xb[DT / 64][2];
-  wave_allsum2<64>(a, b);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { xb[w][0] = (double)a; xb[w][1] = (double)b; }
-  __syncthreads();
-  T sa = 0, sb = 0;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { xb[w][0] = (double)a; xb[w][1] = (double)b; }
+    __syncthreads();
+    T sa = 0, sb = 0;
 #pragma unroll
-  for (int k = 0; k < DT / 64; ++k) { sa += (T)xb[k][0]; sb += (T)xb[k][1]; }  // fixed order: same bits in every wave
-  __syncthreads();
-  a = sa;
-  b = sb;
+    for (int k = 0; k < DT / 64; ++k) { sa += (T)xb[k][0]; sb += (T)xb[k][1]; }  // fixed order: same bits in every wave
+    __syncthreads();
+    a = sa;
+    b = sb;
+  }
+}
+
+// One pass over NV vectors of a chain whose DC elements (compile time) are spread over a group of DT lanes, lane l holding the
+// pairs (i·DT + l)·2, +1: the loads of a chunk of up to 8 pairs per lane (4 with five vectors) are ALL issued before the first element is used (and
+// before any store of the pass, which the compiler could not prove not to alias), so a pass costs one memory round trip per
+// chunk — the loops over a run-time D take one per element.  f(d, x): the element pair at d, x[v] its values in vector v.
+template <class T, int DT, int DC, int NV, class F>
+__device__ __forceinline__ void dn_vec_pass(int lane, const T* const (&src)[NV], F&& f) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  constexpr int NP = DC / (2 * DT), CHM = NV >= 5 ? 4 : 8, CH = NP < CHM ? NP : CHM;  // (≤ 128 registers of operands in flight per lane)
+  static_assert(NP >= 1 && NP % CH == 0, "dn_vec_pass: DC must be a multiple of 2·DT (and of 16·DT beyond that)");
+#pragma unroll
+  for (int c0 = 0; c0 < NP; c0 += CH) {
+    T2 val[CH][NV];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) val[i][v] = *reinterpret_cast<const T2*>(src[v] + ((c0 + i) * DT + lane) * 2);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) f(((c0 + i) * DT + lane) * 2, val[i]);
+  }
 }
 
 // Returns the signed step of the chain's next leapfrog (0 = motionless step or idle).  lp_in / lk_in: ℓπ, ℓκ of the
@@ -1054,6 +1075,9 @@ struct DChain2 {
   int8_t cur, oth, cand, pad_;                   // the leaf in flight (moving edge), the other edge, the tree-level candidate
 };
 
+static_assert(offsetof(DChain2<double>, p_first) % 8 == 0 && offsetof(DChain2<double>, p_cand) == offsetof(DChain2<double>, p_first) + DN_MAXLEV && DN_MAXLEV == 16,
+              "d_tree_advance2 reads p_first / p_cand as four 8-byte words");
+
 // the scalars of a chain every call needs: read at the top of k_d_tree2, together with the energies and the step, so that the
 // tree bookkeeping does not start with a memory round trip of its own after the second half-step's reduction
 template <class T>
@@ -1089,6 +1113,7 @@ struct DP2 {
   int32_t* da_m;
   T *da_eps, *da_mu, *da_xbar, *da_Hbar;
   const T* da_tab;
+  unsigned long long* prof;  // k_dense_epoch built with -DAHMC_EPOCH_PROF: Σ cycles in the products / the epilogue / the trees, Σ steps
 };
 
 template <class T>
@@ -1124,13 +1149,43 @@ __global__ __launch_bounds__(256) void k_d_tree2_reset(DChain2<T>* S, T* es, int
 // The tree bookkeeping of one completed leapfrog (the leaf is the pool point S.cur, its energies lp_in / lk_in).  Returns the
 // signed step of the chain's next leapfrog (0 = idle, or the motionless warm-up step) and, in `src`, the pool point that
 // leapfrog starts from; `used` = bit mask of the points that must survive it.
-template <class T, int DT>
+template <bool WV>
+__device__ __forceinline__ void dn_chain_barrier() {
+  if constexpr (WV) {
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
+// WV: the chain is served by ONE wave of a larger workgroup (k_dense_epoch): the barriers that order thread 0's updates of the chain's
+// scalars against the other threads' reads become wave-local fences
+// DC > 0: D at compile time — the vector passes go through dn_vec_pass (other element order: the sums differ in the last bits
+// from the run-time loops')
+template <class T, int DT, bool WV = false, int DC = 0>
 __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, int64_t c, int lane, T lp_in, T lk_in, const DHot<T>& hot, int& src,
                                              uint64_t& used, bool& rewritten /* the point `src` was given a fresh momentum in this call */) {
   rewritten = false;
   DChain2<T>& S = q.S[c];
   const int D = p.D;
   const bool slice = p.sampler == 2;
+  // DC > 0: the points of the pending levels (p_first, p_cand: 32 bytes) come in with the first round trip, so a merge does not
+  // start with a dependent load of its own
+  unsigned long long pfw[4] = {0, 0, 0, 0};
+  if constexpr (DC > 0) {
+    const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(S.p_first);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pfw[i] = pp[i];
+  }
+  auto lvl_first = [&](int l) -> int {
+    if constexpr (DC > 0) return (int)(int8_t)((l < 8 ? pfw[0] : pfw[1]) >> (8 * (l & 7)));
+    else return S.p_first[l];
+  };
+  auto lvl_cand = [&](int l) -> int {
+    if constexpr (DC > 0) return (int)(int8_t)((l < 8 ? pfw[2] : pfw[3]) >> (8 * (l & 7)));
+    else return S.p_cand[l];
+  };
   Rng rng = make_rng(p, c);
   DrawStream ds;
   auto resume_draws = [&](uint32_t it, uint32_t k) {
@@ -1143,7 +1198,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
   if (phase == DPH_WARM) {
     // the motionless step has produced w = M⁻¹g at the start point of the batch's first transition: let the first leapfrog go
     const T e_first = hot.v < 0 ? -hot.eps : hot.eps;
-    __syncthreads();  // (every thread has read the phase before thread 0 changes it)
+    dn_chain_barrier<WV>();  // (every thread has read the phase before thread 0 changes it)
     if (lane == 0) S.phase = DPH_RUN;
     src = cur;
     used = bit(cur);  // cur = oth = cand = the start point
@@ -1187,7 +1242,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
     const bool will_park = (uint32_t)leaf < nleaf;
     int merged = 0;
     for (int lvl = 0; lvl < nm && !sub_term; ++lvl) {
-      const int pf = S.p_first[lvl];
+      const int pf = lvl_first(lvl);
       const T* p_rho = lvl == 0 ? ppt(q, p, pf, PV_R, c) : prho(q, p, PR_LEVEL0 + lvl, c);
       const T* p_vf = ppt(q, p, pf, PV_V, c);
       // the merged subtree has level lvl + 1: the last merge of a subtree that will be parked writes its ρ straight into
@@ -1204,7 +1259,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
         keep_first = w_new < w_p + (T)ds.randexp();
       }
       if (keep_first) {
-        cand_c = S.p_cand[lvl];
+        cand_c = lvl_cand(lvl);
         sub_lp = S.plp[lvl];
         sub_lk = S.plk[lvl];
       }
@@ -1215,11 +1270,22 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
       // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
       T dots[2] = {0, 0};
-      for (int d = lane; d < D; d += DT) {
-        const T rho = p_rho[d] + rho_v[d];
-        dots[0] += rho * p_vf[d];
-        dots[1] += rho * Vc[d];
-        out[d] = rho;
+      if constexpr (DC > 0) {
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        const T* const srcs[4] = {p_rho, rho_v, p_vf, Vc};
+        dn_vec_pass<T, DT, DC, 4>(lane, srcs, [&](int d, const T2 (&x)[4]) {
+          const T2 rho = x[0] + x[1];
+          dots[0] += rho[0] * x[2][0] + rho[1] * x[2][1];
+          dots[1] += rho[0] * x[3][0] + rho[1] * x[3][1];
+          *reinterpret_cast<T2*>(out + d) = rho;
+        });
+      } else {
+        for (int d = lane; d < D; d += DT) {
+          const T rho = p_rho[d] + rho_v[d];
+          dots[0] += rho * p_vf[d];
+          dots[1] += rho * Vc[d];
+          out[d] = rho;
+        }
       }
       rho_v = out;
       first_c = pf;
@@ -1244,8 +1310,8 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       // at level 0 and already sits in the level's slot otherwise)
       uint64_t u = bit(cur) | bit(oth) | bit(cand_tree) | bit(first_c) | bit(cand_c);
       for (int l = 0; l < DN_MAXLEV; ++l)
-        if (l != nm && (((uint32_t)leaf >> l) & 1u)) u |= bit(S.p_first[l]) | bit(S.p_cand[l]);
-      __syncthreads();  // (all threads have read p_first / p_cand of the pending levels)
+        if (l != nm && (((uint32_t)leaf >> l) & 1u)) u |= bit(lvl_first(l)) | bit(lvl_cand(l));
+      dn_chain_barrier<WV>();  // (all threads have read p_first / p_cand of the pending levels)
       if (lane == 0) {
         S.p_first[nm] = (int8_t)first_c;
         S.p_cand[nm] = (int8_t)cand_c;
@@ -1290,11 +1356,22 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       T* t_rho = prho(q, p, PR_TREE, c);
       const T* o_v = ppt(q, p, oth, PV_V, c);
       T dots[2] = {0, 0};
-      for (int d = lane; d < D; d += DT) {
-        const T rho = t_rho[d] + rho_v[d];
-        dots[0] += rho * Vc[d];
-        dots[1] += rho * o_v[d];
-        t_rho[d] = rho;
+      if constexpr (DC > 0) {
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        const T* const srcs[4] = {t_rho, rho_v, Vc, o_v};
+        dn_vec_pass<T, DT, DC, 4>(lane, srcs, [&](int d, const T2 (&x)[4]) {
+          const T2 rho = x[0] + x[1];
+          dots[0] += rho[0] * x[2][0] + rho[1] * x[2][1];
+          dots[1] += rho[0] * x[3][0] + rho[1] * x[3][1];
+          *reinterpret_cast<T2*>(t_rho + d) = rho;
+        });
+      } else {
+        for (int d = lane; d < D; d += DT) {
+          const T rho = t_rho[d] + rho_v[d];
+          dots[0] += rho * Vc[d];
+          dots[1] += rho * o_v[d];
+          t_rho[d] = rho;
+        }
       }
       block_allsum2<DT>(dots[0], dots[1]);
       turn = (dots[0] <= 0) || (dots[1] <= 0);
@@ -1335,6 +1412,23 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
         T* th = p.th() + c * D;
         T* r = p.r() + c * D;
         T* g = p.g() + c * D;
+        if constexpr (DC > 0) {
+          typedef T T2 __attribute__((ext_vector_type(2)));
+          const T* const srcs[5] = {c_th, c_r, c_g, s1, s2};
+          dn_vec_pass<T, DT, DC, 5>(lane, srcs, [&](int d, const T2 (&x)[5]) {
+            const T2 t = x[0];
+            if (p.accum) {
+              *reinterpret_cast<T2*>(s1 + d) = x[3] + t;
+              *reinterpret_cast<T2*>(s2 + d) = x[4] + t * t;
+            }
+            if (so) *reinterpret_cast<T2*>(so + d) = t;
+            if (last) {
+              *reinterpret_cast<T2*>(th + d) = t;
+              *reinterpret_cast<T2*>(r + d) = x[1];
+              *reinterpret_cast<T2*>(g + d) = x[2];
+            }
+          });
+        } else
         for (int d = lane; d < D; d += DT) {
           const T t = c_th[d];
           if (p.accum) { s1[d] += t; s2[d] += t * t; }
@@ -1389,7 +1483,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       }
       if (q.adapt_ss) {  // the next transition's ϵ is read from memory by every thread (chain_eps): thread 0's store must be visible
         __threadfence_block();
-        __syncthreads();
+        dn_chain_barrier<WV>();
       }
       start = true;
       lp_start = cand_lp;
@@ -1412,6 +1506,20 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
     const T* th = p.th() + c * D;
     const T* g = p.g() + c * D;
     T dots[2] = {0, 0};
+    if constexpr (DC > 0) {
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      const T* const srcs[4] = {rb, vb, th, g};
+      dn_vec_pass<T, DT, DC, 4>(lane, srcs, [&](int d, const T2 (&x)[4]) {
+        dots[0] += x[0][0] * x[1][0] + x[0][1] * x[1][1];
+        *reinterpret_cast<T2*>(s_r + d) = x[0];
+        *reinterpret_cast<T2*>(s_v + d) = x[1];
+        *reinterpret_cast<T2*>(t_rho + d) = x[0];
+        if (first_of_batch) {
+          *reinterpret_cast<T2*>(s_th + d) = x[2];
+          *reinterpret_cast<T2*>(s_g + d) = x[3];
+        }
+      });
+    } else
     for (int d = lane; d < D; d += DT) {
       const T rd = rb[d], vd = vb[d];
       dots[0] += rd * vd;
@@ -1561,6 +1669,301 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
   } else if (lane == 0) {
     q.ptcur[c] = src;  // motionless / idle: the GEMM (if any) serves the point the chain sits on
   }
+}
+
+// ================================================================================================
+// k_dense_epoch (round 4): CHAIN-COMPLETE workgroups.  The alternation k_dgemm → k_d_tree2 makes every chain's step wait for a
+// chip-wide launch twice, and run side by side the two kernels share every CU.  Here a workgroup of 8 waves OWNS 32
+// chains for a whole epoch of global steps: per step it computes g′ = Pθ′ and w′ = (M⁻¹P)θ′ for ITS chains — all D rows of both
+// products, wave w the rows [w·D/8, (w+1)·D/8) — with the matrices streamed from L2 in MFMA-fragment order (k_dense_swizzle: one
+// 16-byte load per lane feeds two MFMAs; no LDS staging, no barrier in the k loop; θ′ comes straight from the chains' pool points),
+// completes the leapfrog in the EPILOGUE (second half-step on the accumulators, r·v and θ′·g′ summed over the workgroup in a fixed
+// order), and then advances the trees of its chains (d_tree_advance2, one wave per chain, four chains per wave) and takes the
+// first half-step of their next leapfrogs.  No other workgroup touches these chains during the epoch, so the only synchronisation
+// is the workgroup's own barrier; workgroups drift apart, and one's memory-bound tree phase runs beside its neighbours' MFMA loops.
+// The state between two steps is exactly k_d_tree2's (DChain2, the point pool, es, ptcur): an epoch can end after any step and
+// the step-synchronous kernels can carry on (they do, for the tail of a batch when few chains are left).
+// Accumulation over k is in the order of k_dgemm (k ascending, four at a time): g′, w′ have its bits.
+// ================================================================================================
+constexpr int DE_WAVES = 8, DE_NCT = 2, DE_CHAINS = 16 * DE_NCT;
+
+// matrices in fragment order: out[(((kk·8 + w)·RT + j)·64 + lane)·2 + e] = A_m[row][4kk + lane/16], fragment f = 2j + e of wave w:
+// m = f / RT (0: A0 → g′, 1: A1 → w′), row tile t = f % RT, row = w·16RT + 4RT·(i mod 4) + 4t + i/4 for the MFMA row i = lane mod 16 —
+// the accumulator of lane (q, n) then holds rows w·16RT + 4RT·q + 4t + v of chain n: 4·RT contiguous elements per lane over (t, v)
+template <class T>
+__global__ __launch_bounds__(256) void k_dense_swizzle(const T* __restrict__ A0, const T* __restrict__ A1, T* __restrict__ out, int D, int RT) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * (int64_t)D * D) return;
+  const int e = (int)(idx & 1), l = (int)((idx >> 1) & 63);
+  int64_t rest = idx >> 7;
+  const int j = (int)(rest % RT);
+  rest /= RT;
+  const int w = (int)(rest % DE_WAVES), kk = (int)(rest / DE_WAVES);
+  const int f = 2 * j + e, m = f / RT, t = f % RT, i = l & 15;
+  const int row = w * 16 * RT + 4 * RT * (i & 3) + 4 * t + (i >> 2), k = 4 * kk + (l >> 4);
+  out[idx] = (m ? A1 : A0)[row + (int64_t)k * D];
+}
+
+template <class T>
+struct DEMeta {  // what the epilogue needs of a chain of the workgroup (per wave: each wave keeps its own copy, no barrier)
+  long long c;
+  T e;
+  int cur, act;
+};
+
+template <class T, int RT>
+__global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q, const T* __restrict__ Asw, int max_steps) {
+  using M = Mfma<T>;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  static_assert(RT == 2 || RT == 4, "k_dense_epoch: D = 256 or 512");
+  constexpr int D = 128 * RT, NK = D / 4, NF = 2 * RT;
+  constexpr int RW = 16 * RT;   // rows of a wave
+  constexpr int LPC = RW / 2;   // lanes per chain in the coalesced pass of the epilogue (16 bytes per lane)
+  constexpr int CPI = 64 / LPC; // chains per instruction there
+  constexpr int TP = RW + 2;    // pitch of a transposition tile (doubles): 16-byte rows, conflict-free columns
+  constexpr int GL = 16, CPW = DE_CHAINS / DE_WAVES;  // tree phase: lanes per chain, chains per wave (all at once)
+  static_assert(CPW * GL == 64, "tree phase: the chains of a wave fill it");
+  __shared__ T tile[DE_WAVES][2][16][TP];
+  __shared__ DEMeta<T> meta[DE_WAVES][DE_CHAINS];
+  __shared__ double red[DE_WAVES][DE_CHAINS][2];
+  __shared__ int any_active[2];
+  __shared__ int spec_pt[DE_CHAINS];  // per chain: the pool point its speculative half-step goes to (−1: none), set by the tree phase
+  const int64_t j0 = (int64_t)blockIdx.x * DE_CHAINS;
+  if (j0 >= q.n_list) return;
+  const int64_t c_safe = q.list ? (int64_t)q.list[j0] : j0;
+  if (threadIdx.x == 0) any_active[0] = any_active[1] = 0;
+  if (threadIdx.x < DE_CHAINS) spec_pt[threadIdx.x] = -1;
+  __syncthreads();
+  constexpr size_t AKS = (size_t)DE_WAVES * RT * 64;  // T2 elements per k-step
+#ifdef AHMC_EPOCH_PROF
+  unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc_ = __builtin_readcyclecounter();
+#define AHMC_EPOCH_TICK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); pt_[i] += n_ - pc_; pc_ = n_; }
+#else
+#define AHMC_EPOCH_TICK(i)
+#endif
+  for (int step = 0; step < max_steps; ++step) {
+    // Nothing a lane holds may live across the tree phase below: its four chain groups run under their own exec masks, and a value
+    // the register allocator spills INSIDE such a region is stored for the active lanes only and reloaded for all (isa_check.py).
+    // So every per-lane quantity is derived anew, per step and again per phase, from a thread index the compiler cannot trace back.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, w = tid >> 6, qd = lane >> 4, n16 = lane & 15;
+    const T2* Ap = reinterpret_cast<const T2*>(Asw) + (size_t)w * RT * 64 + lane;
+    // ---- the columns of this step: the point each chain's leapfrog in flight sits on ----
+    const T* Bp[DE_NCT];
+#pragma unroll
+    for (int ct = 0; ct < DE_NCT; ++ct) {
+      const int64_t jc = j0 + 16 * ct + n16;
+      const int64_t colc = jc < q.n_list ? (q.list ? (int64_t)q.list[jc] : jc) : -1;
+      const int64_t cc = colc >= 0 ? colc : c_safe;
+      const int cur = q.ptcur[cc];
+      const int act = (colc >= 0 && q.S[cc].phase != DPH_IDLE) ? 1 : 0;
+      Bp[ct] = ppt(q, p, cur, PV_TH, cc) + qd;
+      if (qd == 0) meta[w][16 * ct + n16] = DEMeta<T>{(long long)cc, act ? q.es[cc] : T(0), cur, act};
+    }
+    // ---- g′ = Pθ′, w′ = (M⁻¹P)θ′: 2·RT row tiles × 2 column tiles per wave, operands two k-steps ahead in registers ----
+    typename M::acc_t acc[NF][DE_NCT];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int ct = 0; ct < DE_NCT; ++ct) acc[f][ct] = typename M::acc_t{0, 0, 0, 0};
+    AHMC_EPOCH_TICK(0)
+    {
+      T2 a[3][RT];
+      T b[3][DE_NCT];
+      auto load = [&](int kk, T2 (&aa)[RT], T (&bb)[DE_NCT]) {
+        kk = kk < NK ? kk : NK - 1;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) aa[j] = Ap[(size_t)kk * AKS + (size_t)j * 64];
+#pragma unroll
+        for (int ct = 0; ct < DE_NCT; ++ct) bb[ct] = Bp[ct][4 * kk];
+      };
+      auto mult = [&](const T2 (&aa)[RT], const T (&bb)[DE_NCT]) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int ct = 0; ct < DE_NCT; ++ct) acc[2 * j + e][ct] = M::mma(aa[j][e], bb[ct], acc[2 * j + e][ct]);
+      };
+      load(0, a[0], b[0]);
+      load(1, a[1], b[1]);
+      for (int kk = 0; kk < NK; kk += 3) {
+        load(kk + 2, a[2], b[2]);
+        mult(a[0], b[0]);
+        if (kk + 1 < NK) {
+          load(kk + 3, a[0], b[0]);
+          mult(a[1], b[1]);
+        }
+        if (kk + 2 < NK) {
+          load(kk + 4, a[1], b[1]);
+          mult(a[2], b[2]);
+        }
+      }
+    }
+    AHMC_EPOCH_TICK(1)
+    // ---- epilogue: second half of the leapfrog (src/integrator.jl:243-250).  The accumulators hold 4·RT consecutive rows of ONE
+    // chain per lane and sixteen chains per instruction; through the wave's own LDS tile they become 16 bytes per lane with LPC
+    // consecutive lanes per chain, so every access below covers whole cache lines ----
+#pragma unroll
+    for (int ct = 0; ct < DE_NCT; ++ct) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int r0 = 4 * RT * qd + 4 * t;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          *reinterpret_cast<T2*>(&tile[w][0][n16][r0 + 2 * h]) = T2{acc[t][ct][2 * h], acc[t][ct][2 * h + 1]};
+          *reinterpret_cast<T2*>(&tile[w][1][n16][r0 + 2 * h]) = T2{acc[RT + t][ct][2 * h], acc[RT + t][ct][2 * h + 1]};
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      constexpr int NIT = 16 / CPI, NB = NIT < 4 ? NIT : 4;  // chains in batches of NB per half-wave: their loads are all in flight before the first is used
+      const int pos = lane % LPC, dd = w * RW + 2 * pos;
+#pragma unroll
+      for (int ib = 0; ib < NIT; ib += NB) {
+      T2 r2[NB], v2[NB], th2[NB];
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+        const DEMeta<T> m = meta[w][16 * ct + (ib + it) * CPI + lane / LPC];
+        th2[it] = r2[it] = v2[it] = T2{0, 0};  // (defined on every path: a value left undefined for the idle chains' lanes is carried around the step loop)
+        if (m.act) {
+          th2[it] = *reinterpret_cast<const T2*>(ppt(q, p, m.cur, PV_TH, (int64_t)m.c) + dd);
+          r2[it] = *reinterpret_cast<const T2*>(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd);
+          v2[it] = *reinterpret_cast<const T2*>(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+        const int nn = (ib + it) * CPI + lane / LPC;
+        const DEMeta<T> m = meta[w][16 * ct + nn];
+        T s0 = 0, s1 = 0;
+        if (m.act) {
+          const T e = m.e;
+          const T2 g2 = *reinterpret_cast<const T2*>(&tile[w][0][nn][2 * pos]), w2 = *reinterpret_cast<const T2*>(&tile[w][1][nn][2 * pos]);
+          T2 rr = r2[it], vv = v2[it];
+          if (e != T(0)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              rr[h] = rr[h] - e / 2 * g2[h];
+              vv[h] = vv[h] - e / 2 * w2[h];
+            }
+            *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd) = rr;
+            *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd) = vv;
+            const int sp = spec_pt[16 * ct + nn];
+            if (sp >= 0) {  // the first half of the NEXT leapfrog if the tree goes on from this point with this step (the usual case), into a point no
+              T2 rh, vh, tn;  // holder can name whatever the tree decides; the tree phase adopts it or takes the half-step itself
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                rh[h] = rr[h] - e / 2 * g2[h];
+                vh[h] = vv[h] - e / 2 * w2[h];
+                tn[h] = th2[it][h] + e * vh[h];
+              }
+              *reinterpret_cast<T2*>(ppt(q, p, sp, PV_R, (int64_t)m.c) + dd) = rh;
+              *reinterpret_cast<T2*>(ppt(q, p, sp, PV_V, (int64_t)m.c) + dd) = vh;
+              *reinterpret_cast<T2*>(ppt(q, p, sp, PV_TH, (int64_t)m.c) + dd) = tn;
+            }
+          }
+          *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_G, (int64_t)m.c) + dd) = g2;
+          *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_W, (int64_t)m.c) + dd) = w2;
+          s0 = rr[0] * vv[0] + rr[1] * vv[1];
+          s1 = th2[it][0] * g2[0] + th2[it][1] * g2[1];
+        }
+        wave_allsum2<LPC>(s0, s1);
+        if (pos == 0) { red[w][16 * ct + nn][0] = (double)s0; red[w][16 * ct + nn][1] = (double)s1; }
+      }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    AHMC_EPOCH_TICK(2)
+    __syncthreads();  // (A) the points are complete, the partial sums are in LDS
+    AHMC_EPOCH_TICK(3)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    if (tid2 == 0) any_active[(step + 1) & 1] = 0;
+    // ---- trees: the wave serves its CPW chains AT ONCE, GL lanes each (k_d_tree2 from the reduction on; the groups of a wave follow
+    // their own control flow — every exchange of d_tree_advance2 stays inside a 16-lane row) ----
+    {
+      const int lane2 = tid2 & 63, w2 = tid2 >> 6;
+      const int grp = lane2 / GL, l16 = lane2 % GL;
+      const int slot = w2 * CPW + grp;
+      const int64_t jj = j0 + slot;
+      bool chain_active = false;
+      if (jj < q.n_list) {
+        const int64_t c = q.list ? (int64_t)q.list[jj] : jj;
+        DChain2<T>& S = q.S[c];
+        if (S.phase != DPH_IDLE) {
+          T sa = 0, sb = 0;
+#pragma unroll
+          for (int k = 0; k < DE_WAVES; ++k) { sa += (T)red[k][slot][0]; sb += (T)red[k][slot][1]; }
+          const T lk = sanitize(-sa / 2), lp = sanitize(-sb / 2);
+          DHot<T> hot;
+          hot.H0 = S.H0; hot.eps = S.eps; hot.lu = S.lu;
+          hot.phase = S.phase; hot.it = S.it; hot.jw = S.jw; hot.leaf = S.leaf; hot.v = S.v; hot.cur_is_left = S.cur_is_left; hot.numerical = S.numerical;
+          hot.k = S.k;
+          hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand;
+          if (l16 == 0) {
+            p.lk()[c] = lk;
+            p.lp()[c] = lp;
+          }
+          int src = hot.cur;
+          uint64_t used = 0;
+          bool rewritten = false;
+          dn_chain_barrier<true>();
+          const T e = d_tree_advance2<T, GL, true, D>(p, q, c, l16, lp, lk, hot, src, used, rewritten);
+          if (l16 == 0) q.es[c] = e;
+          if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237): src → a fresh point
+            const DEMeta<T> m = meta[w2][slot];
+            const int sp = spec_pt[slot];
+            // the epilogue has already taken it if the leapfrog goes on from the point just completed with the same signed step
+            const bool hit = sp >= 0 && m.e != T(0) && src == hot.cur && e == m.e && !rewritten;
+            const int dst = hit ? sp : __builtin_ctzll(~used);
+            T* dTH = ppt(q, p, dst, PV_TH, c);
+            T* dR = ppt(q, p, dst, PV_R, c);
+            T* dV = ppt(q, p, dst, PV_V, c);
+            dn_chain_barrier<true>();  // (the start of a transition has just written r, v of `src`)
+            const T* const srcs[5] = {ppt(q, p, src, PV_TH, c), ppt(q, p, src, PV_R, c), ppt(q, p, src, PV_G, c), ppt(q, p, src, PV_V, c), ppt(q, p, src, PV_W, c)};
+            if (l16 == 0) spec_pt[slot] = __builtin_ctzll(~(used | ((uint64_t)1 << dst)));
+            if (!hit) dn_vec_pass<T, GL, D, 5>(l16, srcs, [&](int d, const T2 (&x)[5]) {
+              T2 rh, vh, tn;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                rh[h] = x[1][h] - e / 2 * x[2][h];
+                vh[h] = x[3][h] - e / 2 * x[4][h];
+                tn[h] = x[0][h] + e * vh[h];
+              }
+              *reinterpret_cast<T2*>(dR + d) = rh;
+              *reinterpret_cast<T2*>(dV + d) = vh;
+              *reinterpret_cast<T2*>(dTH + d) = tn;
+            });
+            if (l16 == 0) {
+              S.cur = (int8_t)dst;
+              q.ptcur[c] = dst;
+            }
+            chain_active = true;
+          } else {
+            if (l16 == 0) {
+              q.ptcur[c] = src;  // motionless / idle: the products serve the point the chain sits on
+              spec_pt[slot] = -1;
+            }
+            dn_chain_barrier<true>();        // (thread 0 may just have set the phase)
+            if (S.phase != DPH_IDLE) chain_active = true;
+          }
+        }
+      }
+      if (chain_active && l16 == 0) any_active[step & 1] = 1;
+    }
+    AHMC_EPOCH_TICK(4)
+    __syncthreads();  // (B) every chain's next point, step and phase are visible to the whole workgroup
+    AHMC_EPOCH_TICK(5)
+#ifdef AHMC_EPOCH_PROF
+    pt_[7] += 1;
+#endif
+    if (!any_active[step & 1]) break;
+  }
+#ifdef AHMC_EPOCH_PROF
+  if (threadIdx.x == 0 && q.prof)
+    for (int i = 0; i < 8; ++i) atomicAdd(q.prof + i, pt_[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -129,7 +129,7 @@ int dn_ensure(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
 // max_depth + 2 ρ vectors (cfg4's shard, D = 512, 8 192 chains, max_depth 10: 3.7 GB + 0.4 GB of the 288)
 template <class T>
 int dn_ensure_pool(Ctx<T>* c, int max_depth) {
-  const int npt = 2 * max_depth + 2, nrho = PR_LEVEL0 + (max_depth > 1 ? max_depth : 2);
+  const int npt = 2 * max_depth + 3, nrho = PR_LEVEL0 + (max_depth > 1 ? max_depth : 2);
   const size_t DN = (size_t)c->D * (size_t)c->N;
   if (npt > c->dn_npt) {
     if (c->dn_P) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->dn_P)); c->dn_P = nullptr; c->dn_npt = 0; }
@@ -595,6 +595,33 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // kernels slow down by the factor they now share the chip — 18.5–19.6 TFLOP/s against 24.0 for =1 and 22.2 for =0.  Kept as a switch.
   const int CHUNK = 16;
   const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
+  // AHMC_DENSE_EPOCH=1 (round 4): a pipeline with at least AHMC_DENSE_EPOCH_MIN running chains takes its CHUNK global steps in ONE
+  // launch of k_dense_epoch (chain-complete workgroups: both products, the second half-step, the trees and the next first
+  // half-step of 32 chains per workgroup); fewer chains — the tail of a batch — keep the step-synchronous kernels.
+  const int epoch_env = getenv("AHMC_DENSE_EPOCH") ? atoi(getenv("AHMC_DENSE_EPOCH")) : 0;
+  const int64_t epoch_min = getenv("AHMC_DENSE_EPOCH_MIN") ? atoll(getenv("AHMC_DENSE_EPOCH_MIN")) : 2048;
+  const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && sizeof(T) == 8 && c->D == 512;  // (the D = 256 instantiation compiles into a masked spill — isa_check.py — and is not built)
+  if (epoch_ok) {
+    if (!c->dn_Asw) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_Asw), 2 * sizeof(T) * (size_t)c->D * (size_t)c->D));
+    const int64_t tot = 2 * c->D * c->D;
+    hipLaunchKernelGGL((k_dense_swizzle<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->tparams, c->dn_C, c->dn_Asw, (int)c->D, (int)(c->D / 128));
+    HIPCHK(hipGetLastError());
+  }
+#ifdef AHMC_EPOCH_PROF
+  static unsigned long long* prof_dev = nullptr;
+  if (epoch_ok && !prof_dev) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&prof_dev), 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(prof_dev, 0, 8 * sizeof(unsigned long long)));
+  }
+  q2.prof = prof_dev;
+#endif
+  auto launch_epoch = [&](hipStream_t st, int steps) {
+    if constexpr (sizeof(T) == 8) {
+      const unsigned grid = (unsigned)((q2.n_list + DE_CHAINS - 1) / DE_CHAINS);
+      hipLaunchKernelGGL((k_dense_epoch<T, 4>), dim3(grid), dim3(64 * DE_WAVES), 0, st, p, q2, c->dn_Asw, steps);
+      c->dn_epoch_launches += 1;
+    }
+  };
   const int split_env = getenv("AHMC_DENSE_SPLIT") ? atoi(getenv("AHMC_DENSE_SPLIT")) : 1;  // (read per call: the tests toggle it)
   // AHMC_DENSE_PIPES=3|4 (with AHMC_DENSE_SPLIT=1): more, smaller pipelines — more chances for one pipeline's memory-bound tree
   // kernel to run beside another's GEMM, smaller GEMM launches
@@ -658,6 +685,15 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
         Pipe& h = pipes[k];
         if (h.n_list <= 0) continue;
         c->stream = h.s;  // (the helpers enqueue on the context's stream)
+        if (epoch_ok && h.n_list >= epoch_min) {  // the whole chunk of this pipeline in one launch
+          if (s == 0) {
+            q2.list = h.list;
+            q2.n_list = h.n_list;
+            launch_epoch(h.s, CHUNK);
+            if (hipGetLastError() != hipSuccess) return bail(fail(c, AHMC_ERR_RUNTIME, "k_dense_epoch launch failed"));
+          }
+          continue;
+        }
         q.list = h.list;
         q.n_list = h.n_list;
         // one global step = g′ = Pθ′ (or the built-in family's kernel), w′ = M⁻¹g′, then the fused
@@ -729,6 +765,15 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
       HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join_x[k - 2], 0));
     }
   }
+#ifdef AHMC_EPOCH_PROF
+  if (epoch_ok) {
+    unsigned long long h[8];
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[7]) fprintf(stderr, "[ahmc] k_dense_epoch cycles per workgroup-step (thread 0): columns %.0f, products %.0f, epilogue %.0f, barrier A %.0f, trees %.0f, barrier B %.0f (%llu workgroup-steps)\n",
+                      (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7], (double)h[5] / h[7], h[7]);
+  }
+#endif
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] dense NUTS batch of %d: %lld global steps so far, %lld chain-slots stepped\n", n_trans, (long long)c->dn_global_steps, (long long)c->dn_chain_steps);
   c->iteration += (uint64_t)n_trans;

@@ -91,7 +91,7 @@ int red_buf(Ctx<T>* c, size_t n) {
 template <class T>
 int comm_probe(Ctx<T>* c) {
   c->comm_seen = 1; c->comm_chains_total = c->comm_chains_min = c->comm_chains_max = c->N;
-  if (!c->comm || c->comm_ranks <= 1) return AHMC_OK;
+  if (!c->comm) return AHMC_OK;   // (a one-rank communicator is probed too: the same two collectives, so the path runs on one GPU)
   int rc = red_buf(c, 4);
   if (rc) return rc;
   double v[4] = {1.0, (double)c->N, (double)c->N, -(double)c->N};
@@ -189,7 +189,7 @@ int gather_moments(Ctx<T>* c, double* mean, double* var, int64_t* n_draws, int64
   HIPCHK(hipGetLastError());
   const double draws = (double)c->acc_ntrans * (double)c->N;
   HIPCHK(hipMemcpyAsync(c->red + 2 * D + 2, &draws, sizeof(double), hipMemcpyHostToDevice, c->stream));
-  if (c->comm && c->comm_ranks > 1)
+  if (c->comm)   // (a one-rank communicator runs the collective too: the single GPU of the test box exercises this call)
     NCCLCHK(rccl_api().AllReduce(c->red, c->red, (size_t)(2 * D + 3), ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));
   std::vector<double> h((size_t)(2 * D + 3));
   HIPCHK(hipMemcpyAsync(h.data(), c->red, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -212,7 +212,7 @@ template <class T>
 int gather_state(Ctx<T>* c, void* theta_all) {
   if (!theta_all) return fail(c, AHMC_ERR_ARGUMENT, "gather_state: theta_all is NULL");
   const size_t n = (size_t)c->D * (size_t)c->N;
-  if (c->comm && c->comm_ranks > 1) {
+  if (c->comm) {
     // every rank must contribute the same count (ncclAllGather with unequal counts hangs or corrupts): the largest and the
     // smallest N of the communicator were measured when it was attached (comm_probe)
     if (c->comm_chains_min != c->comm_chains_max)
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_pool_finish(const double* __restrict__ 
 template <class T>
 int pooled_update(Ctx<T>* c) {
   const int D = (int)c->D;
-  const int R = c->comm && c->comm_ranks > 1 ? c->comm_ranks : 1;
+  const int R = c->comm ? c->comm_ranks : 1;
   const size_t part = (size_t)(2 * D + 1);
   int rc = red_buf(c, part * (size_t)(R + 1));
   if (rc) return rc;
@@ -296,7 +296,7 @@ int pooled_update(Ctx<T>* c) {
   hipLaunchKernelGGL((k_pool_var<T>), dim3((unsigned)((D + 63) / 64)), dim3(256), 0, c->stream, c->wv_mu, c->wv_M, D, c->N, (double)c->wv_n, mine);
   HIPCHK(hipGetLastError());
   const double* parts = mine;
-  if (R > 1) {
+  if (c->comm) {
     NCCLCHK(rccl_api().AllGather(mine, c->red, part, ncclDouble, static_cast<ncclComm_t>(c->comm), c->stream));
     parts = c->red;
   }

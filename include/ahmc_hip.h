@@ -454,8 +454,9 @@ typedef enum {
   AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES = 9,  /* … of the 64×16-tile GEMM (few columns: the tails of the batches)              */
   AHMC_INFO_DENSE_PIPELINES = 10,           /* chain pipelines (streams) of the last dense NUTS batch: 1 or 2                 */
   AHMC_INFO_DENSE_POOL = 11,                /* 1: the last dense NUTS batch ran on the point pool (k_d_tree2), 0: the copying kernel */
-  AHMC_INFO_NUTS_DRAW_BATCH = 12            /* transitions per launch the engine settled on for the sampling phase by timing its own
+  AHMC_INFO_NUTS_DRAW_BATCH = 12,           /* transitions per launch the engine settled on for the sampling phase by timing its own
                                                launches (ahmc_sample, round 4); 0 while it has not settled (then AHMC_INFO_NUTS_BATCH) */
+  AHMC_INFO_DENSE_EPOCH_LAUNCHES = 13       /* launches of the chain-complete dense kernel (k_dense_epoch, round 4) since ahmc_create  */
 } ahmc_info;
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out);
 

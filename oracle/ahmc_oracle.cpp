@@ -2345,7 +2345,7 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
       case AHMC_INFO_GROUP_LANES: *out = 1; break;
       case AHMC_INFO_ELEMS_PER_LANE: *out = c->D; break;
       case AHMC_INFO_NUTS_LAUNCHES: case AHMC_INFO_NUTS_KERNEL_NS: case AHMC_INFO_NUTS_WARM_LAUNCHES: case AHMC_INFO_NUTS_WARM_KERNEL_NS:
-      case AHMC_INFO_DENSE_GEMM_LAUNCHES: case AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES: case AHMC_INFO_DENSE_PIPELINES: case AHMC_INFO_DENSE_POOL: case AHMC_INFO_NUTS_DRAW_BATCH: *out = 0; break;
+      case AHMC_INFO_DENSE_GEMM_LAUNCHES: case AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES: case AHMC_INFO_DENSE_PIPELINES: case AHMC_INFO_DENSE_POOL: case AHMC_INFO_NUTS_DRAW_BATCH: case AHMC_INFO_DENSE_EPOCH_LAUNCHES: *out = 0; break;
       case AHMC_INFO_NUTS_BATCH: *out = 1; break;
       case AHMC_INFO_ITERATION: *out = (int64_t)c->iteration; break;
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");

@@ -290,6 +290,24 @@ def test_hip_pooled_adaptation_matches_oracle(hip, oracle, path):
 
 
 @pytest.mark.gpu
+def test_hip_pooled_adaptation_through_a_one_rank_communicator(hip):
+    """the rank-merge of the pooled estimator (ncclAllGather of the per-GPU partitions, k_pool_finish over R blocks) with a
+    real RCCL communicator of ONE rank: the same chains as the run without a communicator, bit for bit"""
+    D, N, n_adapts = 24, 300, 150
+    out = []
+    for with_comm in (False, True):
+        e, k, h = make(hip, D, N, "stan_pooled", np.random.default_rng(8), shared_metric=True)
+        if with_comm:
+            e.comm_init(e.comm_unique_id(), 1, 0)
+            assert e.comm_info()["ranks_seen"] == 1
+        e.run(k, 110, n_adapts)
+        out.append((e.get_metric().copy(), e.theta().copy(), e.get_stepsize().copy()))
+        e.close()
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_hip_ebfmi_moments_ess_and_one_rank_rccl(hip, oracle, rng):
     """device-side reductions of the HIP engine (k_moments_reduce, the energy running sums of the transition kernels,
     k_ess) against numpy / the oracle's implementation, and the gather through a real RCCL communicator of one rank"""
@@ -307,6 +325,7 @@ def test_hip_ebfmi_moments_ess_and_one_rank_rccl(hip, oracle, rng):
     mean = acc["sum_theta"].sum(axis=1) / n
     g0 = e.gather_moments()                           # no communicator: a world of one
     e.comm_init(e.comm_unique_id(), 1, 0)             # ncclCommInitRank(…, 1, id, 0): the all-reduce really runs
+    assert e.comm_info() == {"ranks_seen": 1, "chains_total": N, "chains_min": N, "chains_max": N}   # comm_probe's two all-reduces ran
     g1 = e.gather_moments()
     for g in (g0, g1):
         np.testing.assert_allclose(g["mean"], mean, rtol=1e-10, atol=1e-12)
