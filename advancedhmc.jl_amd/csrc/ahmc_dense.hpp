@@ -1686,6 +1686,9 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
 // Accumulation over k is in the order of k_dgemm (k ascending, four at a time): g′, w′ have its bits.
 // ================================================================================================
 constexpr int DE_WAVES = 8, DE_NCT = 2, DE_CHAINS = 16 * DE_NCT;
+#ifndef AHMC_EPOCH_NB
+#define AHMC_EPOCH_NB 8  // (cfg4: 4 → 8 chains per batch of the epilogue 35.7 → 36.1 TFLOP/s)
+#endif
 
 // matrices in fragment order: out[(((kk·8 + w)·RT + j)·64 + lane)·2 + e] = A_m[row][4kk + lane/16], fragment f = 2j + e of wave w:
 // m = f / RT (0: A0 → g′, 1: A1 → w′), row tile t = f % RT, row = w·16RT + 4RT·(i mod 4) + 4t + i/4 for the MFMA row i = lane mod 16 —
@@ -1817,7 +1820,7 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
         }
       }
       __builtin_amdgcn_wave_barrier();
-      constexpr int NIT = 16 / CPI, NB = NIT < 4 ? NIT : 4;  // chains in batches of NB per half-wave: their loads are all in flight before the first is used
+      constexpr int NIT = 16 / CPI, NB = NIT < AHMC_EPOCH_NB ? NIT : AHMC_EPOCH_NB;  // chains in batches of NB per half-wave: their loads are all in flight before the first is used
       const int pos = lane % LPC, dd = w * RW + 2 * pos;
 #pragma unroll
       for (int ib = 0; ib < NIT; ib += NB) {

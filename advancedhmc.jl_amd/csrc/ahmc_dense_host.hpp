@@ -593,12 +593,14 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // GEMM B(s) can only run beside tree A(s), GEMM A(s+1) beside tree B(s).  Same kernels on the same data: bit-identical
   // results.  Measured in round 2 (profiles/r2_cfg4_timeline_split*.json): the phase shift happens as designed and both
   // kernels slow down by the factor they now share the chip — 18.5–19.6 TFLOP/s against 24.0 for =1 and 22.2 for =0.  Kept as a switch.
-  const int CHUNK = 16;
-  const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK;
-  // AHMC_DENSE_EPOCH=1 (round 4): a pipeline with at least AHMC_DENSE_EPOCH_MIN running chains takes its CHUNK global steps in ONE
-  // launch of k_dense_epoch (chain-complete workgroups: both products, the second half-step, the trees and the next first
-  // half-step of 32 chains per workgroup); fewer chains — the tail of a batch — keep the step-synchronous kernels.
-  const int epoch_env = getenv("AHMC_DENSE_EPOCH") ? atoi(getenv("AHMC_DENSE_EPOCH")) : 0;
+  const int chunk_env = getenv("AHMC_DENSE_CHUNK") ? atoi(getenv("AHMC_DENSE_CHUNK")) : 0;  // (experiments: global steps between two compactions)
+  const int CHUNK_STEP = chunk_env >= 4 && chunk_env <= 256 ? chunk_env : 16;   // step-synchronous kernels
+  const int CHUNK_EPOCH = chunk_env >= 4 && chunk_env <= 256 ? chunk_env : 64;  // k_dense_epoch: one launch per chunk (cfg4: 16 / 32 / 64 steps 35.7 / 36.4 / 36.8 TFLOP/s)
+  const int64_t max_steps = (int64_t)n_trans * ((1ll << max_depth) - 1) + CHUNK_EPOCH;
+  // Round 4 (AHMC_DENSE_EPOCH=0 switches it off): a pipeline with at least AHMC_DENSE_EPOCH_MIN running chains takes its chunk of
+  // global steps in ONE launch of k_dense_epoch (chain-complete workgroups: both products, the second half-step, the trees and
+  // the next first half-step of 32 chains per workgroup); fewer chains — the tail of a batch — keep the step-synchronous kernels.
+  const int epoch_env = getenv("AHMC_DENSE_EPOCH") ? atoi(getenv("AHMC_DENSE_EPOCH")) : 1;
   const int64_t epoch_min = getenv("AHMC_DENSE_EPOCH_MIN") ? atoll(getenv("AHMC_DENSE_EPOCH_MIN")) : 2048;
   const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && sizeof(T) == 8 && c->D == 512;  // (the D = 256 instantiation compiles into a masked spill — isa_check.py — and is not built)
   if (epoch_ok) {
@@ -680,6 +682,9 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
     return false;
   };
   for (int64_t done_steps = 0; done_steps < max_steps && any_running();) {
+    bool any_epoch = false;
+    for (int k = 0; k < NP; ++k) any_epoch = any_epoch || (epoch_ok && pipes[k].n_list >= epoch_min);
+    const int CHUNK = any_epoch ? CHUNK_EPOCH : CHUNK_STEP;  // (a pipeline that has fallen below the threshold beside one that has not steps CHUNK_EPOCH times, too)
     for (int s = 0; s < CHUNK; ++s) {
       for (int k = 0; k < NP; ++k) {
         Pipe& h = pipes[k];

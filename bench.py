@@ -292,6 +292,7 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
         r["ess_per_draw_all"] = ess_sum / world
         r["value"] = (r["leap_adapt_all"] + r["leap_draw_all"]) / r["dt_max"]
         r["draw_launch_length"] = eng.info("nuts_draw_batch")
+        r["dense_launches"] = {k: eng.info(k) for k in ("dense_epoch_launches", "dense_gemm_launches", "dense_gemm_small_launches")}
         runs.append(r)
         spent = sum(x["dt_max"] for x in runs)
         want = repeats if repeats > 0 else (3 if runs[0]["dt_max"] < 4.0 else 1)
@@ -387,7 +388,9 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
             tf = (med["leap_adapt"] + med["leap_draw"]) * F_lf / med["dt"] / 1e12
             peak = F64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else F32_MFMA_PEAK_TFLOPS
             roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": tf, "frac": tf / peak, "traffic": None,
-                    "kernel": "k_dgemm (both products of a global step) + k_d_tree, whole timed region",
+                    "kernel": ("k_dense_epoch (chain-complete workgroups: both products, the half-steps and the trees of 32 chains per workgroup, 64 global "
+                               "steps per launch) + k_dgemm / k_d_tree2 for the tails of the batches, whole timed region"),
+                    "launches_since_create": runs[-1].get("dense_launches"),
                     "algorithmic_flops_per_leapfrog": F_lf,
                     "note": "useful leapfrogs x 4 D^2 / wall time of the whole loop (tree kernel, momenta and adaptation included)"}
         out = {

@@ -64,11 +64,11 @@ for cfg in sys.argv[1:]:
     # valid if the two units that hold this config's kernels are the ones the counters were taken on
     ud_then = config_digest(FAMILY[cfg], "f64", s.get("unit_digests") or {}) if cfg in FAMILY else ""
     ud_now = config_digest(FAMILY[cfg]) if cfg in FAMILY else ""
-    if not ud_then or ud_then != ud_now:
+    if cfg in FAMILY and (not ud_then or ud_then != ud_now):
         print(f"{cfg}: counters were taken on other device code (units of family {FAMILY.get(cfg)}: {ud_then[:12]} then, {ud_now[:12]} now): NOT used")
         continue
     c = {"unit_digest": ud_now}
-    for mode, r in s["counters"].items():
+    for mode, r in (s["counters"].items() if cfg in FAMILY else []):  # (cfg4: the dense engine — kernel table and summary only)
         c[mode] = {k: r.get(k) for k in ("valu_per_leapfrog", "salu_per_leapfrog", "lds_per_leapfrog", "vmem_per_leapfrog", "mfma_f64_per_leapfrog",
                                           "hbm_bytes_per_leapfrog", "valu_busy", "mean_waves_per_simd", "valu_mix_per_leapfrog")}
         # the mix-weighted VALU-issue roof of this kernel: measured per-class issue rates (the probe) weighted by its dynamic
@@ -96,7 +96,8 @@ for cfg in sys.argv[1:]:
                                                 "sensitivity_innermost_loop_peak": a0["peak_mix_gwave_instr_per_s"]}
                 except Exception as ex:  # noqa: BLE001
                     c[mode]["valu_peak_mix_error"] = repr(ex)
-    out["configs"][cfg] = c
+    if cfg in FAMILY:
+        out["configs"][cfg] = c
     keep = {k: s.get(k) for k in ("config", "command", "kernel_digest", "kernel_stats", "mode0_launches", "mode3_launches", "counters", "leapfrogs_by_pass", "per_kernel_counters")}
     keep["bench_plain"] = s.get("bench_plain")
     with open(os.path.join(ROOT, "profiles", f"{ROUND}_{cfg}_profile_summary.json"), "w") as f:

@@ -988,8 +988,9 @@ def test_full_size_slice_against_oracle(hip, oracle, cfg, offset):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("engine", ["step", "epoch"])
 @pytest.mark.parametrize("metric", ["identity", "spd"])
-def test_cfg4_shape_against_oracle(hip, oracle, metric):
+def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     """BASELINE configs[3] at its own shape: D = 512, Σᵢⱼ = 0.9^|i−j| as a dense Gaussian target (ℓπ = −½θᵀΣ⁻¹θ, the gradient
     a GEMM), shared DenseEuclideanMetric (`identity` = cfg4's initial M⁻¹ = I; `spd` = a well-conditioned full matrix, so the
     second product (M⁻¹P)θ′ and the momentum solve U⁻¹z are not trivial), NUTS(0.8) + StepSizeAdaptor — on 2 304 chains, so
@@ -997,7 +998,11 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric):
     half), the two chain pipelines on two streams, compaction, `k_d_tree<T,256>`.  The oracle replays the FIRST and the LAST
     64 chains (one in each pipeline) through `chain_offset` (src/hamiltonian.jl:60-68,179-184, src/metric.jl:311-320,
     src/trajectory.jl:626-742 per chain).  Every iteration (transition + adapt!) starts from the oracle's state for those
-    chains and is held to the bar: identical discrete decisions on ≥ 99.9 % of them (i.e. all 128), 1e-8 on θ, r, ∇ℓπ."""
+    chains and is held to the bar: identical discrete decisions on ≥ 99.9 % of them (i.e. all 128), 1e-8 on θ, r, ∇ℓπ.
+    `engine`: "step" = the step-synchronous kernels (`k_dgemm` → `k_d_tree2` per global step); "epoch" = round 4's chain-complete
+    `k_dense_epoch` (what the bench runs at 8 192 chains; here its threshold is lowered so that 1 152 chains per pipeline take it)."""
+    monkeypatch.setenv("AHMC_DENSE_EPOCH", "1" if engine == "epoch" else "0")
+    monkeypatch.setenv("AHMC_DENSE_EPOCH_MIN", "32")
     D, N, n = 512, 2304, 64
     idx = np.arange(D)
     Sigma = 0.9 ** np.abs(idx[:, None] - idx[None, :])
@@ -1058,9 +1063,59 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric):
     assert depth_seen >= 5, depth_seen   # trees of 32+ leaves: merges on several pending levels, compaction of finished chains
     # what ran: the 64×64-tile GEMM, two pipelines, the point-pool tree kernel
     assert g.info("dense_gemm_launches") > 0 and g.info("dense_pipelines") == 2 and g.info("dense_pool") == 1
+    assert (g.info("dense_epoch_launches") > 0) == (engine == "epoch")
     g.close()
     for o in os_:
         o.close()
+
+
+def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
+    """`k_dense_epoch` (chain-complete workgroups: both products, the second half-step and the speculative next one in the epilogue,
+    four chains per wave in the tree phase) against `k_dgemm` + `k_d_tree2` on the HIP engine: the same 2 304 chains through a
+    3-iteration warm-up (StepSizeAdaptor inside the kernel) and 3 draws kept on the device, trees up to the maximum depth —
+    every chain takes the same number of leapfrogs in every transition and ends at the same point (the products accumulate in
+    the same order; only the sums r·v, θ·g, ρ·v are added in another order: 1e-9).  Also with a chain count that leaves the
+    last workgroup partly empty, and with an epoch that ends in the middle of the trees (chunks of 5 steps)."""
+    import torch
+
+    D = 512
+    idx = np.arange(D)
+    P = np.asfortranarray(np.linalg.inv(0.9 ** np.abs(idx[:, None] - idx[None, :])))
+    rs = np.random.default_rng(2025)
+    Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+    Minv = (Q * np.linspace(0.6, 2.0, D)) @ Q.T
+    Minv = np.asfortranarray((Minv + Minv.T) / 2)
+    for N, chunk in ((2304, None), (2090, "5")):
+        th0 = np.asfortranarray(rs.normal(size=(D, N)))
+        eps0 = 0.12 * (0.7 + 0.6 * rs.random(N))
+        out = {}
+        for engine in ("step", "epoch"):
+            monkeypatch.setenv("AHMC_DENSE_EPOCH", "1" if engine == "epoch" else "0")
+            monkeypatch.setenv("AHMC_DENSE_EPOCH_MIN", "32")
+            if chunk:
+                monkeypatch.setenv("AHMC_DENSE_CHUNK", chunk)
+            else:
+                monkeypatch.delenv("AHMC_DENSE_CHUNK", raising=False)
+            lf = A.Leapfrog(eps0)
+            k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+            g = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), A.DenseGaussian(P)), N, rng=A.PhiloxRNG(78), lib=hip)
+            g.set_integrator(lf)
+            g.set_position(th0)
+            g.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+            draws = torch.empty((3, N, D), dtype=torch.float64, device="cuda")
+            g.run(k, 6, 3, drop_warmup=True, samples_out=draws.data_ptr())
+            g.sync()
+            st, acc = g.stats(), g.accum()
+            out[engine] = (draws.cpu().numpy(), st["n_steps"].copy(), acc["total_n_steps"], g.get_stepsize().copy(), st["acceptance_rate"].copy(), g.theta().copy())
+            assert (g.info("dense_epoch_launches") > 0) == (engine == "epoch")
+            g.close()
+        a, b = out["step"], out["epoch"]
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2]
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+        np.testing.assert_allclose(a[4], b[4], rtol=1e-6, atol=1e-12)   # (mean of exp(−ΔH): a rounding of ΔH ≈ 500 is a relative 1e-9 of it)
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(a[5], b[5], rtol=1e-9, atol=1e-9)
 
 
 def test_fixed_integration_time_hmcda(hip, oracle, rng):
