@@ -1621,9 +1621,10 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
     block_allsum2<DT>(s[0], s[1]);
     lk = sanitize(-s[0] / 2);
     if (dense_target) lp = sanitize(-s[1] / 2);
+    else lp = sanitize(lp);  // (a user kernel's ℓπ: PhasePoint's non-finite → −Inf, src/hamiltonian.jl:95-104 — here instead of in a launch of its own)
     if (lane == 0) {
       p.lk()[c] = lk;
-      if (dense_target) p.lp()[c] = lp;
+      p.lp()[c] = lp;
     }
   }
   int src = cur;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_u_sanitize(T* __restrict__ lp, int64_t 
 // AHMC_TARGET_KERNEL: (ℓπ, g = −∇ℓπ) at θ of the listed chains by the user's device kernel, launched on the context's stream —
 // the `h.∂ℓπ∂θ(θ)` call of src/hamiltonian.jl:45-48 without leaving the device (signature: include/ahmc_hip.h)
 template <class T>
-int dn_user_target(Ctx<T>* c, const int* list, int64_t n) {
+int dn_user_target(Ctx<T>* c, const int* list, int64_t n, bool sanitize_lp = true) {  // sanitize_lp = false: the caller's next kernel sanitises ℓπ as it reads it (k_d_tree2)
   if (n <= 0) return AHMC_OK;
   if (!c->uk_handle) return fail(c, AHMC_ERR_STATE, "AHMC_TARGET_KERNEL without a kernel (ahmc_set_target_kernel)");
   const T* th = c->th;
@@ -35,7 +35,7 @@ int dn_user_target(Ctx<T>* c, const int* list, int64_t n) {
     HIPCHK(hipModuleLaunchKernel(static_cast<hipFunction_t>(c->uk_handle), grid, 1, 1, (unsigned)c->uk_block, 1, 1, 0, c->stream, args, nullptr));
   else
     HIPCHK(hipLaunchKernel(c->uk_handle, dim3(grid), dim3((unsigned)c->uk_block), args, 0, c->stream));
-  hipLaunchKernelGGL((k_u_sanitize<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->lp, n, list);
+  if (sanitize_lp) hipLaunchKernelGGL((k_u_sanitize<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->lp, n, list);
   HIPCHK(hipGetLastError());
   return AHMC_OK;
 }
@@ -43,8 +43,8 @@ int dn_user_target(Ctx<T>* c, const int* list, int64_t n) {
 // (ℓπ, g) of the listed chains for a target that is not the dense Gaussian: the user's kernel, or the built-in family's /
 // the plugin's group kernel (which has no chain list: it evaluates every chain)
 template <class T>
-int dn_other_target(Ctx<T>* c, const int* list, int64_t n) {
-  return c->target_kind == AHMC_TARGET_KERNEL ? dn_user_target(c, list, n) : launch_fill_caches_builtin(c);
+int dn_other_target(Ctx<T>* c, const int* list, int64_t n, bool sanitize_lp = true) {
+  return c->target_kind == AHMC_TARGET_KERNEL ? dn_user_target(c, list, n, sanitize_lp) : launch_fill_caches_builtin(c);
 }
 
 template <class T>
@@ -723,7 +723,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
           if (rc) return bail(rc);
         } else {
           // (a target that is not the dense Gaussian reads θ′ from / leaves g′ in the context's arrays: the pool is "staged")
-          rc = dt ? dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps, cs, cs) : dn_other_target(c, h.list, h.n_list);
+          rc = dt ? dn_gemm(c, c->tparams, gX, gY, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps, cs, cs) : dn_other_target(c, h.list, h.n_list, /*sanitize_lp=*/!pool);  // (the pool kernel sanitises ℓπ itself: one launch fewer per global step)
           if (rc) return bail(rc);
           if (dm) {
             rc = dt ? dn_gemm(c, c->dn_minv, (const T*)gY, gW, h.n_list, h.list, (const T*)nullptr, (T*)nullptr, pti, ps, ps, cs, cs)
