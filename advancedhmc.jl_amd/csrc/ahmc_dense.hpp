@@ -1113,6 +1113,7 @@ struct DP2 {
   int32_t* da_m;
   T *da_eps, *da_mu, *da_xbar, *da_Hbar;
   const T* da_tab;
+  int lazy_gw;      // 1: a point's g′, w′ are on record only where a leapfrog can START from it (k_dense_epoch); a transition then begins with the motionless step
   unsigned long long* prof;  // k_dense_epoch built with -DAHMC_EPOCH_PROF: Σ cycles in the products / the epilogue / the trees, Σ steps
 };
 
@@ -1543,7 +1544,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       w_tree = 0;  // MultinomialTS(rng, z0): ℓw = 0 (:155)
     }
     const bool vleft = ds.boolean();
-    const bool warm = q.dense_metric && first_of_batch;  // w = M⁻¹g of the start point is not known yet
+    const bool warm = q.dense_metric && (first_of_batch || q.lazy_gw);  // w = M⁻¹g of the start point is not known yet (lazy_gw: the candidate's record may lack g, w)
     if (lane == 0) {
       p.lk()[c] = lk;
       S.H0 = H0; S.eps = eps; S.lu = lu; S.w_tree = w_tree; S.sa_tree = 0; S.dh_tree = 0; S.na_tree = 0;
@@ -1687,6 +1688,14 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
 // Accumulation over k is in the order of k_dgemm (k ascending, four at a time): g′, w′ have its bits.
 // ================================================================================================
 constexpr int DE_WAVES = 8, DE_NCT = 2, DE_CHAINS = 16 * DE_NCT;
+#ifndef AHMC_EPOCH_NT
+#define AHMC_EPOCH_NT 1  // the epilogue's stores are non-temporal (cfg4 42.5 -> 42.9 TFLOP/s); 0: plain stores
+#endif
+#if AHMC_EPOCH_NT
+#define DE_STORE(ptr, val) __builtin_nontemporal_store(val, reinterpret_cast<T2*>(ptr))
+#else
+#define DE_STORE(ptr, val) (*reinterpret_cast<T2*>(ptr) = (val))
+#endif
 #ifndef AHMC_EPOCH_NB
 #define AHMC_EPOCH_NB 8  // (cfg4: 4 → 8 chains per batch of the epilogue 35.7 → 36.1 TFLOP/s)
 #endif
@@ -1712,7 +1721,7 @@ template <class T>
 struct DEMeta {  // what the epilogue needs of a chain of the workgroup (per wave: each wave keeps its own copy, no barrier)
   long long c;
   T e;
-  int cur, act;
+  int cur, act;  // act bit 0: the chain is running; bit 1: g′, w′ of this point go on record
 };
 
 template <class T, int RT>
@@ -1761,9 +1770,15 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
       const int64_t colc = jc < q.n_list ? (q.list ? (int64_t)q.list[jc] : jc) : -1;
       const int64_t cc = colc >= 0 ? colc : c_safe;
       const int cur = q.ptcur[cc];
-      const int act = (colc >= 0 && q.S[cc].phase != DPH_IDLE) ? 1 : 0;
+      const DChain2<T>& Sc = q.S[cc];
+      int act = (colc >= 0 && Sc.phase != DPH_IDLE) ? 1 : 0;
+      const T ec = act ? q.es[cc] : T(0);
+      // g′ and w′ are read again only by a leapfrog that STARTS from this point: the motionless step's point, the last leaf of a doubling
+      // (the tree's new edge), and — for its g — the candidate of the batch's last transition; everything else goes on from the
+      // speculative half-step (a chain without one keeps the record: bit 1 is also set in the epilogue when there is none)
+      if (!q.lazy_gw || ec == T(0) || Sc.leaf == (1 << Sc.jw) || Sc.it + 1 >= q.n_trans) act |= 2 * act;
       Bp[ct] = ppt(q, p, cur, PV_TH, cc) + qd;
-      if (qd == 0) meta[w][16 * ct + n16] = DEMeta<T>{(long long)cc, act ? q.es[cc] : T(0), cur, act};
+      if (qd == 0) meta[w][16 * ct + n16] = DEMeta<T>{(long long)cc, ec, cur, act};
     }
     // ---- g′ = Pθ′, w′ = (M⁻¹P)θ′: 2·RT row tiles × 2 column tiles per wave, operands two k-steps ahead in registers ----
     typename M::acc_t acc[NF][DE_NCT];
@@ -1851,8 +1866,8 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
               rr[h] = rr[h] - e / 2 * g2[h];
               vv[h] = vv[h] - e / 2 * w2[h];
             }
-            *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd) = rr;
-            *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd) = vv;
+            DE_STORE(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd, rr);
+            DE_STORE(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd, vv);
             const int sp = spec_pt[16 * ct + nn];
             if (sp >= 0) {  // the first half of the NEXT leapfrog if the tree goes on from this point with this step (the usual case), into a point no
               T2 rh, vh, tn;  // holder can name whatever the tree decides; the tree phase adopts it or takes the half-step itself
@@ -1862,13 +1877,15 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
                 vh[h] = vv[h] - e / 2 * w2[h];
                 tn[h] = th2[it][h] + e * vh[h];
               }
-              *reinterpret_cast<T2*>(ppt(q, p, sp, PV_R, (int64_t)m.c) + dd) = rh;
-              *reinterpret_cast<T2*>(ppt(q, p, sp, PV_V, (int64_t)m.c) + dd) = vh;
-              *reinterpret_cast<T2*>(ppt(q, p, sp, PV_TH, (int64_t)m.c) + dd) = tn;
+              DE_STORE(ppt(q, p, sp, PV_R, (int64_t)m.c) + dd, rh);
+              DE_STORE(ppt(q, p, sp, PV_V, (int64_t)m.c) + dd, vh);
+              DE_STORE(ppt(q, p, sp, PV_TH, (int64_t)m.c) + dd, tn);
             }
           }
-          *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_G, (int64_t)m.c) + dd) = g2;
-          *reinterpret_cast<T2*>(ppt(q, p, m.cur, PV_W, (int64_t)m.c) + dd) = w2;
+          if ((m.act & 2) || e == T(0) || spec_pt[16 * ct + nn] < 0) {
+            DE_STORE(ppt(q, p, m.cur, PV_G, (int64_t)m.c) + dd, g2);
+            DE_STORE(ppt(q, p, m.cur, PV_W, (int64_t)m.c) + dd, w2);
+          }
           s0 = rr[0] * vv[0] + rr[1] * vv[1];
           s1 = th2[it][0] * g2[0] + th2[it][1] * g2[1];
         }

@@ -603,6 +603,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   const int epoch_env = getenv("AHMC_DENSE_EPOCH") ? atoi(getenv("AHMC_DENSE_EPOCH")) : 1;
   const int64_t epoch_min = getenv("AHMC_DENSE_EPOCH_MIN") ? atoll(getenv("AHMC_DENSE_EPOCH_MIN")) : 2048;
   const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && sizeof(T) == 8 && c->D == 512;  // (the D = 256 instantiation compiles into a masked spill — isa_check.py — and is not built)
+  q2.lazy_gw = (epoch_ok && (getenv("AHMC_DENSE_LAZY_GW") ? atoi(getenv("AHMC_DENSE_LAZY_GW")) : 1)) ? 1 : 0;  // (for the whole batch: the step-synchronous kernels of its tail must not trust a record the epoch kernel skipped)
   if (epoch_ok) {
     if (!c->dn_Asw) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_Asw), 2 * sizeof(T) * (size_t)c->D * (size_t)c->D));
     const int64_t tot = 2 * c->D * c->D;

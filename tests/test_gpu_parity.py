@@ -1075,7 +1075,9 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
     3-iteration warm-up (StepSizeAdaptor inside the kernel) and 3 draws kept on the device, trees up to the maximum depth —
     every chain takes the same number of leapfrogs in every transition and ends at the same point (the products accumulate in
     the same order; only the sums r·v, θ·g, ρ·v are added in another order: 1e-9).  Also with a chain count that leaves the
-    last workgroup partly empty, and with an epoch that ends in the middle of the trees (chunks of 5 steps)."""
+    last workgroup partly empty, with an epoch that ends in the middle of the trees (chunks of 5 steps), and with SliceTS on one
+    pipeline.  The epoch engine keeps g′, w′ of a point on record only where a leapfrog can start from it and begins every transition with
+    the motionless step (`lazy_gw`) — the step-synchronous kernels of the batch's tail included."""
     import torch
 
     D = 512
@@ -1085,7 +1087,7 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
     Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
     Minv = (Q * np.linspace(0.6, 2.0, D)) @ Q.T
     Minv = np.asfortranarray((Minv + Minv.T) / 2)
-    for N, chunk in ((2304, None), (2090, "5")):
+    for N, chunk, sampler in ((2304, None, A.MultinomialTS), (2090, "5", A.MultinomialTS), (1100, None, A.SliceTS)):
         th0 = np.asfortranarray(rs.normal(size=(D, N)))
         eps0 = 0.12 * (0.7 + 0.6 * rs.random(N))
         out = {}
@@ -1097,7 +1099,7 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
             else:
                 monkeypatch.delenv("AHMC_DENSE_CHUNK", raising=False)
             lf = A.Leapfrog(eps0)
-            k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+            k = A.HMCKernel(A.Trajectory(sampler, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
             g = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), A.DenseGaussian(P)), N, rng=A.PhiloxRNG(78), lib=hip)
             g.set_integrator(lf)
             g.set_position(th0)
