@@ -1679,13 +1679,18 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
 // chains for a whole epoch of global steps: per step it computes g′ = Pθ′ and w′ = (M⁻¹P)θ′ for ITS chains — all D rows of both
 // products, wave w the rows [w·D/8, (w+1)·D/8) — with the matrices streamed from L2 in MFMA-fragment order (k_dense_swizzle: one
 // 16-byte load per lane feeds two MFMAs; no LDS staging, no barrier in the k loop; θ′ comes straight from the chains' pool points),
-// completes the leapfrog in the EPILOGUE (second half-step on the accumulators, r·v and θ′·g′ summed over the workgroup in a fixed
-// order), and then advances the trees of its chains (d_tree_advance2, one wave per chain, four chains per wave) and takes the
-// first half-step of their next leapfrogs.  No other workgroup touches these chains during the epoch, so the only synchronisation
-// is the workgroup's own barrier; workgroups drift apart, and one's memory-bound tree phase runs beside its neighbours' MFMA loops.
-// The state between two steps is exactly k_d_tree2's (DChain2, the point pool, es, ptcur): an epoch can end after any step and
-// the step-synchronous kernels can carry on (they do, for the tail of a batch when few chains are left).
-// Accumulation over k is in the order of k_dgemm (k ascending, four at a time): g′, w′ have its bits.
+// completes the leapfrog in the EPILOGUE (second half-step on the accumulators, transposed through the wave's LDS tile into whole cache
+// lines; r·v and θ′·g′ summed over the workgroup in a fixed order; the first half-step of the NEXT leapfrog written speculatively
+// into a point no holder can name), and then advances the trees of its chains (d_tree_advance2 with 16 lanes per chain: a wave's
+// four chains at once, each under its own exec mask), which adopt the speculative point or take the half-step themselves.
+// No other workgroup touches these chains during the epoch, so the only synchronisation is the workgroup's own barrier; workgroups
+// drift apart, and one's memory-bound phases run beside its neighbours' MFMA loops.
+// The state between two steps is k_d_tree2's (DChain2, the point pool, es, ptcur): an epoch can end after any step and the
+// step-synchronous kernels can carry on (they do, for the tail of a batch when few chains are left) — with one difference,
+// DP2::lazy_gw: g′, w′ of a point are on record only where a leapfrog can START from it, and every transition begins with the
+// motionless step that recomputes them at its start point (what bounds the epilogue is its stores: 38.1 → 42.1 TFLOP/s on cfg4).
+// Accumulation over k is in the order of k_dgemm (k ascending, four at a time): g′, w′ have its bits, and the chains take the
+// decisions of the step-synchronous kernels (tests/test_gpu_parity.py: test_dense_epoch_kernel_equals_step_synchronous_kernels).
 // ================================================================================================
 constexpr int DE_WAVES = 8, DE_NCT = 2, DE_CHAINS = 16 * DE_NCT;
 #ifndef AHMC_EPOCH_NT
