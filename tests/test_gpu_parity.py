@@ -988,8 +988,7 @@ def test_full_size_slice_against_oracle(hip, oracle, cfg, offset):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("engine", ["step", "epoch"])
-@pytest.mark.parametrize("metric", ["identity", "spd"])
+@pytest.mark.parametrize("engine,metric", [("step", "identity"), ("step", "spd"), ("epoch", "identity"), ("epoch", "spd"), ("epoch_full_shard", "spd")])
 def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     """BASELINE configs[3] at its own shape: D = 512, Σᵢⱼ = 0.9^|i−j| as a dense Gaussian target (ℓπ = −½θᵀΣ⁻¹θ, the gradient
     a GEMM), shared DenseEuclideanMetric (`identity` = cfg4's initial M⁻¹ = I; `spd` = a well-conditioned full matrix, so the
@@ -1000,10 +999,15 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     src/trajectory.jl:626-742 per chain).  Every iteration (transition + adapt!) starts from the oracle's state for those
     chains and is held to the bar: identical discrete decisions on ≥ 99.9 % of them (i.e. all 128), 1e-8 on θ, r, ∇ℓπ.
     `engine`: "step" = the step-synchronous kernels (`k_dgemm` → `k_d_tree2` per global step); "epoch" = round 4's chain-complete
-    `k_dense_epoch` (what the bench runs at 8 192 chains; here its threshold is lowered so that 1 152 chains per pipeline take it)."""
-    monkeypatch.setenv("AHMC_DENSE_EPOCH", "1" if engine == "epoch" else "0")
-    monkeypatch.setenv("AHMC_DENSE_EPOCH_MIN", "32")
-    D, N, n = 512, 2304, 64
+    `k_dense_epoch` (what the bench runs at 8 192 chains; here its threshold is lowered so that 1 152 chains per pipeline take it);
+    "epoch_full_shard" = cfg4's own 8 192 chains per GPU with the engine's defaults, exactly the bench's pipeline."""
+    if engine == "epoch_full_shard":
+        monkeypatch.delenv("AHMC_DENSE_EPOCH", raising=False)
+        monkeypatch.delenv("AHMC_DENSE_EPOCH_MIN", raising=False)
+    else:
+        monkeypatch.setenv("AHMC_DENSE_EPOCH", "1" if engine == "epoch" else "0")
+        monkeypatch.setenv("AHMC_DENSE_EPOCH_MIN", "32")
+    D, N, n = 512, (8192 if engine == "epoch_full_shard" else 2304), 64
     idx = np.arange(D)
     Sigma = 0.9 ** np.abs(idx[:, None] - idx[None, :])
     P = np.asfortranarray(np.linalg.inv(Sigma))
@@ -1063,7 +1067,7 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     assert depth_seen >= 5, depth_seen   # trees of 32+ leaves: merges on several pending levels, compaction of finished chains
     # what ran: the 64×64-tile GEMM, two pipelines, the point-pool tree kernel
     assert g.info("dense_gemm_launches") > 0 and g.info("dense_pipelines") == 2 and g.info("dense_pool") == 1
-    assert (g.info("dense_epoch_launches") > 0) == (engine == "epoch")
+    assert (g.info("dense_epoch_launches") > 0) == (engine != "step")
     g.close()
     for o in os_:
         o.close()
