@@ -602,7 +602,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // the next first half-step of 32 chains per workgroup); fewer chains — the tail of a batch — keep the step-synchronous kernels.
   const int epoch_env = getenv("AHMC_DENSE_EPOCH") ? atoi(getenv("AHMC_DENSE_EPOCH")) : 1;
   const int64_t epoch_min = getenv("AHMC_DENSE_EPOCH_MIN") ? atoll(getenv("AHMC_DENSE_EPOCH_MIN")) : 2048;
-  const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && sizeof(T) == 8 && c->D == 512;  // (the D = 256 instantiation compiles into a masked spill — isa_check.py — and is not built)
+  const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && sizeof(T) == 8 && (c->D == 512 || c->D == 256);
   q2.lazy_gw = (epoch_ok && (getenv("AHMC_DENSE_LAZY_GW") ? atoi(getenv("AHMC_DENSE_LAZY_GW")) : 1)) ? 1 : 0;  // (for the whole batch: the step-synchronous kernels of its tail must not trust a record the epoch kernel skipped)
   if (epoch_ok) {
     if (!c->dn_Asw) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_Asw), 2 * sizeof(T) * (size_t)c->D * (size_t)c->D));
@@ -621,7 +621,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   auto launch_epoch = [&](hipStream_t st, int steps) {
     if constexpr (sizeof(T) == 8) {
       const unsigned grid = (unsigned)((q2.n_list + DE_CHAINS - 1) / DE_CHAINS);
-      hipLaunchKernelGGL((k_dense_epoch<T, 4>), dim3(grid), dim3(64 * DE_WAVES), 0, st, p, q2, c->dn_Asw, steps);
+      if (c->D == 256) hipLaunchKernelGGL((k_dense_epoch<T, 2>), dim3(grid), dim3(64 * DE_WAVES), 0, st, p, q2, c->dn_Asw, steps);
+      else hipLaunchKernelGGL((k_dense_epoch<T, 4>), dim3(grid), dim3(64 * DE_WAVES), 0, st, p, q2, c->dn_Asw, steps);
       c->dn_epoch_launches += 1;
     }
   };

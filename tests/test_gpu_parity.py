@@ -1080,18 +1080,21 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
     every chain takes the same number of leapfrogs in every transition and ends at the same point (the products accumulate in
     the same order; only the sums r·v, θ·g, ρ·v are added in another order: 1e-9).  Also with a chain count that leaves the
     last workgroup partly empty, with an epoch that ends in the middle of the trees (chunks of 5 steps), and with SliceTS on one
-    pipeline.  The epoch engine keeps g′, w′ of a point on record only where a leapfrog can start from it and begins every transition with
+    pipeline, and at D = 256 (the kernel's other instantiation).  The epoch engine keeps g′, w′ of a point on record only where a leapfrog can start from it and begins every transition with
     the motionless step (`lazy_gw`) — the step-synchronous kernels of the batch's tail included."""
     import torch
 
-    D = 512
-    idx = np.arange(D)
-    P = np.asfortranarray(np.linalg.inv(0.9 ** np.abs(idx[:, None] - idx[None, :])))
     rs = np.random.default_rng(2025)
-    Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
-    Minv = (Q * np.linspace(0.6, 2.0, D)) @ Q.T
-    Minv = np.asfortranarray((Minv + Minv.T) / 2)
-    for N, chunk, sampler in ((2304, None, A.MultinomialTS), (2090, "5", A.MultinomialTS), (1100, None, A.SliceTS)):
+    mats = {}
+    for D in (512, 256):
+        idx = np.arange(D)
+        P = np.asfortranarray(np.linalg.inv(0.9 ** np.abs(idx[:, None] - idx[None, :])))
+        Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+        Minv = (Q * np.linspace(0.6, 2.0, D)) @ Q.T
+        mats[D] = (P, np.asfortranarray((Minv + Minv.T) / 2))
+    for D, N, chunk, sampler in ((512, 2304, None, A.MultinomialTS), (512, 2090, "5", A.MultinomialTS), (512, 1100, None, A.SliceTS),
+                                 (256, 1300, None, A.MultinomialTS)):
+        P, Minv = mats[D]
         th0 = np.asfortranarray(rs.normal(size=(D, N)))
         eps0 = 0.12 * (0.7 + 0.6 * rs.random(N))
         out = {}
