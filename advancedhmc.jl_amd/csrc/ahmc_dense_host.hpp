@@ -125,8 +125,9 @@ int dn_ensure(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
   return AHMC_OK;
 }
 
-// the point pool of k_d_tree2 for trees of up to max_depth doublings: 2·max_depth + 2 points of 5 vectors per chain, and
-// max_depth + 2 ρ vectors (cfg4's shard, D = 512, 8 192 chains, max_depth 10: 3.7 GB + 0.4 GB of the 288)
+// the point pool of k_d_tree2 / k_dense_epoch for trees of up to max_depth doublings: 2·max_depth + 2 points of 5 vectors per chain
+// (+ 1: the speculative half-step of k_dense_epoch), and max_depth + 2 ρ vectors (cfg4's shard, D = 512, 8 192 chains, max_depth 10:
+// 3.9 GB + 0.4 GB of the 288)
 template <class T>
 int dn_ensure_pool(Ctx<T>* c, int max_depth) {
   const int npt = 2 * max_depth + 3, nrho = PR_LEVEL0 + (max_depth > 1 ? max_depth : 2);
