@@ -454,7 +454,8 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   // its full share, 80 KB at two workgroups per CU = five 16 KB slots at D = 2 048 instead of four.  AHMC_NUTS_LDS_WG_KB caps it.)
   static const size_t wg_cap = (size_t)(getenv("AHMC_NUTS_LDS_WG_KB") ? atoi(getenv("AHMC_NUTS_LDS_WG_KB")) : 160) * 1024;
   if (per_wave > wg_cap / (size_t)NW) per_wave = wg_cap / (size_t)NW;
-  per_wave = per_wave > scalar_bytes + 128 ? per_wave - scalar_bytes - 128 : 0;
+  const size_t static_lds = 128 + (NW > 1 ? 1024 / (size_t)NW : 0);  // per wave: the exchange buffers of the reductions (multi-wave chains: one per call site, ahmc_device.hpp)
+  per_wave = per_wave > scalar_bytes + static_lds ? per_wave - scalar_bytes - static_lds : 0;
   n_lds_slots = (int)std::min<size_t>((size_t)n_slots, per_wave / slot_bytes);
   const char* ovs = getenv("AHMC_NUTS_LDS_SLOTS");
   if (ovs) n_lds_slots = std::max(0, std::min(n_slots, atoi(ovs)));

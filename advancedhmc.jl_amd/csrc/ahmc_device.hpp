@@ -501,6 +501,53 @@ __device__ __forceinline__ T group_sum1(T x) {
   return v[0];
 }
 
+// The same sum with ONE barrier, for a call site whose next use of ITS OWN buffer is always preceded by another barrier of the
+// workgroup (then every wave has read the buffer before it is written again).  Round 4: the hierarchical-Gaussian leaf of a
+// multi-wave chain took eight barriers (two broadcasts, the target's two sums, ℓπ / ℓκ: two each); with an exchange buffer per
+// site — the broadcast's next write follows the sums' barrier, the sums' follows the next leaf's broadcast, the energies' follows
+// both — it takes three.  Same additions in the same order as group_allsum: the bits do not change.
+__device__ __forceinline__ double* xwave_buf_h() {
+  __shared__ __attribute__((aligned(16))) double buf[2];
+  return buf;
+}
+__device__ __forceinline__ double* xwave_buf_s() {
+  __shared__ __attribute__((aligned(16))) double buf[8 * 2];
+  return buf;
+}
+__device__ __forceinline__ double* xwave_buf_f() {
+  __shared__ __attribute__((aligned(16))) double buf[8 * 4];
+  return buf;
+}
+template <int G, class T, int K>
+__device__ __forceinline__ void group_allsum_once(T (&v)[K], double* b) {
+  static_assert(G == 128 || G == 256 || G == 512, "multi-wave groups only");
+  constexpr int NW = G / 64;
+  wave_allsum<64>(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) b[w * K + k] = (double)v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    T s = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) s += (T)b[ww * K + k];  // fixed order: same bits in every wave
+    v[k] = s;
+  }
+}
+// the all-reduce that ends a leapfrog (ℓπ, ℓκ and what rides with them): one barrier where the target's own exchanges separate its uses
+template <int G, int TK, class T, int K>
+__device__ __forceinline__ void leapfrog_allsum(T (&v)[K]) {
+  if constexpr (G > 64 && TK == 3) {
+    static_assert(K <= 4, "xwave_buf_f holds four values per wave");
+    group_allsum_once<G>(v, xwave_buf_f());
+  } else {
+    group_allsum<G>(v);
+  }
+}
+
 // broadcast the value held by lane `src` (0..G-1) of the group to the whole group
 template <int G>
 __device__ __forceinline__ int group_bcast_i32(int v, int src) {
@@ -612,8 +659,20 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
     if constexpr (TK == 4) part = ::ahmc_user::logdensity<T, G, E>(tp.params, D, th, grad, lane, d0);  // target plugin
 #endif
     if constexpr (TK == 3) {  // AHMC_TARGET_HIER_GAUSS: θ = (μ, log τ, x...)
-      T mu = group_bcast<G>(th[0], 0);
-      T lt = (E >= 2) ? group_bcast<G>(th[E >= 2 ? 1 : 0], 0) : group_bcast<G>(th[0], 1);
+      T mu, lt;
+      if constexpr (G > 64) {  // (E >= 4 here: both leading elements sit in the chain's first lane; one exchange, one barrier)
+        double* hb = xwave_buf_h();
+        if (threadIdx.x == 0) {
+          hb[0] = (double)th[0];
+          hb[1] = (double)th[E >= 2 ? 1 : 0];
+        }
+        __syncthreads();
+        mu = (T)hb[0];
+        lt = (T)hb[1];
+      } else {
+        mu = group_bcast<G>(th[0], 0);
+        lt = (E >= 2) ? group_bcast<G>(th[E >= 2 ? 1 : 0], 0) : group_bcast<G>(th[0], 1);
+      }
       T s[2] = {0, 0};
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -623,7 +682,8 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
         s[0] += ok ? df : T(0);
         s[1] += ok ? df * df : T(0);
       }
-      group_allsum<G>(s);
+      if constexpr (G > 64) group_allsum_once<G>(s, xwave_buf_s());
+      else group_allsum<G>(s);
       T itau2 = exp(-2 * lt);
       T n = (T)(D - 2);
       T total = -(log2pi + mu * mu) / 2 - (log2pi + lt * lt) / 2 - n * (log2pi + 2 * lt) / 2 - s[1] * itau2 / 2;
@@ -715,7 +775,7 @@ __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E]
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
   if constexpr (TEMPER) temper(lf, z.r, i, false, n);
   red[1] = kinetic_partial(z.r, minv);
-  group_allsum<G>(red);
+  leapfrog_allsum<G, TK>(red);
   z.lp = sanitize(red[0]);
   z.lk = sanitize(-red[1] / 2);
 }
@@ -738,7 +798,9 @@ __device__ __forceinline__ T leapfrog_step_ne(Point<T, E>& z, const T (&minv)[E]
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
   const T kin = kinetic_partial(z.r, minv);
-  const T s = group_sum1<G>(part - kin / 2);
+  T sv[1] = {part - kin / 2};
+  leapfrog_allsum<G, TK>(sv);
+  const T s = sv[0];
   return is_finite(s) ? s : -Lim<T>::inf();
 }
 
@@ -760,7 +822,7 @@ __device__ __forceinline__ void leapfrog_step_plus2(Point<T, E>& z, const T (&mi
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
   red[1] = kinetic_partial(z.r, minv);
   partials(red[2], red[3]);
-  group_allsum<G>(red);
+  leapfrog_allsum<G, TK>(red);
   z.lp = sanitize(red[0]);
   z.lk = sanitize(-red[1] / 2);
   extra[0] = red[2];
@@ -773,7 +835,7 @@ __device__ __forceinline__ void fill_caches(Point<T, E>& z, const T (&minv)[E], 
   T red[2];
   red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
   red[1] = kinetic_partial(z.r, minv);
-  group_allsum<G>(red);
+  leapfrog_allsum<G, TK>(red);
   z.lp = sanitize(red[0]);
   z.lk = sanitize(-red[1] / 2);
 }
