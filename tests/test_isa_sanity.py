@@ -130,3 +130,31 @@ def test_nested_region_scan_flags_the_shape_that_faulted_on_the_gpu():
     close = next(i for i, l in enumerate(lines) if "s_or_b64 exec, exec, s[10:11]" in l)
     inside = lines[:close] + [lines[load]] + lines[close:load] + lines[load + 1:]
     assert isa_check.scan("\n".join(inside), "reduced-inside", quiet=True) == 0
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs llvm-objdump")
+def test_dense_epoch_kernel_keeps_its_products_and_epilogue_out_of_scratch(tmp_path):
+    """`k_dense_epoch<double,4>` (cfg4): between the first MFMA of a step and the barrier that ends the epilogue there is no
+    scratch access.  Round 4 measured what one costs there: the epilogue's loads, left undefined for the idle chains' lanes,
+    were carried around the step loop, 238 registers spilled, 92 scratch reloads sat in the epilogue — 29 instead of 35 TFLOP/s
+    (DESIGN §4.2).  The tree phase after that barrier may spill (it runs under per-chain exec masks; the build's scan covers it)."""
+    import re
+
+    from ahmc_amd import build as B
+    from ahmc_amd import isa_check
+
+    obj = os.path.join(B.OBJ, "api.o")
+    if not os.path.exists(obj):
+        pytest.skip("object cache empty (the .so was built elsewhere)")
+    text = isa_check.disassemble(obj, str(tmp_path))
+    m = re.search(r"^[0-9a-f]+ <_ZN4ahmc13k_dense_epochIdLi4EE[^>]*>:$", text, re.M)
+    assert m, "k_dense_epoch<double, 4> is not in the api unit"
+    body = text[m.end():]
+    body = body[:body.index("\n\n")] if "\n\n" in body else body
+    ins = [l.split("//")[0].strip() for l in body.splitlines() if l.strip()]
+    mfma = [i for i, l in enumerate(ins) if l.startswith("v_mfma_f64_16x16x4")]
+    assert len(mfma) >= 3 * 16, len(mfma)   # three unrolled k-steps of 16 MFMAs per wave
+    end = next(i for i, l in enumerate(ins) if i > mfma[-1] and l.startswith("s_barrier"))
+    hot = ins[mfma[0]:end]
+    assert not [l for l in hot if l.startswith("scratch_")], [l for l in hot if l.startswith("scratch_")][:5]
+    assert sum(l.startswith("global_store") for l in hot) >= 5 * 16   # r, v and the speculative r½, v½, θ″ of 16 chains per half-wave pass
