@@ -78,6 +78,17 @@ def algorithmic_bytes_per_leapfrog(D, metric, itemsize):
 CONFIG_FAMILY = {"cfg2": 0, "cfg3": 2, "cfg5": 3}   # the log-density family (TK) whose instantiation units hold a config's k_nuts
 
 
+def dense_counter_bytes_per_leapfrog():
+    """cfg4: bytes beyond L2 per useful chain-leapfrog of ALL the dense engine's kernels, from the committed PMC passes of a short run
+    (profiles/r4_cfg4_dense_counters.json: 2 x FETCH_SIZE + WRITE_SIZE; the bench-sized run does not finish under PMC serialisation);
+    None when the file is missing.  A figure for orientation (matrices missing L2 included), not an in-run counter."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r4_cfg4_dense_counters.json")))
+        return d["derived"]["hbm_d_vectors_per_chain_leapfrog_all_kernels"] * 4096.0
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def sources_digest(config="cfg2"):
     """digest of the DEVICE code of the two instantiation units that hold `config`'s trajectory kernels in the shipped
     libahmc_hip.so (advancedhmc.jl_amd/build.py: config_digest — the stamp libahmc_hip.so.kdigests travels with the library)"""
@@ -391,6 +402,7 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
                     "kernel": ("k_dense_epoch (chain-complete workgroups: both products, the half-steps and the trees of 32 chains per workgroup, 64 global "
                                "steps per launch) + k_dgemm / k_d_tree2 for the tails of the batches, whole timed region"),
                     "launches_since_create": runs[-1].get("dense_launches"),
+                    "hbm_bytes_per_leapfrog_by_counters": dense_counter_bytes_per_leapfrog(),
                     "algorithmic_flops_per_leapfrog": F_lf,
                     "note": "useful leapfrogs x 4 D^2 / wall time of the whole loop (tree kernel, momenta and adaptation included)"}
         out = {
