@@ -267,3 +267,18 @@ print("ok")
     env = dict(os.environ, MALLOC_PERTURB_="165")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+
+
+def test_info_ids_agree_between_header_python_mirror_and_oracle(oracle):
+    """every AHMC_INFO_* of include/ahmc_hip.h has the same id in the Python mirror (`Engine.INFO`) and is answered by the CPU
+    checker's `ahmc_get_info` (0 for what only the device engine has) — the three places an introspection key is added in"""
+    import re
+
+    hdr = open(os.path.join(ROOT, "include", "ahmc_hip.h")).read()
+    ids = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"AHMC_INFO_([A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
+    assert len(ids) >= 14 and sorted(ids.values()) == list(range(len(ids)))
+    assert ids == A.Engine.INFO, (sorted(set(ids.items()) ^ set(A.Engine.INFO.items())))
+    e = A.Engine(A.Hamiltonian(A.UnitEuclideanMetric(3), A.IsoGaussian(3)), 4, rng=1, lib=oracle)
+    for key in ids:
+        assert isinstance(e.info(key), int), key
+    e.close()
