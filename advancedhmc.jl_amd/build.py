@@ -116,7 +116,9 @@ def unit_digests() -> dict:
 
     out = {}
     for name, _, _ in _units():
-        if not name.startswith("inst_"):
+        # (`api`: the unit that holds the dense engine's kernels — k_dense_epoch, k_dgemm, k_d_tree2 — and the target-independent
+        # ones: what cfg4's counters are keyed on)
+        if not (name.startswith("inst_") or name == "api"):
             continue
         f = os.path.join(OBJ, name + ".o.isa")
         if not os.path.exists(f):
@@ -148,7 +150,7 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> str:
     digest = _sources_digest()
     stamp = OUT + ".digest"  # next to the .so (the object cache is outside the repo and does not travel to the GPU box)
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == digest:
-        if not os.path.exists(OUT + ".kdigest") or not os.path.exists(OUT + ".kdigests"):
+        if not os.path.exists(OUT + ".kdigest") or not os.path.exists(OUT + ".kdigests") or '"api"' not in open(OUT + ".kdigests").read():
             _write_stamps()
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

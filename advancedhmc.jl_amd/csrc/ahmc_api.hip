@@ -758,6 +758,8 @@ int reserve_normals(Ctx<T>* c, int64_t n_trans) {
     need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
   }
   c->znorm_elems = need;
+  // (the cap is what the device could hold THEN: a later reserve that gets everything it asked for lifts it again)
+  if (c->znorm_cap_trans > 0 && n_trans > c->znorm_cap_trans) c->znorm_cap_trans = 0;
   return AHMC_OK;
 }
 
@@ -1276,6 +1278,7 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
     c->tparams = np_dev;
     c->target_kind = kind;
     c->have_point = false;
+    c->order_valid = false; c->sched = {};   // (a dispatch order and a launch length measured on another density say nothing about this one)
     return dn_refresh_fused(c);
   });
 }
@@ -1343,12 +1346,16 @@ int32_t ahmc_set_target_kernel(ahmc_ctx* ctx, int32_t handle_kind, void* handle,
     c->uk_user = user;
     c->target_kind = AHMC_TARGET_KERNEL;
     c->have_point = false;
+    c->order_valid = false; c->sched = {};
     return dn_refresh_fused(c);
   });
 }
 
 int32_t ahmc_set_metric(ahmc_ctx* ctx, int32_t kind, const void* Minv, int64_t n) {
-  FOR_CTX_MUT(ctx, { return set_metric(c, kind, static_cast<const T*>(Minv), n); });
+  FOR_CTX_MUT(ctx, {
+    c->order_valid = false; c->sched = {};   // (tree sizes follow the metric: the measured order and launch length are another sampler's)
+    return set_metric(c, kind, static_cast<const T*>(Minv), n);
+  });
 }
 
 int32_t ahmc_get_metric(ahmc_ctx* ctx, void* out, int64_t n) {
@@ -1746,6 +1753,8 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         bool probing = false;   // this launch belongs to a group that is being timed
         auto& sc = c->sched;
         if (draw_batch_env <= 0 && sched_env != 0 && order_refresh && sc.phase != 4 && batch >= 2 * SCHED_MIN) {
+          if (sc.g_left > 0 && sc.g_len > left) sc.g_left = 0;   // a group an earlier call left unfinished (it returned an error, or
+                                                                   // ended inside the group): abandoned, never a launch longer than what is left
           if (sc.g_left > 0) {                       // inside a group
             k = sc.g_len; probing = true;
           } else if (!sc.primed && !c->order_from_work && left >= 4 * SCHED_START) {

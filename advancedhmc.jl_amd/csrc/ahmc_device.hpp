@@ -661,6 +661,10 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
     if constexpr (TK == 3) {  // AHMC_TARGET_HIER_GAUSS: θ = (μ, log τ, x...)
       T mu, lt;
       if constexpr (G > 64) {  // (E >= 4 here: both leading elements sit in the chain's first lane; one exchange, one barrier)
+        // Invariants of the one-barrier exchanges (xwave_buf_h / _s / _f): ONE chain per workgroup of G threads — threadIdx.x == 0 is the
+        // chain's first lane and wave w = threadIdx.x >> 6 (the launch plan of every multi-wave geometry, ahmc_kernels.hpp: group_grid);
+        // θ[0] and θ[1] in that lane; and every leapfrog_allsum<G,3> follows a target_eval, whose barriers separate two uses of a buffer.
+        static_assert(E >= 2, "multi-wave hierarchical target: mu and log tau must both sit in the chain's first lane (E >= 2)");
         double* hb = xwave_buf_h();
         if (threadIdx.x == 0) {
           hb[0] = (double)th[0];

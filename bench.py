@@ -80,13 +80,21 @@ CONFIG_FAMILY = {"cfg2": 0, "cfg3": 2, "cfg5": 3}   # the log-density family (TK
 
 def dense_counter_bytes_per_leapfrog():
     """cfg4: bytes beyond L2 per useful chain-leapfrog of ALL the dense engine's kernels, from the committed PMC passes of a short run
-    (profiles/r4_cfg4_dense_counters.json: 2 x FETCH_SIZE + WRITE_SIZE; the bench-sized run does not finish under PMC serialisation);
-    None when the file is missing.  A figure for orientation (matrices missing L2 included), not an in-run counter."""
+    (profiles/counters_at_head.json: configs.cfg4 — 2 x FETCH_SIZE + WRITE_SIZE; the bench-sized run does not finish under PMC
+    serialisation).  Valid only for the device code it was taken on: the digest of the unit that holds the dense engine's kernels
+    (`api`, libahmc_hip.so.kdigests) must match, else (None, reason) — never a figure from other kernels.  A figure for orientation
+    (matrices missing L2 included; a 10 + 10-transition run), not an in-run counter."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r4_cfg4_dense_counters.json")))
-        return d["derived"]["hbm_d_vectors_per_chain_leapfrog_all_kernels"] * 4096.0
+        c = json.load(open(os.path.join(ROOT, "profiles", "counters_at_head.json")))["configs"]["cfg4"]
     except Exception:  # noqa: BLE001
-        return None
+        return None, "profiles/counters_at_head.json has no counters for cfg4"
+    try:
+        have = json.load(open(os.path.join(ROOT, "advancedhmc.jl_amd", "csrc", "libahmc_hip.so.kdigests"))).get("api")
+    except (OSError, ValueError):
+        have = None
+    if not have or c.get("unit_digest") != have:
+        return None, "profiles/counters_at_head.json: the counters of cfg4 were taken on other device code (digest mismatch): stale, not used"
+    return c["hbm_d_vectors_per_chain_leapfrog_all_kernels"] * c.get("d_vector_bytes", 4096.0), c.get("source", "profiles/counters_at_head.json")
 
 
 def sources_digest(config="cfg2"):
@@ -234,6 +242,10 @@ def launch_check(args):
     return 0 if seen == world == args.gpus else 1
 
 
+class SetupFailed(RuntimeError):
+    """a config's setup failed on some rank and ALL ranks know (they agreed before the first collective of its timed loop)"""
+
+
 def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0, chains=0):
     """One bench line for one config: W untimed transitions on a throw-away engine, then the timed sample loop (median of
     `repeats` runs on fresh engines), the final gather, the roofline of the dominant kernel and — rank 0 of a one-GPU run — the CPU
@@ -266,17 +278,43 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
     # the draws of the timed region: θ after every post-warm-up transition of every chain, (D, N, n_draws) in HBM — what the
     # reference's `sample` returns (src/sampler.jl:224-227); written by the trajectory kernel inside the timed region
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
-    draws = None if args.no_draws_out else torch.empty((n_draws, N, D), dtype=tdt, device=dev)
+    try:
+        draws = None if args.no_draws_out else torch.empty((n_draws, N, D), dtype=tdt, device=dev)
+    except Exception as ex:  # noqa: BLE001  (out of memory: the other ranks must hear of it)
+        if dist is None:
+            raise
+        draws = ex
+
+    def agree(ok, what):
+        """N > 1: every rank learns whether ALL ranks got through `what` (allocations that depend on a rank's free memory) BEFORE the
+        first collective of the timed loop — a rank that raised alone would leave the others waiting in a barrier for ever"""
+        if dist is not None:
+            t = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok_all = bool(t.item() > 0.5)
+        else:
+            ok_all = ok
+        if not ok_all:
+            raise SetupFailed(f"{cfg_name}: {what} failed on " + ("this rank" if not ok else "another rank"))
+
+    agree(not isinstance(draws, Exception), "the draws buffer")
 
     # W untimed warm-up transitions of the same loop (code objects, allocator, clocks, first touch of the draws buffer) on a throw-away engine
     if warm_trans > 0:
-        eng, kernel = make()
+        try:
+            eng, kernel = make()
+            err = None
+        except Exception as ex:  # noqa: BLE001
+            eng, err = None, ex
+        if err is not None and dist is None:
+            raise err
+        agree(err is None, f"engine setup ({err!r})" if err else "engine setup")
         nwa = int(round(warm_trans * args.adapt_fraction))
         nwd = max(1, warm_trans - nwa)
         sample_loop(eng, kernel, nwa, nwd, barrier_for(eng), draws_ptr=draws.data_ptr() if (draws is not None and nwd <= n_draws) else None)
         eng.close()
 
-    want_ess = draws is not None and (args.ess > 0 or (args.ess < 0 and D <= 256)) and n_draws >= 8
+    want_ess = draws is not None and args.ess != 0 and n_draws >= 8   # every config: one thread per (dimension, chain) series, any D
     ess_buf = torch.empty((N, D), dtype=tdt, device=dev) if want_ess else None
 
     runs = []
@@ -396,13 +434,15 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
                         "device_time_share_of_timed_region": sum(x["launches"] * x["avg_launch_ms"] for x in both) / 1e3 / med["dt"]}
         else:
             F_lf = 4 * D * D
+            dense_bytes, dense_src = dense_counter_bytes_per_leapfrog() if (args.dtype == "f64" and not dim) else (None, "counters are for cfg4 at D = 512, f64")
             tf = (med["leap_adapt"] + med["leap_draw"]) * F_lf / med["dt"] / 1e12
             peak = F64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else F32_MFMA_PEAK_TFLOPS
             roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": tf, "frac": tf / peak, "traffic": None,
-                    "kernel": ("k_dense_epoch (chain-complete workgroups: both products, the half-steps and the trees of 32 chains per workgroup, 64 global "
-                               "steps per launch) + k_dgemm / k_d_tree2 for the tails of the batches, whole timed region"),
+                    "kernel": "k_dense_epoch + k_dgemm / k_d_tree2 tails (whole timed region)",
+                    "kernel_note": ("k_dense_epoch: chain-complete workgroups — both products, the half-steps and the trees of 32 chains per workgroup, 64 global "
+                                    "steps per launch; k_dgemm / k_d_tree2 for the tails of the batches"),
                     "launches_since_create": runs[-1].get("dense_launches"),
-                    "hbm_bytes_per_leapfrog_by_counters": dense_counter_bytes_per_leapfrog(),
+                    "hbm_bytes_per_leapfrog_by_counters": dense_bytes, "counters": dense_src,
                     "algorithmic_flops_per_leapfrog": F_lf,
                     "note": "useful leapfrogs x 4 D^2 / wall time of the whole loop (tree kernel, momenta and adaptation included)"}
         out = {
@@ -485,6 +525,117 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
     return out
 
 
+LINE_BUDGET = 6000   # characters of the ONE line the driver parses (its capture keeps ~8 KB of output tail)
+
+
+def _sig(x, n=6):
+    """numbers to n significant digits (the line is a record, not an archive: bench_detail.json keeps every bit)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if not math.isfinite(x):
+            return None
+        if x == int(x) and abs(x) < 1e15:
+            return int(x)
+        return float(f"{x:.{n}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _roof_compact(r, with_launches):
+    """the judge's fields of `roofline`: bound / unit / peak / achieved / frac / traffic / kernel (+ the launches the in-run HIP
+    events timed); the instruction mix, the peak's definition and the counters' provenance stay in bench_detail.json"""
+    if not r:
+        return None
+    o = {k: r.get(k) for k in ("bound", "unit", "peak", "achieved", "frac", "traffic")}
+    o["kernel"] = (r.get("kernel") or "")[:64]
+    for k in ("valu_efficiency", "device_time_share_of_timed_region", "hbm_bytes_per_leapfrog_by_counters"):
+        if r.get(k) is not None:
+            o[k] = r[k]
+    if with_launches:
+        for which in ("dominant", "other"):
+            x = r.get(which)
+            if x:
+                o[which] = {k: x.get(k) for k in ("kernel", "launches", "avg_launch_ms", "leapfrogs_per_launch", "frac", "traffic", "hbm_model_frac") if x.get(k) is not None}
+    elif r.get("dominant"):
+        x = r["dominant"]
+        o["launches"], o["avg_launch_ms"] = x.get("launches"), x.get("avg_launch_ms")
+    return o
+
+
+def _cpu_compact(b, full):
+    if not b:
+        return None
+    if b.get("value") is None:
+        return {"value": None, "error": str(b.get("error"))[:120]}
+    o = {k: b.get(k) for k in ("value", "unit", "cores", "kind")}
+    if full:
+        o["sample"] = (b.get("sample") or "")[:140]
+        if b.get("single_thread"):
+            o["single_thread_value"] = b["single_thread"].get("value")
+    else:
+        o.pop("unit", None)
+    return o
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line the driver parses, from the full record: the contract's headline keys, `roofline` and `cpu_baseline` with the
+    fields the contract names, `config` with the workload and — default invocation — `config.secondary.{cfg3,cfg5,cfg4}` each as
+    {value, ms_per_step, steps, workload, dtype, roofline, cpu_baseline}.  Everything else (instruction mixes, definitions, every run,
+    ESS prose) is in `detail_path`.  Round 4's line had grown to 31.9 KB and the driver's 8 KB capture lost its head: this one is
+    built to stay under LINE_BUDGET and, should a future field push it over, sheds optional fields instead of growing."""
+    c = full["config"]
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data")}
+    cc = {"workload": c["workload"][:300]}
+    for k in ("chains_per_gpu", "D", "parallelism", "ranks_seen", "transitions_per_step", "n_adapts", "n_draws", "leapfrogs", "runs", "reported",
+              "fits_quoted_config", "draw_launch_length_found_by_the_engine", "max_abs_mean", "max_abs_var_minus_1"):
+        if c.get(k) is not None:
+            cc[k] = c[k]
+    for ph in ("warmup_phase", "post_adaptation"):
+        if c.get(ph):
+            cc[ph] = {k: c[ph].get(k) for k in ("value", "mean_leapfrogs_per_transition", "divergent")}
+    if c.get("ess"):
+        cc["ess_per_sec"] = c["ess"].get("ess_per_sec")
+        cc["ess_per_draw_min_over_dims"] = c["ess"].get("ess_per_draw_min_over_dims")
+    if c.get("draws_materialised_in_timed_region"):
+        cc["draws_gib_written_in_timed_region"] = c["draws_materialised_in_timed_region"].get("gib")
+    sec = c.get("secondary")
+    if sec:
+        cs = {}
+        for name, o in sec.items():
+            if not o or "value" not in o:
+                cs[name] = {"error": str((o or {}).get("error"))[:160]}
+                continue
+            oc = o["config"]
+            cs[name] = {"value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "dtype": o["dtype"],
+                        "workload": oc["workload"].split(", timed =")[0].split("; timed =")[0][:200],
+                        "n_adapts": oc["n_adapts"], "n_draws": oc["n_draws"], "chains_per_gpu": oc["chains_per_gpu"],
+                        "ess_per_sec": (oc.get("ess") or {}).get("ess_per_sec"),
+                        "roofline": _roof_compact(o.get("roofline"), False), "cpu_baseline": _cpu_compact(o.get("cpu_baseline"), False)}
+        cc["secondary"] = cs
+    if detail_path:
+        cc["detail"] = detail_path
+    out["config"] = cc
+    out["roofline"] = _roof_compact(full.get("roofline"), True)
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = _cpu_compact(full["cpu_baseline"], True)
+    out = _sig(out)
+    # the budget is a hard one: shed optional fields, most dispensable first, rather than print a line the driver cannot hold
+    for path in (("config", "runs"), ("roofline", "other"), ("config", "max_abs_var_minus_1"), ("config", "max_abs_mean"),
+                 ("config", "leapfrogs"), ("roofline", "dominant"), ("cpu_baseline", "sample")):
+        if len(json.dumps(out)) <= LINE_BUDGET:
+            break
+        out.get(path[0], {}).pop(path[1], None)
+    if len(json.dumps(out)) > LINE_BUDGET:
+        for o in out["config"].get("secondary", {}).values():
+            o.pop("workload", None)
+    return out
+
+
 # the default run reports the other single-GPU BASELINE configs beside the headline (config.secondary): (steps, transitions per
 # step, untimed warm-up transitions, timed runs, seconds of CPU baseline) — sized so that the whole default invocation stays
 # well under two minutes: cfg3 1 000 + 1 000, cfg5 and cfg4 100 + 100 on one GPU's shard
@@ -510,8 +661,10 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64", help="f64 = the reference default and the headline; f32 = what the "
                     "reference's CUDA smoke test uses (test/CUDA/cuda.jl:18), reported for information")
     ap.add_argument("--ess", type=int, default=-1, help="ESS of the TIMED run's draws (every chain, every dimension; device reduction through ahmc_ess): "
-                    "-1 = on for D <= 256, 0 = off, 1 = on")
+                    "0 = off, anything else = on (every config; outside the timed region)")
     ap.add_argument("--no-draws-out", action="store_true", help="do not materialise the draws in the timed region (A/B of its cost; the reported line always does)")
+    ap.add_argument("--detail", default="bench_detail.json", help="file (relative to the repository) that receives the FULL record; the printed line "
+                    "is its compact form (<= 6 000 characters).  '' = none")
     ap.add_argument("--launch-check", action="store_true", help="spawn/rendezvous check only (gloo, no GPU, no compute)")
     args = ap.parse_args()
 
@@ -547,16 +700,23 @@ def main():
     out = run_config(ctx, headline, args.steps, T, args.warmup * T, args.repeats, 12.0, dim=args.dim, chains=args.chains)
     # The other BASELINE configs a single GPU holds, each with its own value / roofline / cpu_baseline, beside the headline — in
     # the default invocation only (what the driver runs).  At N > 1: the configs BASELINE.json quotes on exactly N GPUs.
-    if args.config is None and not args.no_secondary and not args.dim and not args.chains and args.dtype == "f64":
+    if args.config is None and not args.no_secondary and not args.dim and args.dtype == "f64":
         sec = {}
         ctx["single_thread_leg"] = False
         for name, (st, t2, wt, rp, cpu_s) in SECONDARY.items():
             if world > 1 and CONFIGS[name]["quoted_gpus"] != world:
                 continue
             try:
-                o = run_config(ctx, name, st, t2, wt, rp, cpu_s)
+                # (--chains with the default invocation: the contract test's reduced run — every config at that many chains)
+                o = run_config(ctx, name, st, t2, wt, rp, cpu_s, chains=min(args.chains, CONFIGS[name]["N"]) if args.chains else 0)
             except Exception as ex:  # a secondary config must never take the headline down with it
                 o = {"error": repr(ex)} if rank == 0 else None
+                if dist is not None and not isinstance(ex, SetupFailed):
+                    # one rank failing INSIDE the loop leaves the others waiting in its collectives: no way to agree any more — say so
+                    # on stderr and stop running secondaries on this rank (the headline is already computed; setup failures — the
+                    # likely ones: memory — are agreed on by all ranks before the first collective, see run_config)
+                    print(f"bench.py rank {rank}: {name} failed after setup: {ex!r}", file=sys.stderr, flush=True)
+                    break
             if rank == 0:
                 sec[name] = o
         if rank == 0:
@@ -566,7 +726,19 @@ def main():
             ctypes.CDLL(None).fflush(None)  # that the JSON line is the LAST line of stdout whatever the buffering
         except Exception:
             pass
-        print(json.dumps(out), flush=True)  # flushed NOW: with a process group alive the interpreter's exit path (RCCL / c10d
+        detail = None
+        if args.detail:
+            try:  # the full record (instruction mixes, every run, definitions, ESS prose): a side file, named in the line
+                detail = args.detail if os.path.isabs(args.detail) else os.path.join(ROOT, args.detail)
+                os.makedirs(os.path.dirname(detail), exist_ok=True)
+                with open(detail, "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as ex:
+                detail = None
+                print(f"bench.py: cannot write {args.detail}: {ex}", file=sys.stderr)
+        line = json.dumps(compact_line(out, os.path.relpath(detail, ROOT) if detail else None))
+        assert len(line) <= LINE_BUDGET, len(line)
+        print(line, flush=True)             # flushed NOW: with a process group alive the interpreter's exit path (RCCL / c10d
         sys.stdout.flush()                  # teardown) was seen to drop a block-buffered stdout — the line must not depend on it
     if dist is not None:
         dist.destroy_process_group()

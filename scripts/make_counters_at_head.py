@@ -13,12 +13,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ahmc_amd as A  # noqa: E402
-from ahmc_amd.build import kernel_digest, config_digest, OBJ  # noqa: E402
+from ahmc_amd.build import kernel_digest, config_digest, unit_digests, OBJ  # noqa: E402
 from ahmc_amd import isa_check  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import valu_mix  # noqa: E402
 
-ROUND = os.environ.get("AHMC_ROUND", "r4")
+ROUND = os.environ.get("AHMC_ROUND", "r5")
 RATES = os.path.join(ROOT, "profiles", "r3_valu_rate.json")   # scripts/probe/valu_rate.hip on the MI355X
 
 
@@ -98,6 +98,28 @@ for cfg in sys.argv[1:]:
                     c[mode]["valu_peak_mix_error"] = repr(ex)
     if cfg in FAMILY:
         out["configs"][cfg] = c
+    elif cfg == "cfg4":
+        # the dense engine: bytes beyond L2 per USEFUL chain-leapfrog over all its kernels (2 x FETCH_SIZE + WRITE_SIZE summed over every
+        # dispatch of the fetch / write passes), keyed on the digest of the unit that holds those kernels (`api`)
+        api_then, api_now = (s.get("unit_digests") or {}).get("api"), unit_digests().get("api")
+        if not api_then or api_then != api_now:
+            print(f"cfg4: counters were taken on other device code (unit api: {str(api_then)[:12]} then, {str(api_now)[:12]} now): NOT used")
+        else:
+            pk = [k for k in s.get("per_kernel_counters", []) if "hbm_gbytes" in k]
+            lfp = s.get("leapfrogs_by_pass", {})
+            lf = [sum(v.values()) if isinstance(v, dict) else v for v in (lfp.get("fetch"), lfp.get("write")) if v]
+            if pk and lf:
+                useful = sum(lf) / len(lf)
+                total = sum(k["hbm_gbytes"] for k in pk) * 1e9
+                ep = [k for k in pk if "k_dense_epoch" in k["kernel"]]
+                out["configs"]["cfg4"] = {
+                    "unit_digest": api_now, "d_vector_bytes": 4096.0, "useful_chain_leapfrogs": useful,
+                    "hbm_d_vectors_per_chain_leapfrog_all_kernels": total / useful / 4096.0,
+                    "k_dense_epoch_share_of_hbm_bytes": sum(k["hbm_gbytes"] for k in ep) * 1e9 / total if ep else None,
+                    "k_dense_epoch_mfma_f64_per_useful_leapfrog": sum(k.get("SQ_INSTS_VALU_MFMA_F64", 0) for k in ep) / useful if ep else None,
+                    "command": s.get("command"),
+                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a SHORT cfg4 run (scripts/profile_head.sh cfg4 with PROFILE_EXTRA)"}
+                c = out["configs"]["cfg4"]
     keep = {k: s.get(k) for k in ("config", "command", "kernel_digest", "kernel_stats", "mode0_launches", "mode3_launches", "counters", "leapfrogs_by_pass", "per_kernel_counters")}
     keep["bench_plain"] = s.get("bench_plain")
     with open(os.path.join(ROOT, "profiles", f"{ROUND}_{cfg}_profile_summary.json"), "w") as f:

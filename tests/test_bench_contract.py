@@ -32,40 +32,139 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert res.returncode != 0
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("config", ["cfg2", "cfg3"])
-def test_bench_json_contract(config):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "4", "--warmup", "1", "--transitions-per-step", "20",
-           "--chains", "4096", "--cpu-chains", "64", "--cpu-transitions", "24", "--ess", "40", "--repeats", "2"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+def _run_bench(extra, tmp_path, timeout=900):
+    detail = str(tmp_path / "detail.json")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--detail", detail] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout
-    d = json.loads(lines[0])
+    # what the driver does: the LAST line of stdout is the record, and it must fit its capture (round 4's 31.9 KB line did not)
+    assert res.stdout.strip().splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 6000, len(lines[0])
+    return json.loads(lines[0]), json.load(open(detail))
+
+
+def _check_headline(d, steps, warmup, chains, n_adapts, n_draws):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["steps"] == 4 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["steps"] == steps and d["warmup"] == warmup and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     c = d["config"]
-    assert "workload" in c and c["n_adapts"] == 40 and c["n_draws"] == 40 and len(c["runs"]) == 2
-    # value = leapfrogs of BOTH phases / the whole loop's wall time (adaptation inside the timed region)
-    total = (c["warmup_phase"]["mean_leapfrogs_per_transition"] * c["n_adapts"] + c["post_adaptation"]["mean_leapfrogs_per_transition"] * c["n_draws"]) * 4096
-    assert abs(d["ms_per_step"] * d["steps"] / 1e3 * d["value"] - total) < 1e-6 * total
+    assert "workload" in c and c["n_adapts"] == n_adapts and c["n_draws"] == n_draws
+    # value = leapfrogs of BOTH phases / the whole loop's wall time (adaptation inside the timed region); 6 significant digits in the line
+    total = (c["warmup_phase"]["mean_leapfrogs_per_transition"] * c["n_adapts"] + c["post_adaptation"]["mean_leapfrogs_per_transition"] * c["n_draws"]) * chains
+    assert abs(d["ms_per_step"] * d["steps"] / 1e3 * d["value"] - total) < 1e-4 * total
+    assert abs(c["leapfrogs"]["adapt"] + c["leapfrogs"]["draw"] - total) < 1e-4 * total
     assert c["post_adaptation"]["value"] > 0 and c["warmup_phase"]["value"] > 0
-    assert c["ess"] is not None and c["ess"]["ess_per_sec"] > 0
-    assert c["gathered_draws"] == c["n_draws"] * 4096
+    assert c["ess_per_sec"] > 0
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in r, k
     assert r["bound"] == "valu" and r["peak"] > 0
     if r["frac"] is not None:   # counters at HEAD present for this workload size only
-        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["frac"] <= 1.0
-    assert r["dominant"]["hbm_model_frac"] > 0 and r["dominant"]["avg_launch_ms"] > 0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["frac"] <= 1.0
+    assert r["dominant"]["hbm_model_frac"] > 0 and r["dominant"]["avg_launch_ms"] > 0 and r["dominant"]["launches"] > 0
     b = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in b, k
-    assert b["kind"] == "port" and b["value"] > 0 and b["single_thread"]["value"] > 0
+    assert b["kind"] == "port" and b["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["cfg2", "cfg3"])
+def test_bench_json_contract(config, tmp_path):
+    d, full = _run_bench(["--config", config, "--steps", "4", "--warmup", "1", "--transitions-per-step", "20", "--chains", "4096",
+                          "--cpu-chains", "64", "--cpu-transitions", "24", "--repeats", "2"], tmp_path)
+    _check_headline(d, 4, 1, 4096, 40, 40)
+    assert len(d["config"]["runs"]) == 2 and d["cpu_baseline"]["single_thread_value"] > 0
+    assert "secondary" not in d["config"]
+    # the side file holds the FULL record the line was made from
+    assert d["config"]["detail"] and full["value"] == pytest.approx(d["value"], rel=1e-5)
+    assert full["config"]["gathered_draws"] == 40 * 4096 and full["config"]["ess"]["ess_per_sec"] == pytest.approx(d["config"]["ess_per_sec"], rel=1e-5)
+    assert full["cpu_baseline"]["single_thread"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_default_invocation_line(tmp_path):
+    """What the driver runs — `python bench.py` with no --config — on reduced chains: ONE line under 6 000 characters that carries the
+    headline AND config.secondary.{cfg3, cfg5, cfg4}, each with value / ms_per_step / steps / workload / dtype / roofline / cpu_baseline.
+    (Round 4: this invocation was never tested, its line grew to 31.9 KB and the driver's 8 KB capture lost the headline.)"""
+    d, full = _run_bench(["--steps", "4", "--warmup", "1", "--transitions-per-step", "20", "--chains", "2048", "--cpu-chains", "64",
+                          "--cpu-transitions", "24", "--repeats", "1"], tmp_path, timeout=1500)
+    _check_headline(d, 4, 1, 2048, 40, 40)
+    sec = d["config"]["secondary"]
+    assert sorted(sec) == ["cfg3", "cfg4", "cfg5"]
+    for name, o in sec.items():
+        assert "error" not in o, (name, o)
+        for k in ("value", "ms_per_step", "steps", "workload", "dtype", "roofline", "cpu_baseline"):
+            assert k in o, (name, k)
+        assert o["value"] > 0 and o["dtype"] == "f64" and name in o["workload"]
+        for k in ("bound", "frac", "achieved", "peak", "traffic", "kernel"):
+            assert k in o["roofline"], (name, k)
+        assert o["roofline"]["bound"] == ("mfma" if name == "cfg4" else "valu")
+        assert o["cpu_baseline"]["value"] > 0 and o["cpu_baseline"]["kind"] == "port" and o["cpu_baseline"]["cores"] >= 1
+        assert o["ess_per_sec"] is not None and o["ess_per_sec"] > 0     # the second half of BASELINE's metric, every config
+        assert full["config"]["secondary"][name]["value"] == pytest.approx(o["value"], rel=1e-5)
+    assert sec["cfg4"]["roofline"]["achieved"] > 0
+
+
+def _stub_full_record():
+    """a full default-invocation record as bench.py builds it (round 4's own: the 31.9 KB one the driver could not hold)"""
+    return json.load(open(os.path.join(ROOT, "profiles", "r4_bench_default_line.json")))
+
+
+def test_default_line_stays_under_the_drivers_capture():
+    """compact_line on a full default-invocation record: < 6 000 characters, every key of the contract, the three secondary configs;
+    and a record that grew (longer texts, more runs) still comes out under the budget — the line sheds optional fields, never grows"""
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    bench = importlib.import_module("bench")
+    full = _stub_full_record()
+    assert len(json.dumps(full)) > 30000
+    d = bench.compact_line(full, "bench_detail.json")
+    line = json.dumps(d)
+    assert len(line) < 6000, len(line)
+    assert json.loads(line) == d
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == pytest.approx(full["value"], rel=1e-5) and d["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    for k in ("bound", "unit", "peak", "achieved", "frac", "traffic", "kernel", "valu_efficiency", "dominant", "other"):
+        assert k in d["roofline"], k
+    for which in ("dominant", "other"):
+        for k in ("launches", "avg_launch_ms", "leapfrogs_per_launch"):
+            assert k in d["roofline"][which], (which, k)
+    assert "valu_mix" not in line and "peak_definition" not in line
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert sorted(d["config"]["secondary"]) == ["cfg3", "cfg4", "cfg5"]
+    for name, o in d["config"]["secondary"].items():
+        for k in ("value", "ms_per_step", "steps", "workload", "dtype", "roofline", "cpu_baseline"):
+            assert k in o, (name, k)
+        for k in ("bound", "frac", "achieved", "peak", "traffic", "kernel"):
+            assert k in o["roofline"], (name, k)
+        for k in ("value", "cores", "kind"):
+            assert k in o["cpu_baseline"], (name, k)
+    assert d["config"]["detail"] == "bench_detail.json"
+    # a record that grew: the budget holds, the contract's keys stay
+    fat = _stub_full_record()
+    fat["config"]["runs"] = [fat["value"] * (1 + 1e-3 * i) for i in range(50)]
+    fat["config"]["workload"] *= 8
+    fat["cpu_baseline"]["sample"] *= 8
+    fat["roofline"]["kernel"] *= 20
+    for o in fat["config"]["secondary"].values():
+        o["config"]["workload"] = o["config"]["workload"] * 6
+        o["roofline"]["kernel"] = o["roofline"]["kernel"] * 10
+    d2 = bench.compact_line(fat, "bench_detail.json")
+    assert len(json.dumps(d2)) <= bench.LINE_BUDGET
+    assert d2["value"] == d["value"] and sorted(d2["config"]["secondary"]) == ["cfg3", "cfg4", "cfg5"] and d2["roofline"]["frac"] == d["roofline"]["frac"]
+    # a secondary config that failed is an error entry, not a lost line
+    fat["config"]["secondary"]["cfg5"] = {"error": "RuntimeError('out of memory')" * 30}
+    d3 = bench.compact_line(fat, None)
+    assert "error" in d3["config"]["secondary"]["cfg5"] and len(json.dumps(d3)) <= bench.LINE_BUDGET
 
 
 def test_counters_are_refused_when_taken_on_other_kernels(tmp_path, monkeypatch):
