@@ -988,7 +988,8 @@ def test_full_size_slice_against_oracle(hip, oracle, cfg, offset):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("engine,metric", [("step", "identity"), ("step", "spd"), ("epoch", "identity"), ("epoch", "spd"), ("epoch_full_shard", "spd")])
+@pytest.mark.parametrize("engine,metric", [("step", "identity"), ("step", "spd"), ("epoch", "identity"), ("epoch", "spd"), ("epoch_full_shard", "spd"),
+                                           ("epoch_slice", "spd"), ("epoch_d256", "spd"), ("epoch_d256_slice", "identity")])
 def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     """BASELINE configs[3] at its own shape: D = 512, Σᵢⱼ = 0.9^|i−j| as a dense Gaussian target (ℓπ = −½θᵀΣ⁻¹θ, the gradient
     a GEMM), shared DenseEuclideanMetric (`identity` = cfg4's initial M⁻¹ = I; `spd` = a well-conditioned full matrix, so the
@@ -1000,14 +1001,20 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     chains and is held to the bar: identical discrete decisions on ≥ 99.9 % of them (i.e. all 128), 1e-8 on θ, r, ∇ℓπ.
     `engine`: "step" = the step-synchronous kernels (`k_dgemm` → `k_d_tree2` per global step); "epoch" = round 4's chain-complete
     `k_dense_epoch` (what the bench runs at 8 192 chains; here its threshold is lowered so that 1 152 chains per pipeline take it);
-    "epoch_full_shard" = cfg4's own 8 192 chains per GPU with the engine's defaults, exactly the bench's pipeline."""
+    "epoch_full_shard" = cfg4's own 8 192 chains per GPU with the engine's defaults, exactly the bench's pipeline;
+    "epoch_slice" = `k_dense_epoch` with SliceTS (src/trajectory.jl:144-150,178-189,500-502) and "epoch_d256(_slice)" = its D = 256
+    instantiation — round 5: both were HIP == HIP only (test_dense_epoch_kernel_equals_step_synchronous_kernels), now against the oracle."""
+    sampler = A.SliceTS if engine.endswith("_slice") else A.MultinomialTS
+    D = 256 if "_d256" in engine else 512
+    if engine.startswith("epoch_") and engine != "epoch_full_shard":
+        engine = "epoch"
     if engine == "epoch_full_shard":
         monkeypatch.delenv("AHMC_DENSE_EPOCH", raising=False)
         monkeypatch.delenv("AHMC_DENSE_EPOCH_MIN", raising=False)
     else:
         monkeypatch.setenv("AHMC_DENSE_EPOCH", "1" if engine == "epoch" else "0")
         monkeypatch.setenv("AHMC_DENSE_EPOCH_MIN", "32")
-    D, N, n = 512, (8192 if engine == "epoch_full_shard" else 2304), 64
+    N, n = (8192 if engine == "epoch_full_shard" else 2304), 64
     idx = np.arange(D)
     Sigma = 0.9 ** np.abs(idx[:, None] - idx[None, :])
     P = np.asfortranarray(np.linalg.inv(Sigma))
@@ -1022,7 +1029,7 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     th0 = np.asfortranarray(rs.normal(size=(D, N)))
     eps0 = 0.12 * (0.7 + 0.6 * rs.random(N))
     lf = A.Leapfrog(eps0)
-    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+    k = A.HMCKernel(A.Trajectory(sampler, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
     g = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), target), N, rng=A.PhiloxRNG(77), lib=hip)
     g.set_integrator(lf)
     g.set_position(th0)

@@ -108,7 +108,7 @@ def test_bench_pipeline_against_oracle_in_chunks(hip, oracle, D, target, N, geom
     for e in (g, o):
         e.adaptor_init(ad)
     floor = (N - 2) / N if N <= 128 else 0.97       # at most 2 chains (3 %) flip a decision somewhere in a chunk
-    worst, n_div, max_depth, n_stable_checked = 1.0, 0, 0, 0
+    worst, n_div, max_depth, n_stable_checked, n_short_div = 1.0, 0, 0, 0, 0
     # Chunks: ONE iteration each through the warm-up, five for the draws.  From θ0 ~ U(0,1) the first iterations integrate
     # with step sizes that are still far too large (and again after each dual-averaging restart) — energy errors of 10³ … 10⁶⁹, hundreds of leapfrogs per tree: such a
     # trajectory is numerically unstable (that is what the divergence test detects), a last-bit difference between the two
@@ -128,9 +128,18 @@ def test_bench_pipeline_against_oracle_in_chunks(hip, oracle, D, target, N, geom
         assert sg["adaptor"] == so["adaptor"]
         on = np.isclose(sg["theta"], so["theta"], rtol=1e-7, atol=1e-7).all(axis=0)
         if lo == hi:
-            stable = np.abs(o.stats()["max_hamiltonian_energy_error"]) < 2.0
+            # Round 5: no iteration passes unchecked.  A transition is comparable when it was stable on the oracle (|ΔH|_max < 2) OR SHORT
+            # (≤ 8 leapfrogs: the first iterations and the one after each dual-averaging restart diverge on the first or third leaf —
+            # nothing has had the time to amplify a rounding, and a divergent first leaf must come out as n_steps = 1, θ unchanged, on
+            # both sides).  By the oracle every iteration of the three pipelines has ≥ 15 such chains (iterations 1–3 and 56: all of them
+            # short and divergent; iteration 4: 15 / 29 / 509); fewer than 8 is a failure, not a pass.
+            sto1 = o.stats()
+            stable = (np.abs(sto1["max_hamiltonian_energy_error"]) < 2.0) | (sto1["n_steps"] <= 8)
             n_stable_checked += int(stable.sum())
-            assert on[stable].mean() >= floor if stable.sum() >= 8 else True, (lo, on[stable].mean(), int(stable.sum()))
+            assert stable.sum() >= 8, (lo, int(stable.sum()))
+            allowed = max(2, int(np.ceil((1.0 - floor) * stable.sum())))       # at most 2 chains (3 %) flip a decision
+            assert int((~on[stable]).sum()) <= allowed, (lo, int((~on[stable]).sum()), int(stable.sum()))
+            n_short_div += int(((sto1["n_steps"] <= 8) & (sto1["numerical_error"] != 0)).sum())
         else:
             worst = min(worst, on.mean())
             assert on.mean() >= floor, (lo, hi, on.mean())
@@ -166,7 +175,8 @@ def test_bench_pipeline_against_oracle_in_chunks(hip, oracle, D, target, N, geom
     st = o.get_state()
     assert st["adaptor"]["adapting"] == 0 and st["adaptor"]["iteration"] == n_total
     assert max_depth >= 4, max_depth            # real trees: merges on several pending levels
-    assert n_stable_checked >= 4 * N, n_stable_checked   # the one-iteration chunks did compare stable transitions
+    assert n_stable_checked >= 40 * N, n_stable_checked   # the one-iteration chunks compared most chains at most iterations
+    assert n_short_div >= N, n_short_div                 # … among them the short divergent transitions of the first iterations
     if target == "funnel":
         assert n_div > 0, "the funnel's warm-up must contain divergent transitions"
     g.close(); o.close()
