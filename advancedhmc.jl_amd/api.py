@@ -212,6 +212,19 @@ class PluginTarget:
 
 
 @dataclass
+class ObjectTarget:
+    """User log-density as COMPILED device code — a relocatable object of `hipcc -fgpu-rdc -c` or raw amdgcn LLVM bitcode (`.bc`,
+    what GPUCompiler.jl / AMDGPU.jl emit for a Julia function) that defines the C symbol of include/ahmc_user_target_object.h.
+    `build_target_plugin_from_object` links it with the engine's trajectory kernels (device LTO: a bitcode density is inlined
+    into the leaf loop) and the result is bound like a PluginTarget (ahmc_set_target_plugin): the fused kernels incl. the
+    in-kernel warm-up, no host round trip, no per-leapfrog launch.  HIP engine only."""
+    D: int
+    object: str
+    params: Optional[np.ndarray] = None
+    kind: int = capi.TARGET_PLUGIN
+
+
+@dataclass
 class KernelTarget:
     """User log-density as a device KERNEL the engine launches itself (ahmc_set_target_kernel): `handle` is a hipFunction_t
     (handle_kind = capi.KERNEL_HIP_FUNCTION; what hipModuleGetFunction returns / AMDGPU.jl compiles a Julia kernel to), the
@@ -532,6 +545,13 @@ class Engine:
             from .build import build_target_plugin
 
             so = build_target_plugin(target.source, self.dtype, self.info("group_lanes"), self.info("elems_per_lane"))
+            self._call("ahmc_set_target_plugin", so.encode(), capi.as_ptr(p), 0 if p is None else p.size)
+            return
+        if isinstance(target, ObjectTarget):
+            from .build import build_target_plugin_from_object
+
+            so = build_target_plugin_from_object(target.object, self.dtype, self.info("group_lanes"), self.info("elems_per_lane"),
+                                                 n_params=-1 if p is None else p.size)
             self._call("ahmc_set_target_plugin", so.encode(), capi.as_ptr(p), 0 if p is None else p.size)
             return
         if isinstance(target, KernelTarget):

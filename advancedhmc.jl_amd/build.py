@@ -293,6 +293,109 @@ def build_target_plugin(source: str, dtype, G: int, E: int, n_params: int = -1, 
     return out
 
 
+def build_device_object(source: str, bitcode: bool = False, force: bool = False) -> str:
+    """Compile a file that DEFINES `ahmc_user_logdensity_f64 / _f32` (include/ahmc_user_target_object.h) to what a user without
+    the engine's headers would hand over: a relocatable device object (`hipcc -fgpu-rdc -c`, host ELF + bundled device
+    bitcode) or — `bitcode=True` — raw device LLVM bitcode for amdgcn-amd-amdhsa (the form GPUCompiler.jl / AMDGPU.jl emit for a
+    Julia function).  For tests and as the recipe INTEGRATION.md quotes; cached outside the repository by content."""
+    source = os.path.abspath(source)
+    h = hashlib.sha256(_include_closure(source, (INCLUDE,)) + (b"bc" if bitcode else b"o") + " ".join(FLAGS).encode()).hexdigest()[:20]
+    out_dir = os.path.join(OBJ, "objects")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"{os.path.splitext(os.path.basename(source))[0]}_{h}.{'bc' if bitcode else 'o'}")
+    if os.path.exists(out) and not force:
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    flags = [f for f in FLAGS if f != "-fno-gpu-rdc"] + ["-fgpu-rdc"]
+    cmd = [hipcc, *flags, "-I", INCLUDE, "-c", source, "-o", out + ".tmp"] + (["--cuda-device-only", "-emit-llvm"] if bitcode else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {source}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_target_plugin_from_object(obj: str, dtype, G: int, E: int, n_params: int = -1, force: bool = False, verbose: bool = False) -> str:
+    """A user log-density that exists only as COMPILED device code (include/ahmc_user_target_object.h: one C symbol,
+    `ahmc_user_logdensity_f64 / _f32`) → a target plugin for `ahmc_set_target_plugin`: the engine's trajectory kernels are
+    compiled under -fgpu-rdc with the symbol as their log-density family (TK = 4) and LINKED with the object; the device link
+    runs LTO over both, so a bitcode object is inlined into the leaf loop like a header plugin's function.
+
+    `obj`: a relocatable object of `hipcc -fgpu-rdc -c` (host ELF with bundled device bitcode), or raw device bitcode / IR
+    for amdgcn-amd-amdhsa (`.bc` / `.ll`: what GPUCompiler.jl emits) — wrapped with an empty host object by
+    clang-offload-bundler.  Returns the plugin's path; `<path>.json` says whether the density was inlined (no call left in the
+    kernels).  Cached by the object's content, the engine's kernel sources, flags, dtype and geometry; ISA-scanned."""
+    import json
+
+    import numpy as np
+
+    obj = os.path.abspath(obj)
+    if not os.path.exists(obj):
+        raise FileNotFoundError(obj)
+    tname = {"float32": "float", "float64": "double"}[np.dtype(dtype).name]
+    kd = source_digest()
+    shim = os.path.join(INCLUDE, "ahmc_user_target_object.h")
+    h = hashlib.sha256()
+    for part in (open(obj, "rb").read(), open(shim, "rb").read(), kd.encode(), tname.encode(), f"obj,{G},{E},{n_params}".encode(), " ".join(FLAGS).encode(),
+                 open(os.path.join(CSRC, "ahmc_kernels.hpp"), "rb").read(), open(os.path.join(CSRC, "ahmc_inst.hpp"), "rb").read()):
+        h.update(part)
+    out_dir = os.path.join(OBJ, "plugins")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"libahmc_target_obj_{h.hexdigest()[:20]}.so")
+    if os.path.exists(out) and os.path.exists(out + ".json") and not force:
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: a target plugin is linked from the engine's kernel sources")
+    llvm = isa_check.LLVM
+    tmp = out + f".tmp{os.getpid()}"
+    work = []
+
+    def run(cmd, what):
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            for f in work:
+                if os.path.exists(f):
+                    os.remove(f)
+            raise RuntimeError(f"{what} failed for the target object {obj}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+
+    user_o = obj
+    if obj.endswith((".bc", ".ll")):
+        # raw device bitcode: bundle it with an empty host object, as `hipcc -fgpu-rdc -c` would have
+        host_c, host_o, user_o = tmp + ".host.c", tmp + ".host.o", tmp + ".user.o"
+        work += [host_c, host_o, user_o]
+        open(host_c, "w").write("\n")
+        run([f"{llvm}/clang", "-c", "-fPIC", host_c, "-o", host_o], "compiling the empty host half")
+        run([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=host-x86_64-unknown-linux-gnu,hip-amdgcn-amd-amdhsa--gfx950",
+             f"--input={host_o}", f"--input={obj}", f"--output={user_o}"], "bundling the device bitcode")
+    rdc = [f for f in FLAGS if f != "-fno-gpu-rdc"] + ["-fgpu-rdc"]
+    inst_o = tmp + ".inst.o"
+    work.append(inst_o)
+    run([hipcc, *rdc, f"-DAHMC_INST_T={tname}", "-DAHMC_INST_TK=4", f"-DAHMC_PLUGIN_G={int(G)}", f"-DAHMC_PLUGIN_E={int(E)}",
+         f"-DAHMC_PLUGIN_NPARAMS={int(n_params)}", "-DAHMC_USER_TARGET_FROM_OBJECT=1", f'-DAHMC_USER_TARGET_HEADER="{shim}"',
+         f'-DAHMC_SOURCES_DIGEST="{kd}"', "-I", INCLUDE, "-c", os.path.join(CSRC, "ahmc_inst.hip"), "-o", inst_o], "compiling the engine's kernels (-fgpu-rdc)")
+    run([hipcc, "--offload-arch=gfx950", "-fgpu-rdc", "--hip-link", "-shared", "-fPIC", inst_o, user_o, "-o", tmp], "the device link")
+    for f in work:
+        if os.path.exists(f):
+            os.remove(f)
+    inlined = None
+    if isa_check.available():
+        import tempfile
+
+        with tempfile.TemporaryDirectory(prefix="ahmc_isa_") as td:
+            text = isa_check.disassemble(tmp, td)
+        inlined = ("s_swappc_b64" not in text) and ("ahmc_user_logdensity" not in text)
+        if not os.environ.get("AHMC_SKIP_ISA_CHECK") and isa_check.check_object(tmp, os.path.basename(obj)):
+            os.remove(tmp)
+            raise RuntimeError(f"{obj}: the linked plugin holds a spill stored under a narrowed exec mask (isa_check.py); discarded")
+    os.replace(tmp, out)
+    with open(out + ".json", "w") as f:
+        json.dump({"object": obj, "dtype": tname, "G": int(G), "E": int(E), "inlined": inlined}, f)
+    if verbose:
+        print("built target plugin", out, "(density inlined)" if inlined else "(density CALLED per leapfrog: no bitcode in the object?)")
+    return out
+
+
 def build_code_object(source: str, force: bool = False) -> str:
     """hipcc --genco of a file of user KERNELS (ahmc_set_target_kernel) → a gfx950 code object for hipModuleLoad; cached
     outside the repository by content."""

@@ -498,7 +498,7 @@ int launch_nuts(Ctx<T>* c, KP<T> p, int max_depth) {
   static int tl_launch = 0;
   unsigned long long* tl_buf = nullptr;
   const char* tl_path = getenv("AHMC_WAVE_TIMELINE_OUT");
-  const size_t tl_words = (size_t)p.n_chunks * 8;
+  const size_t tl_words = (size_t)p.n_chunks * AHMC_TL_WORDS;
   p.hmc_H = nullptr;
   if (tl_path && (MODE == 0 || MODE == 3)) {
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&tl_buf), tl_words * 8));

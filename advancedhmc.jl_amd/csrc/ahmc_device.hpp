@@ -175,10 +175,19 @@ static __device__ const unsigned long long EXP2_64_BITS[64] = {
     0x3ffc199bdd85529cULL, 0x3ffc67f12e57d14bULL, 0x3ffcb720dcef9069ULL, 0x3ffd072d4a07897cULL,
     0x3ffd5818dcfba487ULL, 0x3ffda9e603db3285ULL, 0x3ffdfc97337b9b5fULL, 0x3ffe502ee78b3ff6ULL,
     0x3ffea4afa2a490daULL, 0x3ffefa1bee615a27ULL, 0x3fff50765b6e4540ULL, 0x3fffa7c1819e90d8ULL};
+#ifndef AHMC_LEAF_EXP_NARROW_TABLE
+// Chains that SHARE a wave (G < 64): the table entry is a per-lane GLOBAL load in the middle of the leaf's chain of dependent stages — and
+// its s_waitcnt vmcnt(0) also waits for every slot store still in flight.  Round 5, stage stamps of a measurement build
+// (profiles/r5_leaf_latency_cfg3.json): the weight stage took 1 112 of a lone wave's 2 905 cycles per leaf step on cfg3 (1 830 of 4 023 at
+// the bench's occupancy) against 310 of 1 571 on cfg2, where the entry is a scalar load.  0: those kernels evaluate the Horner-11 form
+// (no memory access: 9 more VALU, ≈ 700 fewer cycles); 1: the table for every geometry (rounds 3–4).
+#define AHMC_LEAF_EXP_NARROW_TABLE 0
+#endif
 template <bool UNIFORM>
 __device__ __forceinline__ double leaf_weight_exp(double x) {
   constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
 #if AHMC_LEAF_EXP == 2
+  if constexpr (UNIFORM || AHMC_LEAF_EXP_NARROW_TABLE) {
   // (clamped first: ℓw = −Inf is a routine input — every divergent leaf — and a float-to-int conversion of ±Inf is undefined
   // behaviour, however the hardware's v_cvt_i32_f64 saturates; the final select still returns 0 below −1075)
   const double xc = x < -1100.0 ? -1100.0 : x;
@@ -196,9 +205,12 @@ __device__ __forceinline__ double leaf_weight_exp(double x) {
   double z = __builtin_ldexp(__builtin_fma(tj, q, tj), k >> 6);
   z = x < -1075.0 ? 0.0 : z;                                                // (incl. x = −Inf; a NaN x fails the compare and propagates)
   return z;
-#else
-  const double dn = __builtin_rint(x * C(0x3ff71547652b82feULL));                 // x·log2(e)
-  double t = __builtin_fma(dn, C(0xbfe62e42fefa39efULL), x);                      // − n·ln2 (high part)
+  }
+#endif
+  {
+  const double xh = x < -1100.0 ? -1100.0 : x;                                    // (as above: −Inf is a routine input; the final select returns 0 for it)
+  const double dn = __builtin_rint(xh * C(0x3ff71547652b82feULL));                // x·log2(e)
+  double t = __builtin_fma(dn, C(0xbfe62e42fefa39efULL), xh);                     // − n·ln2 (high part)
   t = __builtin_fma(dn, C(0xbc7abc9e3b39803fULL), t);                             // − n·ln2 (low part)
   double q = __builtin_fma(t, C(0x3e5ade156a5dcb37ULL), C(0x3e928af3fca7ab0cULL));
   q = fma3(t, q, C(0x3ec71dee623fde64ULL));
@@ -217,7 +229,7 @@ __device__ __forceinline__ double leaf_weight_exp(double x) {
 #endif
   z = x < -1075.0 ? 0.0 : z;
   return z;
-#endif
+  }
 }
 template <bool UNIFORM>
 __device__ __forceinline__ float leaf_weight_exp(float x) { return exp(x); }

@@ -38,6 +38,32 @@
 #define AHMC_RUNNING_STATS 1
 #endif
 
+// AHMC_LEAF_PROF (measurement build only, scripts/leaf_latency.py; implies the per-wave timeline record): where a leaf step's cycles go.
+// Every wave reads the shader-clock counter (s_memtime) at the stage boundaries of the leaf loop — fenced by scheduling barriers, so no
+// instruction moves across a stamp — and sums the differences per stage: [0] leapfrog vector work (half-steps, density and its
+// gradient), [1] the energy all-reduce, [2] leaf weight / exp, divergence test, running statistics, [3] merges (operand loads, dot
+// products, their all-reduce, RNG, selects), [4] parking a finished subtree + loop control, [5] the top level of a doubling (direction,
+// edge swap, whole-tree U-turn test), [6] transition prologue, [7] epilogue (re-integration to the candidate, stores, adapt!); counts:
+// [8] leaf steps, [9] merges, [10] doublings, [11] transitions.  A stamp costs an s_memtime + s_waitcnt lgkmcnt(0): the build is for
+// attribution, not for throughput numbers.
+#ifndef AHMC_LEAF_PROF
+#define AHMC_LEAF_PROF 0
+#endif
+#if AHMC_LEAF_PROF
+#undef AHMC_WAVE_TIMELINE
+#define AHMC_WAVE_TIMELINE 1
+#define AHMC_TL_WORDS 24
+// (32-bit sums, kept scalar through readfirstlane: a launch stays far below 2^32 cycles per stage and wave)
+#define AHMC_LP_TICK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned n_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_readcyclecounter()); __builtin_amdgcn_sched_barrier(0); lp_t[i] += n_ - lp_c; lp_c = n_; }
+#define AHMC_LP_COUNT(i, n) { lp_t[i] += (unsigned)(n); }
+#else
+#define AHMC_LP_TICK(i)
+#define AHMC_LP_COUNT(i, n)
+#endif
+#ifndef AHMC_TL_WORDS
+#define AHMC_TL_WORDS 8
+#endif
+
 #include <type_traits>
 
 #include "ahmc_kernels.hpp"
@@ -347,6 +373,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   const unsigned long long tl_t0 = wall_clock64();
   unsigned long long tl_steps = 0, tl_alive = 0, tl_re = 0, tl_trans = 0;
 #endif
+#if AHMC_LEAF_PROF
+  unsigned lp_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned lp_c = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_readcyclecounter());
+#endif
   for (int kt = 0; kt < p.n_trans; ++kt) {
     // Make the per-lane indices opaque once per transition: otherwise every address and every
     // constant derived from them is loop-invariant w.r.t. this loop, gets hoisted out of it and
@@ -402,8 +432,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     // the transition, so that the deep trees every launch waits for would step faster: cfg3 2.47 / 2.52 / 2.56e9 against 2.49e9
     // without, cfg2 and cfg5 unchanged — within the run-to-run spread.  A lone deep tree is bound by the latency of its own chain of
     // dependent reductions, not by the issue slots it shares.)
+    AHMC_LP_TICK(6)
     for (int jw = 0; jw < p.max_depth; ++jw) {  // doubling loop (:691-723), wave-uniform
       if (!AHMC_ANY(!done)) break;
+      AHMC_LP_COUNT(10, 1)
       // ---- direction (:693) and edge selection ----
       bool vleft = false;
       if (!done) vleft = AHMC_UNI(ds.boolean());
@@ -437,8 +469,10 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       T A_c[E], RF_c[E];
       T w_c = 0, sa_c = 0, dh_c = 0;
       int na_c = 0, ck_c = 0;
+      AHMC_LP_TICK(5)
       for (uint32_t leaf = 1; leaf <= nleaf; ++leaf) {
         if (!AHMC_ANY(alive)) break;
+        AHMC_LP_COUNT(8, 1)
 #if AHMC_WAVE_TIMELINE
         tl_steps += 1;
         tl_alive += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive && lane == 0));
@@ -476,8 +510,32 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             leapfrog_step<T, G, E, TK, false>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
             ne_leaf = cur.lp + cur.lk;
           } else {
+#if AHMC_LEAF_PROF
+            {
+              const T e_ = v > 0 ? eps : -eps, eh_ = e_ / 2;
+#pragma unroll
+              for (int e = 0; e < E; ++e) cur.r[e] = cur.r[e] - eh_ * cur.g[e];
+#pragma unroll
+              for (int e = 0; e < E; ++e) cur.th[e] = cur.th[e] + e_ * (minv[e] * cur.r[e]);
+              const T part_ = target_eval<T, G, E, TK>(p.tp, cur.th, cur.g, lane, d0);
+#pragma unroll
+              for (int e = 0; e < E; ++e) cur.r[e] = cur.r[e] - eh_ * cur.g[e];
+              const T kin_ = kinetic_partial(cur.r, minv);
+              T sv_[1] = {part_ - kin_ / 2};
+              asm volatile("" : "+v"(sv_[0]));   // the partial is complete before the stamp
+              AHMC_LP_TICK(0)
+              leapfrog_allsum<G, TK>(sv_);
+              asm volatile("" : "+v"(sv_[0]));
+              AHMC_LP_TICK(1)
+              ne_leaf = is_finite(sv_[0]) ? sv_[0] : -Lim<T>::inf();
+            }
+#else
             ne_leaf = leapfrog_step_ne<T, G, E, TK>(cur, minv, v > 0 ? eps : -eps, p.tp, lane, d0);
+#endif
           }
+#if AHMC_LEAF_PROF
+          if (GENERAL || G > 64) AHMC_LP_TICK(0)   // (the other leaf forms: the whole leapfrog incl. its reduction under [0])
+#endif
           pos_cur += v;
           const T ne = (GENERAL || (FUSE_M0 && nm > 0)) ? cur.lp + cur.lk : ne_leaf;  // neg_energy(z′)
           const T dH = -ne - H0;
@@ -525,6 +583,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             copy_vec(RF_c, cur.r);
           }
         }
+        AHMC_LP_TICK(2)
         // A_in / RF_in: ρ (Classic: θ of the first-built leaf) and first-built r of the half just completed;
         // pre: the first merge of a fast kernel — A_c, the dot products and RF_p were made with the leaf (above)
         auto merge_level = [&](const int lvl, const T (&A_in)[E], const T (&RF_in)[E], auto pre) {
@@ -613,6 +672,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             }
             if constexpr (pre.value) copy_vec(RF_c, RF_m0); else copy_vec(RF_c, RF_p);
             merged = lvl + 1;
+            AHMC_LP_COUNT(9, 1)
           }
         };
         if constexpr (GENERAL) {
@@ -639,6 +699,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             }
           }
         }
+        AHMC_LP_TICK(3)
         if (alive && sub_term) {
           // enclosing unfinished subtrees still absorb the statistics of their first halves
           // (tree′ = combine(treeleft, treeright) at every level that is a second half, :666)
@@ -671,6 +732,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #endif
           S_CK(nm) = ck_c;
         }
+        AHMC_LP_TICK(4)
       }
       // ---- top level of the doubling loop (:708-722) ----
       if constexpr (!GENERAL) {
@@ -751,6 +813,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         }
         if (sub_term || turn) done = true;
       }
+      AHMC_LP_TICK(5)
     }
 
     // ---- Transition(zcand, stats) (:725-741): re-integrate from z0 to the candidate leaf ----
@@ -876,10 +939,20 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #if AHMC_WAVE_TIMELINE
     tl_trans += 1;
 #endif
+    AHMC_LP_TICK(7)
+    AHMC_LP_COUNT(11, 1)
   }  // transitions of this launch
 #if AHMC_WAVE_TIMELINE
   if (p.hmc_H && lane64 == 0) {  // (the static-HMC energy buffer is not used by NUTS: the measurement build borrows the field)
-    unsigned long long* tl = reinterpret_cast<unsigned long long*>(p.hmc_H) + (size_t)chunk * 8;
+    // (the chunk index recomputed here: carried from the top it is one more value live across the whole kernel, and the register
+    // allocator parked it in scratch under the `chunk < n_chunks` mask — harmless there, but isa_check refuses the pattern)
+    unsigned int tid_tl = threadIdx.x;
+    asm volatile("" : "+v"(tid_tl));   // (opaque: otherwise the expression is the one at the top and its value is carried after all)
+    const unsigned int chunk_tl = G > 64 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (tid_tl >> 6);
+    unsigned long long* tl = reinterpret_cast<unsigned long long*>(p.hmc_H) + (size_t)chunk_tl * AHMC_TL_WORDS;
+#if AHMC_LEAF_PROF
+    for (int i = 0; i < 12; ++i) tl[8 + i] = (unsigned long long)lp_t[i];
+#endif
     tl[0] = tl_t0; tl[1] = wall_clock64(); tl[2] = tl_steps; tl[3] = tl_alive; tl[4] = tl_re; tl[5] = tl_trans;
     tl[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     tl[7] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID

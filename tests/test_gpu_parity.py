@@ -949,6 +949,53 @@ def test_cfg2_pipeline_against_oracle(hip, oracle):
     g.close(); o.close()
 
 
+def test_cfg2_pipeline_against_oracle_f32(hip, oracle):
+    """The cfg2 pipeline in Float32 (the element type of the reference's own GPU smoke test, test/CUDA/cuda.jl:18) against the Float32
+    oracle: fused warm-up (adapt! inside k_nuts<float,32,4,3,0> … the f32 geometry of D = 128) through a whole Stan schedule —
+    init buffer 9, window splits at 24 and 54 with metric update + dual-averaging restart, term buffer, finalize! at 60 — and the first
+    draws, ONE iteration per chunk from the oracle's complete state: in single precision a rounding is 1e-7 and dual averaging doubles
+    it every iteration, so only the single transition + adapt! is held to the Float32 bar of this file (2e-3, ≥ 90 % of the chains on
+    identical discrete decisions), every iteration of the schedule."""
+    D, N, n_adapts, n_total = 128, 256, 60, 66
+    metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.1))
+    k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+    th0 = np.asfortranarray(np.random.default_rng(2).random((D, N)))
+    g, o = pair(hip, oracle, h, N, np.float32, seed=0x5EED0002, lf=lf)
+    for e in (g, o):
+        e.set_position(th0)
+    eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
+    assert (eg == eo).mean() >= 0.9
+    g.set_integrator(A.Leapfrog(eo))
+    ad = A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf), init_buffer=9, term_buffer=6, window_size=15)
+    for e in (g, o):
+        e.adaptor_init(ad)
+    worst, updated = 1.0, False
+    for i in range(1, n_total + 1):
+        g.set_state(o.get_state())
+        for e in (g, o):
+            e.run(k, i, n_adapts, i_first=i)
+        sg, so = g.get_state(), o.get_state()
+        assert sg["adaptor"] == so["adaptor"]
+        stg, sto = g.stats(), o.stats()
+        same = (stg["n_steps"] == sto["n_steps"]) & (stg["tree_depth"] == sto["tree_depth"]) & (stg["numerical_error"] == sto["numerical_error"])
+        on = same & np.isclose(sg["theta"], so["theta"], rtol=2e-3, atol=2e-3).all(axis=0)
+        worst = min(worst, on.mean())
+        assert on.mean() >= 0.90, (i, on.mean())
+        np.testing.assert_allclose(stg["hamiltonian_energy"][on], sto["hamiltonian_energy"][on], rtol=2e-3, err_msg=f"H at iteration {i}")
+        np.testing.assert_allclose(stg["acceptance_rate"][on], sto["acceptance_rate"][on], rtol=2e-2, atol=2e-3, err_msg=f"α at iteration {i}")
+        np.testing.assert_allclose(sg["stepsize"][on], so["stepsize"][on], rtol=5e-3, err_msg=f"ϵ after adapt! {i}")
+        np.testing.assert_allclose(sg["metric"][:, on], so["metric"][:, on], rtol=5e-3, atol=1e-5, err_msg=f"M⁻¹ after adapt! {i}")
+        if sg["welford"] is not None:
+            np.testing.assert_allclose(sg["welford"][:, on, :], so["welford"][:, on, :], rtol=5e-3, atol=5e-3, err_msg=f"Welford after {i}")
+        updated = updated or not np.allclose(so["metric"], 1.0)
+    st = o.get_state()
+    assert st["adaptor"]["adapting"] == 0 and st["adaptor"]["iteration"] == n_total and updated
+    assert 0.3 < np.median(st["stepsize"]) < 0.9, np.median(st["stepsize"])
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("cfg,offset", [("cfg2", 0), ("cfg2", 30000), ("cfg2", 65536 - 256), ("cfg3", 0), ("cfg3", 41000), ("cfg3", 65536 - 256)])
 def test_full_size_slice_against_oracle(hip, oracle, cfg, offset):
     """cfg2 (65 536 chains × D = 128 iso Gaussian) and cfg3 (65 536 × D = 32 Neal's funnel, 4 chains per wave in lockstep,
@@ -986,6 +1033,54 @@ def test_full_size_slice_against_oracle(hip, oracle, cfg, offset):
     if cfg == "cfg3":
         assert ao["n_divergent"] > 0, "the funnel slice must contain divergent transitions"
     g.close(); o.close()
+
+
+def test_cfg5_full_size_slices_against_oracle(hip, oracle):
+    """cfg5 at FULL size — 32 768 chains × D = 2 048 hierarchical Gaussian, one chain across the 4 wavefronts of a workgroup
+    (k_nuts<double,256,8,·,3>), per-chain M⁻¹ and ϵ, 4 transitions in ONE launch dispatched in ascending-ϵ order, 512 MiB per (D, N)
+    array, per-wave global scratch for the pending levels ≥ 3 — and 32 of its chains replayed by the oracle at three offsets (first,
+    middle, last workgroups of the grid) with the same global Philox stream (src/trajectory.jl:626-742 at D = 2 048).  Round 2's silent
+    bug was a size / instantiation effect: the chains of the full launch must be the chains of a small one, decision for decision.
+    Step sizes ≈ 0.02 from θ0 ~ N(0, I): trees from one leaf to 512 leaves, divergent transitions among them."""
+    N, n, D = 32768, 32, 2048
+    rs = np.random.default_rng(11)
+    minv = np.asfortranarray(0.5 + rs.random((D, N)))
+    eps = 0.02 * (0.6 + 0.8 * rs.random(N))
+    th0 = np.asfortranarray(rs.normal(size=(D, N)))
+    target = A.HierGaussian(D)
+    k_of = lambda e: A.HMCKernel(A.Trajectory(A.MultinomialTS, A.Leapfrog(e), A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))  # noqa: E731
+    g = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(minv), target), N, rng=A.PhiloxRNG(42), lib=hip)
+    assert hip.backend != "hip:gfx950" or (g.info("group_lanes"), g.info("elems_per_lane")) == (256, 8)
+    g.set_integrator(A.Leapfrog(eps))
+    g.set_position(th0)
+    g.run(k_of(eps), 4)
+    sg, zg, ag = g.stats(), g.phasepoint(), g.accum()
+    g.close()
+    depth_max, n_div, n_on = 0, 0, 0
+    for offset in (0, 17000, N - n):
+        sl = slice(offset, offset + n)
+        o = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(np.asfortranarray(minv[:, sl])), target), n,
+                     rng=A.PhiloxRNG(42, chain_offset=offset), lib=oracle)
+        o.set_integrator(A.Leapfrog(eps[sl]))
+        o.set_position(th0[:, sl])
+        o.run(k_of(eps[sl]), 4)
+        so, zo, ao = o.stats(), o.phasepoint(), o.accum()
+        o.close()
+        same = (sg["n_steps"][sl] == so["n_steps"]) & (sg["tree_depth"][sl] == so["tree_depth"])
+        on = np.isclose(zg.theta[:, sl], zo.theta, rtol=1e-8, atol=1e-8).all(axis=0)
+        assert on.sum() >= n - 2, (offset, int(on.sum()))      # 4 free-running transitions of up to 512 leaves: a flipped decision stays flipped
+        assert (same | ~on).all(), offset
+        np.testing.assert_allclose(sg["hamiltonian_energy"][sl][on], so["hamiltonian_energy"][on], rtol=1e-9)
+        # (α = mean of exp(min(0, −ΔH)) over up to 512 leaves with |H| ≈ 10⁴: the rounding of ΔH after four free-running transitions
+        # shows at 1e-6 relative — the bar of tests/test_pipeline_parity.py)
+        np.testing.assert_allclose(sg["acceptance_rate"][sl][on], so["acceptance_rate"][on], rtol=1e-4, atol=1e-6)
+        np.testing.assert_array_equal(sg["numerical_error"][sl][on], so["numerical_error"][on])
+        np.testing.assert_allclose(zg.r[:, sl][:, on], zo.r[:, on], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(ag["sum_theta"][:, sl][:, on], ao["sum_theta"][:, on], rtol=1e-8, atol=1e-8)
+        depth_max = max(depth_max, int(so["tree_depth"].max()))
+        n_div += int(ao["n_divergent"])
+        n_on += int(on.sum())
+    assert depth_max >= 7 and n_div > 0 and n_on >= 3 * n - 3, (depth_max, n_div, n_on)
 
 
 @pytest.mark.parametrize("engine,metric", [("step", "identity"), ("step", "spd"), ("epoch", "identity"), ("epoch", "spd"), ("epoch_full_shard", "spd"),
@@ -1073,7 +1168,7 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
             depth_seen = max(depth_seen, int(st_o["tree_depth"].max()))
     assert depth_seen >= 5, depth_seen   # trees of 32+ leaves: merges on several pending levels, compaction of finished chains
     # what ran: the 64×64-tile GEMM, two pipelines, the point-pool tree kernel
-    assert g.info("dense_gemm_launches") > 0 and g.info("dense_pipelines") == 2 and g.info("dense_pool") == 1
+    assert g.info("dense_gemm_launches") + g.info("dense_gemm_small_launches") > 0 and g.info("dense_pipelines") == 2 and g.info("dense_pool") == 1
     assert (g.info("dense_epoch_launches") > 0) == (engine != "step")
     g.close()
     for o in os_:

@@ -78,6 +78,29 @@ def test_plugin_builds_and_describes_itself():
     assert so == build_target_plugin(os.path.join(UT, "banana.hpp"), np.float64, 64, 2, n_params=2)  # cached by content
 
 
+@pytest.mark.parametrize("form", ["object", "bitcode"])
+def test_object_plugin_links_and_inlines(form):
+    """A density handed over as COMPILED device code (include/ahmc_user_target_object.h: one C symbol): a relocatable object of
+    `hipcc -fgpu-rdc -c`, or raw amdgcn bitcode as GPUCompiler.jl emits it.  The engine's kernels are linked with it under
+    device LTO (no GPU needed): the plugin exports the descriptor, every kernel of the geometry is there, and the density is
+    INLINED — no call is left in the device code, the symbol is gone."""
+    import json
+    import subprocess
+    from ahmc_amd.build import build_device_object, build_target_plugin_from_object
+
+    obj = build_device_object(os.path.join(UT, "banana_object.hip"), bitcode=(form == "bitcode"))
+    assert obj.endswith(".bc" if form == "bitcode" else ".o") and os.path.getsize(obj) > 0
+    so = build_target_plugin_from_object(obj, np.float64, 64, 2, n_params=2)
+    assert os.path.exists(so) and not os.path.realpath(so).startswith(os.path.realpath(os.path.dirname(HERE)) + os.sep)
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert " ahmc_target_plugin_v1" in syms
+    for mode in range(5):
+        assert f"k_nutsIdLi64ELi2ELi{mode}ELi4EE" in syms, mode      # the five NUTS instantiations of the geometry, family TK = 4
+    meta = json.load(open(so + ".json"))
+    assert meta["inlined"] is True and meta["G"] == 64 and meta["E"] == 2
+    assert so == build_target_plugin_from_object(obj, np.float64, 64, 2, n_params=2)  # cached by content
+
+
 def test_oracle_host_kernel_equals_builtin_family(oracle):
     """the checker's form of ahmc_set_target_kernel: the isotropic Gaussian as a host function == its built-in family,
     chain for chain (same scalar code path, only the evaluation of (ℓπ, ∇ℓπ) is the user's)"""
@@ -206,6 +229,47 @@ def test_plugin_equals_builtin_family_bit_for_bit(hip, dtype, D, N):
     np.testing.assert_array_equal(a[6], b[6])
     np.testing.assert_array_equal(a[7]["sum_theta"], b[7]["sum_theta"])
     assert a[4]["tree_depth"].max() >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,dtype,D,N", [("object", np.float64, 128, 512), ("bitcode", np.float64, 128, 512), ("bitcode", np.float64, 50, 768),
+                                            ("object", np.float32, 128, 256), ("bitcode", np.float64, 600, 48)])
+def test_object_plugin_equals_header_plugin_bit_for_bit(hip, form, dtype, D, N):
+    """The SAME density (banana) as a header plugin (compiled into the kernels from source) and as an object / bitcode plugin
+    (linked into them under device LTO): static HMC, NUTS, find_good_stepsize and a fused Stan warm-up + draws must give the
+    same chains BIT FOR BIT — the object form is the header form's arithmetic, inlined — on one-wave, shared-wave and multi-wave
+    geometries, f64 and f32."""
+    from ahmc_amd.build import build_device_object
+
+    obj = build_device_object(os.path.join(UT, "banana_object.hip"), bitcode=(form == "bitcode"))
+    params = np.array([0.5, 0.05])
+    rs = np.random.default_rng(D + N)
+    minv = np.asfortranarray(0.5 + rs.random((D, N)))
+    th0 = np.asfortranarray(0.5 * rs.normal(size=(D, N)))
+    out = []
+    for target in (A.PluginTarget(D, os.path.join(UT, "banana.hpp"), params=params), A.ObjectTarget(D, obj, params=params)):
+        metric = A.DiagEuclideanMetric(minv.copy(order="F"))
+        e = A.Engine(A.Hamiltonian(metric, target), N, dtype=dtype, rng=A.PhiloxRNG(9), lib=hip)
+        lf = A.Leapfrog(np.full(N, 0.1))
+        e.set_integrator(lf)
+        e.set_position(th0)
+        z0 = e.phasepoint()
+        eps = e.find_good_stepsize()
+        hmc = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(7)))
+        e.transition(hmc)
+        s_h = e.stats()
+        k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=8, delta_max=1000.0)))
+        e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf), init_buffer=9, term_buffer=6, window_size=15))
+        draws = np.zeros((D, N, 10), order="F", dtype=dtype)
+        e.run(k, 50, 40, drop_warmup=True, samples_out=draws)
+        e.sync()
+        out.append((z0.lp.value.copy(), z0.lp.gradient.copy(), eps.copy(), s_h["is_accept"].copy(), s_h["hamiltonian_energy"].copy(), draws,
+                    e.get_stepsize().copy(), e.get_metric().copy(), e.stats()["n_steps"].copy(), e.accum()["total_n_steps"]))
+        e.close()
+    a, b = out
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    assert a[8].max() >= 7 and np.isfinite(a[5]).all()
 
 
 @pytest.mark.gpu
