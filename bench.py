@@ -384,7 +384,7 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
         # what the leapfrog itself needs (src/integrator.jl:231-243 on E elements per lane): r −= ϵ/2·g, θ += ϵ·(M⁻¹r), the density's
         # gradient and value, r −= ϵ/2·g′, ℓκ — ≈ 7 f64 VALU instructions per element; everything above that is the tree
         # (reductions, weights, merges, U-turn tests, RNG) and the kernel's bookkeeping
-        useful_floor = 7.0 * E
+        useful_floor = 7.0 * E * max(1, G // 64)   # (per chain: a multi-wave chain's leapfrog is issued by G / 64 waves — round 4 counted one)
 
         def kernel_roof(label, mode, launches, kns, leap):
             """VALU-issue roof of one instantiation of k_nuts from this run's launches (HIP events) and the counters at HEAD"""
@@ -638,8 +638,9 @@ def compact_line(full, detail_path=None):
 
 # the default run reports the other single-GPU BASELINE configs beside the headline (config.secondary): (steps, transitions per
 # step, untimed warm-up transitions, timed runs, seconds of CPU baseline) — sized so that the whole default invocation stays
-# well under two minutes: cfg3 1 000 + 1 000, cfg5 and cfg4 100 + 100 on one GPU's shard
-SECONDARY = {"cfg3": (20, 100, 100, 1, 5.0), "cfg5": (2, 100, 10, 1, 5.0), "cfg4": (2, 100, 10, 1, 5.0)}
+# well under two minutes: cfg3 1 000 + 1 000, cfg5 100 + 100 and cfg4 200 + 200 on one GPU's shard (cfg4's batches end in a tail of
+# few running chains: 2 / 6 steps measure 42.5 / 44.0 TFLOP/s, profiles/r5_experiments.md)
+SECONDARY = {"cfg3": (20, 100, 100, 1, 5.0), "cfg5": (2, 100, 10, 1, 5.0), "cfg4": (4, 100, 10, 1, 5.0)}
 
 
 def main():
