@@ -1,4 +1,5 @@
-/* ahmc_user_target.h — how to hand the engine a log-density that runs ON THE DEVICE, inside the trajectory kernels.
+/* ahmc_user_target.h — DOCUMENTATION ONLY: this header declares nothing (the user supplies the template it describes; the form with a
+ * declared C symbol is ahmc_user_target_object.h).  How to hand the engine a log-density that runs ON THE DEVICE, inside the trajectory kernels.
  *
  * Reference surface replaced: the user callable `h.∂ℓπ∂θ(θ) -> (ℓπ, ∇ℓπ)` of /root/reference/src/hamiltonian.jl:45-48, built from a
  * LogDensityProblems object at src/AdvancedHMC.jl:163-186.  A Julia closure cannot run inside a HIP kernel behind a C ABI; the
@@ -9,6 +10,9 @@
  *     NUTS incl. the fused warm-up, find_good_stepsize — with that function in place of a built-in family, for the element type
  *     and thread geometry of the context, into a small shared object the engine binds with dlopen.  Same kernels, same speed as
  *     the built-in families: no host round trip, no per-leapfrog launch.
+ *  1b. TARGET OBJECT (ahmc_user_target_object.h; build_target_plugin_from_object): the same fused kernels for a density that exists only
+ *     as COMPILED device code — a relocatable object or amdgcn LLVM bitcode (what GPUCompiler.jl emits for a Julia function) defining one C
+ *     symbol; linked with the engine's kernels under device LTO (inlined), bound like a plugin.
  *  2. TARGET KERNEL (ahmc_set_target_kernel, ahmc_hip.h): the density is a device KERNEL the caller already has — a
  *     hipFunction_t (hipModuleGetFunction; what AMDGPU.jl compiles a Julia kernel to) or a __global__ symbol of the process —
  *     and the step-synchronous engine launches it itself between its tree kernels: one launch per leapfrog of all running

@@ -4,6 +4,8 @@ Gaussian, per-chain Diag metric, NUTS(0.8) after a StanHMCAdaptor / StepSizeAdap
 
   builtin   AHMC_TARGET_ISO_GAUSS                      (fused k_nuts)
   plugin    tests/user_targets/iso_gauss.hpp           (the same fused kernels with the user's device function inside)
+  bitcode / object   tests/user_targets/iso_gauss_object.hip compiled to raw amdgcn bitcode / a relocatable device object and LINKED into
+            the fused kernels (build_target_plugin_from_object: device LTO inlines it)
   kernel    tests/user_targets/kernels.hip iso_gauss_f64 as a hipFunction_t (the engine launches it once per global step)
   asktell   the same density evaluated by torch on the device through ahmc_ext_* (a host round trip per leapfrog)
 """
@@ -24,7 +26,7 @@ D, N = int(os.environ.get("D", 128)), int(os.environ.get("N", 65536))
 n_adapt, n_draw = int(os.environ.get("ADAPT", 100)), int(os.environ.get("DRAWS", 60))
 UT = os.path.join(ROOT, "tests", "user_targets")
 lib = A.load_hip_library()
-which = sys.argv[1:] or ["builtin", "plugin", "kernel"]
+which = sys.argv[1:] or ["builtin", "plugin", "bitcode", "object", "kernel"]
 out = {}
 for mode in which:
     metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
@@ -33,6 +35,9 @@ for mode in which:
         target = A.IsoGaussian(D)
     elif mode == "plugin":
         target = A.PluginTarget(D, os.path.join(UT, "iso_gauss.hpp"))
+    elif mode in ("object", "bitcode"):   # the same density as COMPILED device code, linked into the fused kernels (round 5)
+        from ahmc_amd.build import build_device_object
+        target = A.ObjectTarget(D, build_device_object(os.path.join(UT, "iso_gauss_object.hip"), bitcode=(mode == "bitcode")))
     elif mode == "kernel":
         from ahmc_amd.build import build_code_object
         from ahmc_amd.hipmod import Module
@@ -49,7 +54,7 @@ for mode in which:
     e.set_integrator(lf)
     e.set_position(np.asfortranarray(np.random.default_rng(2).random((D, N))))
     e.find_good_stepsize()
-    fused = mode in ("builtin", "plugin")
+    fused = mode in ("builtin", "plugin", "object", "bitcode")
     e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)) if fused else A.StepSizeAdaptor(0.8, lf))
     k = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=10)))
     t = time.perf_counter(); e.run(k, n_adapt, n_adapt); e.sync(); ta = time.perf_counter() - t
