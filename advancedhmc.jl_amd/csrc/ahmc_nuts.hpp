@@ -82,46 +82,61 @@ struct Chunking {
 // Vector slots of one wave.  Slot s, piece c, lane l lives at ((s*NCH + c)*64 + l)*CH elements.
 // Addresses are always formed as (wave-uniform slot base) + (32-bit lane offset) so that global
 // accesses use the saddr+voffset form and no per-lane 64-bit pointer has to stay live.
+// Round 5: the two homes of a slot are pointers in their OWN address spaces (LDS / global).  As two generic pointers the
+// compiler merged `slot < n_lds ? lds : glb` into a select of addresses and ONE flat instruction per piece — 64-bit
+// address arithmetic per access, the LDS slots reached through the flat path (longer latency, counted on vmcnt AND lgkmcnt,
+// so a wait for one slot also waited for every scratch store in flight).  Now the choice is a scalar branch between a
+// ds_read / ds_write with an immediate offset and a global access in the saddr form.
+#ifndef AHMC_SLOTS_ADDRSPACE
+#define AHMC_SLOTS_ADDRSPACE 1   // 0: generic pointers (rounds 1–4)
+#endif
+#if AHMC_SLOTS_ADDRSPACE
+#define AHMC_AS_LDS __attribute__((address_space(3)))
+#define AHMC_AS_GLB __attribute__((address_space(1)))
+#else
+#define AHMC_AS_LDS
+#define AHMC_AS_GLB
+#endif
 template <class T, int E>
 struct Slots {
-  T* lds;          // first n_lds slots
-  T* glb;          // the remaining ones
+  AHMC_AS_LDS T* lds;   // first n_lds slots
+  AHMC_AS_GLB T* glb;   // the remaining ones
   int n_lds;
   unsigned lane_off;  // lane64 * CH (elements)
 
-  template <class P>
-  static __device__ __forceinline__ void put(P* __restrict__ sb, unsigned off, const T (&v)[E]) {
-    constexpr int CH = Chunking<T, E>::CH, NCH = Chunking<T, E>::NCH;
-    if constexpr (CH > 1) {
-      using V = T __attribute__((ext_vector_type(CH)));
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        V t;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) t[k] = v[c * CH + k];
-        *reinterpret_cast<V*>(&sb[off + (unsigned)(c * 64 * CH)]) = t;
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) sb[off + (unsigned)(c * 64)] = v[c];
-    }
+#define AHMC_SLOT_PUT(AS)                                                                                   \
+  static __device__ __forceinline__ void put(AS T* __restrict__ sb, unsigned off, const T (&v)[E]) {         \
+    constexpr int CH = Chunking<T, E>::CH, NCH = Chunking<T, E>::NCH;                                       \
+    if constexpr (CH > 1) {                                                                                 \
+      using V = T __attribute__((ext_vector_type(CH)));                                                     \
+      _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                     \
+        V t;                                                                                                \
+        _Pragma("unroll") for (int k = 0; k < CH; ++k) t[k] = v[c * CH + k];                                \
+        *(AS V*)(&sb[off + (unsigned)(c * 64 * CH)]) = t;                                                    \
+      }                                                                                                     \
+    } else {                                                                                                \
+      _Pragma("unroll") for (int c = 0; c < NCH; ++c) sb[off + (unsigned)(c * 64)] = v[c];                  \
+    }                                                                                                       \
+  }                                                                                                         \
+  static __device__ __forceinline__ void get(const AS T* __restrict__ sb, unsigned off, T (&v)[E]) {         \
+    constexpr int CH = Chunking<T, E>::CH, NCH = Chunking<T, E>::NCH;                                       \
+    if constexpr (CH > 1) {                                                                                 \
+      using V = T __attribute__((ext_vector_type(CH)));                                                     \
+      _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                     \
+        V t = *(const AS V*)(&sb[off + (unsigned)(c * 64 * CH)]);                                            \
+        _Pragma("unroll") for (int k = 0; k < CH; ++k) v[c * CH + k] = t[k];                                \
+      }                                                                                                     \
+    } else {                                                                                                \
+      _Pragma("unroll") for (int c = 0; c < NCH; ++c) v[c] = sb[off + (unsigned)(c * 64)];                  \
+    }                                                                                                       \
   }
-  template <class P>
-  static __device__ __forceinline__ void get(const P* __restrict__ sb, unsigned off, T (&v)[E]) {
-    constexpr int CH = Chunking<T, E>::CH, NCH = Chunking<T, E>::NCH;
-    if constexpr (CH > 1) {
-      using V = T __attribute__((ext_vector_type(CH)));
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        V t = *reinterpret_cast<const V*>(&sb[off + (unsigned)(c * 64 * CH)]);
-#pragma unroll
-        for (int k = 0; k < CH; ++k) v[c * CH + k] = t[k];
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) v[c] = sb[off + (unsigned)(c * 64)];
-    }
-  }
+#if AHMC_SLOTS_ADDRSPACE
+  AHMC_SLOT_PUT(AHMC_AS_LDS)
+  AHMC_SLOT_PUT(AHMC_AS_GLB)
+#else
+  AHMC_SLOT_PUT()
+#endif
+#undef AHMC_SLOT_PUT
   __device__ __forceinline__ void store(int slot, const T (&v)[E]) const {
     constexpr int SE = Chunking<T, E>::NCH * 64 * Chunking<T, E>::CH;
     if (slot < n_lds) put(lds + slot * SE, lane_off, v);
@@ -269,8 +284,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #define S_CK(lvl) sI[((1) * NLEV + (lvl)) * CPW + gi]
   const int64_t wave_slot = (int64_t)blockIdx.x * nwaves + wib;
   Slots<T, E> sl;
-  sl.lds = lds_vec;
-  sl.glb = p.scratch + wave_slot * (int64_t)(n_slots - n_lds_slots) * SLOT_ELEMS;
+  sl.lds = (AHMC_AS_LDS T*)lds_vec;
+  sl.glb = (AHMC_AS_GLB T*)(p.scratch + wave_slot * (int64_t)(n_slots - n_lds_slots) * SLOT_ELEMS);
   sl.n_lds = n_lds_slots;
   sl.lane_off = (unsigned)lane64 * CH;
   const int DORM = NV * NLEV;  // first dormant slot (logical numbering: levels first, then the dormant vectors)
