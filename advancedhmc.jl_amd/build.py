@@ -53,7 +53,9 @@ PART_B_FLAGS = ["-mllvm", "-disable-machine-licm"]
 
 
 def _units():
-    units = [("api", "ahmc_api.hip", [])]
+    # (the host side knows the digest of the kernel sources it was built with: ahmc_set_target_plugin refuses a plugin compiled from OTHER
+    # kernel sources — a plugin whose kernels expect another scratch layout than this library allocates would write out of bounds)
+    units = [("api", "ahmc_api.hip", [f'-DAHMC_KERNEL_SOURCES_DIGEST="{source_digest()}"'])]
     for tname, tdef in (("f32", "float"), ("f64", "double")):
         for tk in range(4):
             # part A: everything but …; part B: the warm-up instantiations of k_nuts and all of the multi-wave geometries', with the

@@ -435,7 +435,7 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   const int CPW = c->G >= 64 ? 1 : 64 / c->G;
   const int NW = c->G > 64 ? c->G / 64 : 1;  // waves per chain (multi-wave groups: one chain per workgroup)
   const int NLEV = max_depth > 1 ? max_depth - 1 : 1;
-  const int n_slots = (criterion == AHMC_TC_STRICT ? 3 : 2) * NLEV + NUTS_DORMANT;
+  const int n_slots = (criterion == AHMC_TC_STRICT ? 3 : 2) * NLEV + NUTS_DORMANT + NUTS_CKPT;
   const size_t slot_bytes = (size_t)64 * c->E * sizeof(T);
   const size_t scalar_bytes = (size_t)(NUTS_NSC * NLEV + NUTS_NAT) * CPW * sizeof(T) + (size_t)(NUTS_NSI * NLEV + NUTS_NAI) * CPW * sizeof(int);
   const int64_t n_chunks = (c->N + CPW - 1) / CPW;
@@ -456,9 +456,9 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   if (per_wave > wg_cap / (size_t)NW) per_wave = wg_cap / (size_t)NW;
   const size_t static_lds = 128 + (NW > 1 ? 1024 / (size_t)NW : 0);  // per wave: the exchange buffers of the reductions (multi-wave chains: one per call site, ahmc_device.hpp)
   per_wave = per_wave > scalar_bytes + static_lds ? per_wave - scalar_bytes - static_lds : 0;
-  n_lds_slots = (int)std::min<size_t>((size_t)n_slots, per_wave / slot_bytes);
+  n_lds_slots = (int)std::min<size_t>((size_t)(n_slots - NUTS_CKPT), per_wave / slot_bytes);   // (the checkpoint triples are cold and addressed per lane: always global)
   const char* ovs = getenv("AHMC_NUTS_LDS_SLOTS");
-  if (ovs) n_lds_slots = std::max(0, std::min(n_slots, atoi(ovs)));
+  if (ovs) n_lds_slots = std::max(0, std::min(n_slots - NUTS_CKPT, atoi(ovs)));
   smem = (size_t)n_lds_slots * slot_bytes + scalar_bytes;
   static const bool dbg = getenv("AHMC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[ahmc] k_nuts<%s,%d,%d,mode=%d>: occupancy %d waves/CU, %d/%d vector slots in LDS, %zu B LDS/wave, %lld waves\n", sizeof(T) == 8 ? "f64" : "f32", c->G, c->E, MODE, occ, n_lds_slots, n_slots, smem, (long long)n_chunks);
@@ -1283,6 +1283,9 @@ int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t
   });
 }
 
+#ifndef AHMC_KERNEL_SOURCES_DIGEST
+#define AHMC_KERNEL_SOURCES_DIGEST ""
+#endif
 int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void* params, int64_t n_params) {
   FOR_CTX_MUT(ctx, {
     if (!plugin_so) return fail(c, AHMC_ERR_ARGUMENT, "set_target_plugin: path is NULL");
@@ -1297,6 +1300,11 @@ int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void*
     if (!d) return reject("no symbol ahmc_target_plugin_v1 (not a target plugin)");
     if (d->plugin_abi != AHMC_PLUGIN_ABI || d->struct_bytes != (int32_t)sizeof(TargetPluginDesc) || d->kp_bytes != (int32_t)sizeof(KP<T>))
       return reject("built against another version of the engine's kernel sources: rebuild it (build_target_plugin)");
+    // the kernel sources themselves (round 5): the scratch layout of k_nuts is a contract between the launch plan here and the kernels there that no
+    // struct size shows — a plugin compiled from other sources than this library is refused (an empty digest on either side: not checked)
+    if (d->sources_digest && d->sources_digest[0] && AHMC_KERNEL_SOURCES_DIGEST[0] && strcmp(d->sources_digest, AHMC_KERNEL_SOURCES_DIGEST) != 0)
+      return reject(std::string("compiled from other kernel sources (") + std::string(d->sources_digest).substr(0, 12) + "…) than this library (" +
+                    std::string(AHMC_KERNEL_SOURCES_DIGEST).substr(0, 12) + "…): rebuild it (build_target_plugin)");
     if (d->dtype != (sizeof(T) == 4 ? AHMC_F32 : AHMC_F64)) return reject("built for the other element type");
     if (d->G != c->G || d->E != c->E)
       return reject("built for thread geometry (" + std::to_string(d->G) + "," + std::to_string(d->E) + "), the context uses (" + std::to_string(c->G) + "," +

@@ -147,6 +147,16 @@ struct Slots {
     if (slot < n_lds) get(lds + slot * SE, lane_off, v);
     else get(glb + (size_t)(slot - n_lds) * SE, lane_off, v);
   }
+  // a slot that is NEVER in LDS (the launch plan keeps the checkpoint triples behind n_lds), `extra` more elements into it PER LANE:
+  // chains that share a wave may address different triples
+  __device__ __forceinline__ void store_cold(int slot, unsigned extra, const T (&v)[E]) const {
+    constexpr int SE = Chunking<T, E>::NCH * 64 * Chunking<T, E>::CH;
+    put(glb + (size_t)(slot - n_lds) * SE, lane_off + extra, v);
+  }
+  __device__ __forceinline__ void load_cold(int slot, unsigned extra, T (&v)[E]) const {
+    constexpr int SE = Chunking<T, E>::NCH * 64 * Chunking<T, E>::CH;
+    get(glb + (size_t)(slot - n_lds) * SE, lane_off + extra, v);
+  }
 };
 
 // the vector half of a leapfrog step (no energies): used to re-integrate to the candidate
@@ -257,7 +267,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
   constexpr bool ADAPT = MODE >= 3;  // MODE 0 / 1 + adapt!(…) after every transition, inside the kernel (AdaptK)
   const bool strict = GENERAL && p.criterion == 2;
   const int NV = strict ? 3 : 2;  // vectors per pending level: A, RF (, RL)
-  const int n_slots = NV * NLEV + NUTS_DORMANT;
+  const int n_slots = NV * NLEV + NUTS_DORMANT + NUTS_CKPT;
+  const int CK0 = NV * NLEV + NUTS_DORMANT;   // first checkpoint slot (physical = logical: behind every other slot of either numbering)
   const int n_lds_slots = p.n_lds_levels;  // (re-used field) number of vector slots held in LDS
   // LDS carve-up: [nwaves][n_lds_slots][SLOT_ELEMS] T | [nwaves][NSC][NLEV][CPW] T | [nwaves][NAT][CPW] T |
   //                [nwaves][NSI][NLEV][CPW] int | [nwaves][NAI][CPW] int
@@ -438,6 +449,30 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     }
     bool cur_is_left = false;
     int pos_cur = 0, pos_oth = 0;  // leaf index (signed distance from z0) of the two edges
+#if AHMC_CKPT
+    // Checkpoint of the re-integration (round 5).  The candidate is carried as a leaf index and re-integrated at the end — from z0 that
+    // is ≈ 0.5 leapfrogs per leaf step (0.37 / 0.51 / 0.48 measured on cfg2 / cfg3 / cfg5: 9 / 14 / 18 % of a leaf step's cycles).  The state
+    // of the EDGE a doubling grows from is in registers when the doubling starts, and every leaf of that doubling lies beyond it: saved
+    // there (three stores to cold global slots, off the chain of dependent stages), it is where the replay starts if the tree's
+    // candidate ends up in that subtree — the same leapfrogs from the same state, so the same bits, and half as many of them.
+    // chk = (position << 1) | triple of the COMMITTED checkpoint (position 0: none, replay from z0); a doubling saves into the other triple.
+    // (not in the Float32 warm-up kernels: with it the register allocator parks a spill under a narrowed exec mask in k_nuts<float,32,4,3,·> and
+    // <float,16|32,2,3,·>, which isa_check refuses; the replay there starts at z0 as before — same results either way)
+    int chk = 0;
+#ifndef AHMC_CKPT_MIN_JW
+#define AHMC_CKPT_MIN_JW 2
+#endif
+    constexpr int CKPT_MIN_JW = AHMC_CKPT_MIN_JW;   // subtrees of 4 leaves and more
+    // … and not where one chain fills one wave with two elements per lane (cfg2's (64,2)): that kernel is bound by VALU issue at its
+    // register cap, the replay is 3 % of its instructions, and the checkpoint's extra live value costs it six more spilled registers —
+    // measured 2.851e9 against 2.881e9 leapfrog/s; the chains that share a wave (cfg3 +7 %) and the multi-wave chains (cfg5 +6.7 %) are
+    // bound by the latency of their dependent stages, where half the replay is half the time.
+    constexpr bool CKPT = !(sizeof(T) == 4 && ADAPT) && !(G == 64 && E <= 2);
+#else
+    int chk = 0;
+    constexpr int CKPT_MIN_JW = 2;
+    constexpr bool CKPT = false;
+#endif
     bool numerical = false;
     bool redo = false;  // LINW only: a weight came too close to overflow
     int depth = 0;
@@ -476,6 +511,19 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       }
       if (strict && AHMC_ANY(!done)) {
         if (!done) sl.store(DS(SL_START_R), cur.r);  // r of the edge the subtree grows from
+      }
+      if (CKPT && jw >= CKPT_MIN_JW) {   // (wave-uniform)
+        // A chain that owns its wave saves only an edge that is not z0 itself; chains that SHARE a wave all store (a finished chain, or an
+        // edge at z0, writes a triple nobody will read): no exec-masked block here for the register allocator to park a spill in
+        // (isa_check refused the masked form in the f32 warm-up kernels)
+        bool ck_save = true;
+        if constexpr (CPW == 1) ck_save = AHMC_UNI(!done && pos_cur != 0);
+        if (ck_save) {
+          const unsigned xo = (unsigned)(((chk & 1) ^ 1) * 3 * SLOT_ELEMS);
+          sl.store_cold(CK0 + 0, xo, cur.th);
+          sl.store_cold(CK0 + 1, xo, cur.r);
+          sl.store_cold(CK0 + 2, xo, cur.g);
+        }
       }
       // ---- build the subtree of 2^jw leaves (:626-675) ----
       const uint32_t nleaf = 1u << jw;
@@ -763,7 +811,15 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
           if (slice) acc = w_tree * (T)ds.uniform() < w_c;
           else if constexpr (LINW) acc = AHMC_UNI((T)ds.uniform() * w_tree < w_c);
           else acc = AHMC_UNI(w_tree < w_c + (T)ds.randexp());
-          if (acc) ck_tree = ck_c;
+          if (acc) {
+            ck_tree = ck_c;
+            if constexpr (CKPT) {
+              const int start = pos_cur - v * (int)nleaf;   // the edge this (complete) subtree grew from
+              if (jw >= CKPT_MIN_JW && start != 0) chk = (start << 1) | ((chk & 1) ^ 1);   // saved above: commit it
+              else if (((chk >> 1) > 0) != (v > 0) || (chk >> 1) == 0) chk = chk & 1;        // an older checkpoint on the other side: none
+              // (an older one on the same side lies between z0 and the new candidate: still a valid, if distant, start)
+            }
+          }
         }
         sa_tree = sa_tree + sa_c;
         na_tree = na_tree + na_c;
@@ -838,10 +894,41 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       int64_t ce = cc;
       asm volatile("" : "+v"(ce));
       Point<T, E> zc;
-      load_vec<T, E>(zc.th, p.th(), ce * p.D, d0, p.D, T(0));
-      sl.load(DS(SL_Z0_R), zc.r);
-      sl.load(DS(SL_Z0_G), zc.g);
-      const int steps = on ? (ck_tree < 0 ? -ck_tree : ck_tree) : 0;
+      const int cp = chk >> 1;
+      const bool from_ck = CKPT && AHMC_UNI(on && cp != 0);
+      if constexpr (!CKPT) {
+        load_vec<T, E>(zc.th, p.th(), ce * p.D, d0, p.D, T(0));
+        sl.load(DS(SL_Z0_R), zc.r);
+        sl.load(DS(SL_Z0_G), zc.g);
+      } else if constexpr (CPW == 1) {   // (wave-uniform: a scalar branch)
+        if (from_ck) {
+          const unsigned xo = (unsigned)((chk & 1) * 3 * SLOT_ELEMS);
+          sl.load_cold(CK0 + 0, xo, zc.th);
+          sl.load_cold(CK0 + 1, xo, zc.r);
+          sl.load_cold(CK0 + 2, xo, zc.g);
+        } else {
+          load_vec<T, E>(zc.th, p.th(), ce * p.D, d0, p.D, T(0));
+          sl.load(DS(SL_Z0_R), zc.r);
+          sl.load(DS(SL_Z0_G), zc.g);
+        }
+      } else {   // chains that share a wave: both starts are read and the chain's own is selected — no exec-masked block (see the save)
+        Point<T, E> zk;
+        const unsigned xo = (unsigned)((chk & 1) * 3 * SLOT_ELEMS);
+        load_vec<T, E>(zc.th, p.th(), ce * p.D, d0, p.D, T(0));
+        sl.load(DS(SL_Z0_R), zc.r);
+        sl.load(DS(SL_Z0_G), zc.g);
+        sl.load_cold(CK0 + 0, xo, zk.th);
+        sl.load_cold(CK0 + 1, xo, zk.r);
+        sl.load_cold(CK0 + 2, xo, zk.g);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          zc.th[e] = from_ck ? zk.th[e] : zc.th[e];
+          zc.r[e] = from_ck ? zk.r[e] : zc.r[e];
+          zc.g[e] = from_ck ? zk.g[e] : zc.g[e];
+        }
+      }
+      const int dist = from_ck ? ck_tree - cp : ck_tree;
+      const int steps = on ? (dist < 0 ? -dist : dist) : 0;
       const T es = ck_tree < 0 ? -eps : eps;
       for (int s = 0;; ++s) {
         const bool go = AHMC_UNI(s < steps);

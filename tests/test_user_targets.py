@@ -273,6 +273,32 @@ def test_object_plugin_equals_header_plugin_bit_for_bit(hip, form, dtype, D, N):
 
 
 @pytest.mark.gpu
+def test_plugin_from_other_kernel_sources_is_refused(hip, tmp_path):
+    """The scratch layout of k_nuts is a contract between the library's launch plan and the kernels a plugin carries that no struct size
+    shows (round 5: a plugin compiled from newer sources than the loaded library wrote out of bounds).  The library knows the digest of the
+    kernel sources it was built from; a plugin that names another one is refused with an ArgumentError, nothing is bound."""
+    import subprocess
+    from ahmc_amd import build as B
+
+    so = str(tmp_path / "libstale_plugin.so")
+    cmd = ["hipcc", *B.FLAGS, "-shared", "-DAHMC_INST_T=double", "-DAHMC_INST_TK=4", "-DAHMC_PLUGIN_G=64", "-DAHMC_PLUGIN_E=2",
+           "-DAHMC_PLUGIN_NPARAMS=-1", f'-DAHMC_USER_TARGET_HEADER="{os.path.join(UT, "iso_gauss.hpp")}"', '-DAHMC_SOURCES_DIGEST="0123456789abcdef-not-this-library"',
+           "-I", B.INCLUDE, os.path.join(B.CSRC, "ahmc_inst.hip"), "-o", so]
+    subprocess.run(cmd, check=True, capture_output=True)
+    D, N = 128, 64
+    e = A.Engine(A.Hamiltonian(A.DiagEuclideanMetric(np.ones((D, N), order="F")), A.IsoGaussian(D)), N, rng=A.PhiloxRNG(1), lib=hip)
+    with pytest.raises(A.ArgumentError, match="other kernel sources"):
+        e._call("ahmc_set_target_plugin", so.encode(), None, 0)
+    # the context still runs its built-in family
+    lf = A.Leapfrog(np.full(N, 0.2))
+    e.set_integrator(lf)
+    e.set_position(np.zeros((D, N), order="F"))
+    e.transition(A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=5))))
+    assert np.isfinite(e.theta()).all()
+    e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D", [10, 128, 300])
 def test_plugin_banana_against_oracle(hip, oracle, D):
     """a density that is no built-in family, compiled into the fused kernels, vs the oracle evaluating the same density as a
