@@ -463,11 +463,12 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #define AHMC_CKPT_MIN_JW 2
 #endif
     constexpr int CKPT_MIN_JW = AHMC_CKPT_MIN_JW;   // subtrees of 4 leaves and more
-    // … and not where one chain fills one wave with two elements per lane (cfg2's (64,2)): that kernel is bound by VALU issue at its
-    // register cap, the replay is 3 % of its instructions, and the checkpoint's extra live value costs it six more spilled registers —
-    // measured 2.851e9 against 2.881e9 leapfrog/s; the chains that share a wave (cfg3 +7 %) and the multi-wave chains (cfg5 +6.7 %) are
-    // bound by the latency of their dependent stages, where half the replay is half the time.
-    constexpr bool CKPT = !(sizeof(T) == 4 && ADAPT) && !(G == 64 && E <= 2);
+    // … and not where ONE chain fills ONE wave (G = 64: cfg2's (64,2), and (64,4), (64,8)): those kernels are bound by VALU issue at their
+    // register caps, the replay is ≈ 3 % of their instructions, and the checkpoint's extra live value costs them spilled registers — measured
+    // with / without: (64,2) 2.851e9 / 2.881e9, (64,4) at D = 256 1.587e9 / 1.603e9, (64,8) at D = 512 7.78e8 / 8.08e8 leapfrog/s.  The chains
+    // that share a wave (cfg3 +7 %) and the multi-wave chains (cfg5 +6.7 %) are bound by the latency of their dependent stages, where half
+    // the replay is half the time (profiles/r5_experiments.md r5i, r5j).
+    constexpr bool CKPT = !(sizeof(T) == 4 && ADAPT) && G != 64;
 #else
     int chk = 0;
     constexpr int CKPT_MIN_JW = 2;
