@@ -142,7 +142,11 @@ def analyse(text, rates, mix=None, total=None, LEVEL=0, W="W4"):
         return any(pat in i[1] for b in body for i in blocks[b])
 
 
-    cands = sorted((l for l in loops if has(l, "v_ldexp_f64") and has(l, "v_mul_hi_u32")), key=len)
+    # the leaf loop holds the leaf weight's exp (v_ldexp_f64), the tree draws (Philox: v_mul_hi_u32) AND the cross-lane reductions (DPP moves);
+    # round 5: without the last condition the smallest such "loop" of the restructured kernels was a fragment with no reduction in it
+    cands = sorted((l for l in loops if has(l, "v_ldexp_f64") and has(l, "v_mul_hi_u32") and has(l, "_dpp")), key=len)
+    if not cands:
+        cands = sorted((l for l in loops if has(l, "v_ldexp_f64") and has(l, "v_mul_hi_u32")), key=len)
     if not cands:
         cands = sorted((l for l in loops if has(l, "v_ldexp_f64") or has(l, "v_exp")), key=len) or [set(range(len(blocks)))]
     hot = cands[min(LEVEL, len(cands) - 1)]
