@@ -638,9 +638,9 @@ def compact_line(full, detail_path=None):
 
 # the default run reports the other single-GPU BASELINE configs beside the headline (config.secondary): (steps, transitions per
 # step, untimed warm-up transitions, timed runs, seconds of CPU baseline) — sized so that the whole default invocation stays
-# well under two minutes: cfg3 1 000 + 1 000, cfg5 100 + 100 and cfg4 200 + 200 on one GPU's shard (cfg4's batches end in a tail of
+# well under two minutes: cfg3 1 000 + 1 000, cfg5 100 + 100 and cfg4 300 + 300 on one GPU's shard (cfg4's batches end in a tail of
 # few running chains: 2 / 6 steps measure 42.5 / 44.0 TFLOP/s, profiles/r5_experiments.md)
-SECONDARY = {"cfg3": (20, 100, 100, 1, 5.0), "cfg5": (2, 100, 10, 1, 5.0), "cfg4": (4, 100, 10, 1, 5.0)}
+SECONDARY = {"cfg3": (20, 100, 100, 1, 5.0), "cfg5": (2, 100, 10, 1, 5.0), "cfg4": (6, 100, 10, 1, 5.0)}
 
 
 def main():
