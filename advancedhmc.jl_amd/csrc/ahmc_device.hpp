@@ -183,6 +183,9 @@ static __device__ const unsigned long long EXP2_64_BITS[64] = {
 // (no memory access: 9 more VALU, ≈ 700 fewer cycles); 1: the table for every geometry (rounds 3–4).
 #define AHMC_LEAF_EXP_NARROW_TABLE 0
 #endif
+#ifndef AHMC_LEAF_MICRO
+#define AHMC_LEAF_MICRO 1   // round 5's two instruction cuts in the leaf (no underflow select in the weight's exp; ΔH_max by a scalar branch on the direction); 0: round 4's forms, for A/B runs
+#endif
 template <bool UNIFORM>
 __device__ __forceinline__ double leaf_weight_exp(double x) {
   constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
@@ -202,13 +205,19 @@ __device__ __forceinline__ double leaf_weight_exp(double x) {
   q = fma3(t, q, 0.5);
   q = fma3(t, q, 1.0);
   q = q * t;                                                                // e^t − 1
+  // (no select for the underflow: x is clamped at −1100 above — ℓw = −Inf included — and from −1075 down ldexp's exponent is ≤ −1551, below
+  // the smallest subnormal: the result IS 0 there; a NaN x fails the clamp's compare and propagates.  Round 5: three VALU per leaf fewer.)
+#if AHMC_LEAF_MICRO
+  return __builtin_ldexp(__builtin_fma(tj, q, tj), k >> 6);
+#else
   double z = __builtin_ldexp(__builtin_fma(tj, q, tj), k >> 6);
-  z = x < -1075.0 ? 0.0 : z;                                                // (incl. x = −Inf; a NaN x fails the compare and propagates)
+  z = x < -1075.0 ? 0.0 : z;
   return z;
+#endif
   }
 #endif
   {
-  const double xh = x < -1100.0 ? -1100.0 : x;                                    // (as above: −Inf is a routine input; the final select returns 0 for it)
+  const double xh = x < -1100.0 ? -1100.0 : x;                                    // (as above: −Inf is a routine input; ldexp underflows to 0 for it)
   const double dn = __builtin_rint(xh * C(0x3ff71547652b82feULL));                // x·log2(e)
   double t = __builtin_fma(dn, C(0xbfe62e42fefa39efULL), xh);                     // − n·ln2 (high part)
   t = __builtin_fma(dn, C(0xbc7abc9e3b39803fULL), t);                             // − n·ln2 (low part)
@@ -227,8 +236,10 @@ __device__ __forceinline__ double leaf_weight_exp(double x) {
 #if AHMC_LEAF_EXP == 0
   z = x > 1024.0 ? Lim<double>::inf() : z;
 #endif
+#if !AHMC_LEAF_MICRO
   z = x < -1075.0 ? 0.0 : z;
-  return z;
+#endif
+  return z;   // (the underflow needs no select either: clamped at −1100, ldexp's exponent −1587 gives 0)
   }
 }
 template <bool UNIFORM>

@@ -634,7 +634,15 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #if AHMC_RUNNING_STATS
           sa_c = sa_c + sa_leaf;                                     // over the leaves of this doubling, in build order
           na_c = na_c + 1;
-          dh_c = v > 0 ? maxabs(dh_c, dH) : maxabs(dH, dh_c);        // (maxabs keeps the right-hand one on a tie, :526)
+          // v > 0 ? maxabs(dh_c, dH) : maxabs(dH, dh_c) (maxabs keeps the right-hand one on a tie, :526).  As a select between the two calls
+          // the compiler evaluated both (two compares, six v_cndmask per leaf: round 5's census of the leaf loop); a chain that owns its wave
+          // has a wave-uniform direction, so it is a scalar branch around ONE of them (the empty asm keeps it a branch).
+          if constexpr (CPW == 1 && AHMC_LEAF_MICRO) {
+            if (v > 0) { dh_c = maxabs(dh_c, dH); asm volatile(""); }
+            else { dh_c = maxabs(dH, dh_c); asm volatile(""); }
+          } else {
+            dh_c = v > 0 ? maxabs(dh_c, dH) : maxabs(dH, dh_c);
+          }
 #else
           sa_c = sa_leaf;
           na_c = 1;
