@@ -418,6 +418,20 @@ function set_target_plugin!(z::MI355XChains{T}, plugin_so::AbstractString, param
                        isempty(params) ? C_NULL : params, length(params)))
 end
 
+# (3) COMPILED device code — what GPUCompiler.jl / AMDGPU.jl emit for a Julia function: amdgcn LLVM bitcode (or a relocatable device object)
+#     defining the C symbol of include/ahmc_user_target_object.h (`ahmc_user_logdensity_f64` / `_f32`).  The build helper links it with the
+#     engine's fused kernels under device LTO (the density is inlined into the leaf loop: built-in speed, INTEGRATION.md §3c) and the result
+#     is bound like (2).  (G, E) of the context: AHMC_INFO_GROUP_LANES = 0, AHMC_INFO_ELEMS_PER_LANE = 1 of ahmc_get_info.
+function set_target_object!(z::MI355XChains{T}, object_or_bitcode::AbstractString, params::Vector{T}=T[]; python::AbstractString="python") where {T}
+    G, E = Ref{Int64}(0), Ref{Int64}(0)
+    check(z.ctx, ccall((:ahmc_get_info, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), z.ctx, 0, G))
+    check(z.ctx, ccall((:ahmc_get_info, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), z.ctx, 1, E))
+    dt = T === Float32 ? "float32" : "float64"
+    code = "from ahmc_amd.build import build_target_plugin_from_object as b; print(b(r'$(object_or_bitcode)', '$(dt)', $(G[]), $(E[]), $(length(params))))"
+    plugin_so = strip(read(`$python -c $code`, String))
+    set_target_plugin!(z, plugin_so, params)
+end
+
 "the running accumulators (Σθ, Σθ², Σ n_steps, divergences, the energy sums behind EBFMI) as part of a Checkpoint"
 function accum_state(z::MI355XChains{T}) where {T}
     n = Ref{Int64}(0)
