@@ -84,7 +84,7 @@ struct KP {
 constexpr int NUTS_NSC = 3;      // T scalars per pending level: w, Σα, ΔH_max
 constexpr int NUTS_NSI = 2;      // int scalars per pending level: nα, candidate leaf index
 constexpr int NUTS_NAT = 5;      // per chain, T: the adaptor's state while a warm-up batch runs (nominal ϵ, DAState ϵ, μ, x̄, H̄)
-constexpr int NUTS_NAI = 2;      // per chain, int: DAState m, Welford count
+constexpr int NUTS_NAI = 3;      // per chain, int: DAState m, Welford count, the re-integration checkpoint (position << 1 | triple)
 constexpr int NUTS_DORMANT = 7;  // vector slots OTH_TH, OTH_R, OTH_G, TREE_A, Z0_R, Z0_G, START_R (strict)
 #ifndef AHMC_CKPT
 #define AHMC_CKPT 1              // k_nuts re-integrates to the candidate from the EDGE its subtree grew from instead of from z0 (ahmc_nuts.hpp); 0: from z0 (rounds 1–4)

@@ -60,6 +60,9 @@
 #define AHMC_LP_TICK(i)
 #define AHMC_LP_COUNT(i, n)
 #endif
+#ifndef AHMC_CKPT_G64
+#define AHMC_CKPT_G64 0   // 1: the checkpoint also where one chain fills one wave (experiment)
+#endif
 #ifndef AHMC_TL_WORDS
 #define AHMC_TL_WORDS 8
 #endif
@@ -288,6 +291,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #define A_DAHBAR sAT[4 * CPW + gi]
 #define A_DAM sAI[0 * CPW + gi]
 #define A_WVN sAI[1 * CPW + gi]
+#define A_CHK sAI[2 * CPW + gi]   // the checkpoint of the re-integration: touched at the top of a doubling only, so it lives in LDS, not in a register
 #define S_W(lvl) sT[((0) * NLEV + (lvl)) * CPW + gi]
 #define S_SA(lvl) sT[((1) * NLEV + (lvl)) * CPW + gi]
 #define S_DH(lvl) sT[((2) * NLEV + (lvl)) * CPW + gi]
@@ -458,7 +462,6 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     // chk = (position << 1) | triple of the COMMITTED checkpoint (position 0: none, replay from z0); a doubling saves into the other triple.
     // (not in the Float32 warm-up kernels: with it the register allocator parks a spill under a narrowed exec mask in k_nuts<float,32,4,3,·> and
     // <float,16|32,2,3,·>, which isa_check refuses; the replay there starts at z0 as before — same results either way)
-    int chk = 0;
 #ifndef AHMC_CKPT_MIN_JW
 #define AHMC_CKPT_MIN_JW 2
 #endif
@@ -468,9 +471,9 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
     // with / without: (64,2) 2.851e9 / 2.881e9, (64,4) at D = 256 1.587e9 / 1.603e9, (64,8) at D = 512 7.78e8 / 8.08e8 leapfrog/s.  The chains
     // that share a wave (cfg3 +7 %) and the multi-wave chains (cfg5 +6.7 %) are bound by the latency of their dependent stages, where half
     // the replay is half the time (profiles/r5_experiments.md r5i, r5j).
-    constexpr bool CKPT = !(sizeof(T) == 4 && ADAPT) && G != 64;
+    constexpr bool CKPT = !(sizeof(T) == 4 && ADAPT) && (G != 64 || AHMC_CKPT_G64);
+    if constexpr (CKPT) A_CHK = 0;
 #else
-    int chk = 0;
     constexpr int CKPT_MIN_JW = 2;
     constexpr bool CKPT = false;
 #endif
@@ -520,7 +523,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
         bool ck_save = true;
         if constexpr (CPW == 1) ck_save = AHMC_UNI(!done && pos_cur != 0);
         if (ck_save) {
-          const unsigned xo = (unsigned)(((chk & 1) ^ 1) * 3 * SLOT_ELEMS);
+          const unsigned xo = (unsigned)(((A_CHK & 1) ^ 1) * 3 * SLOT_ELEMS);
           sl.store_cold(CK0 + 0, xo, cur.th);
           sl.store_cold(CK0 + 1, xo, cur.r);
           sl.store_cold(CK0 + 2, xo, cur.g);
@@ -824,9 +827,11 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
             ck_tree = ck_c;
             if constexpr (CKPT) {
               const int start = pos_cur - v * (int)nleaf;   // the edge this (complete) subtree grew from
+              int chk = A_CHK;
               if (jw >= CKPT_MIN_JW && start != 0) chk = (start << 1) | ((chk & 1) ^ 1);   // saved above: commit it
               else if (((chk >> 1) > 0) != (v > 0) || (chk >> 1) == 0) chk = chk & 1;        // an older checkpoint on the other side: none
               // (an older one on the same side lies between z0 and the new candidate: still a valid, if distant, start)
+              A_CHK = chk;
             }
           }
         }
@@ -903,6 +908,8 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
       int64_t ce = cc;
       asm volatile("" : "+v"(ce));
       Point<T, E> zc;
+      int chk = 0;
+      if constexpr (CKPT) chk = A_CHK;
       const int cp = chk >> 1;
       const bool from_ck = CKPT && AHMC_UNI(on && cp != 0);
       if constexpr (!CKPT) {
@@ -1084,6 +1091,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) 
 #undef A_DAHBAR
 #undef A_DAM
 #undef A_WVN
+#undef A_CHK
 #undef AHMC_UNI
 }
 
