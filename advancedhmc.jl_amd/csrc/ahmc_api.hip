@@ -154,6 +154,7 @@ struct Ctx : CtxBase {
   T* znorm = nullptr;  // standard normals of the momentum draws of one k_nuts launch
   size_t znorm_elems = 0;
   int64_t znorm_cap_trans = 0;  // > 0: the device could not hold the normals of a full batch; launches are capped at this many transitions
+  size_t znorm_cap_fail_bytes = 0;  // the smallest allocation that failed when the cap was set: the cap holds while the device cannot offer twice that
   int32_t* redo = nullptr;  // per-chain "redo in the log domain" flags of the NUTS fast pass
   int nuts_blocks = 0;
   // static multinomial
@@ -442,6 +443,10 @@ int plan_nuts(Ctx<T>* c, int max_depth, int criterion, int& blocks, int& wpb, si
   int occ = 0;  // single-wave workgroups per CU
   const TargetOps<T>* o = ops_for(c);
   if (!o) return fail(c, AHMC_ERR_STATE, "k_nuts: the context's target has no fused kernels");
+  // the scratch sized here is indexed by kernels of another translation unit (or of a plugin): same layout constants, or no launch
+  if (!o->scratch_layout || o->scratch_layout() != nuts_scratch_layout())
+    return fail(c, AHMC_ERR_STATE, "k_nuts: the kernels of this target were compiled with another scratch layout (AHMC_CKPT / NUTS_* constants) than "
+                                   "the host side of this library: rebuild the library (or the target plugin) as a whole");
   occ = o->nuts_occupancy(c->G, c->E, MODE, scalar_bytes * NW);
   occ *= NW;
   if (occ < 1) occ = 4;
@@ -691,6 +696,14 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   return AHMC_OK;
 }
 
+// An out-of-memory cap on the launch length (reserve_normals) holds only while the device cannot offer twice the allocation that
+// failed — counting the buffer the context holds as free; after that the full request is tried again.
+template <class T>
+static bool normals_cap_holds(const Ctx<T>* c, size_t free_b) {
+  if (c->znorm_cap_trans <= 0) return false;
+  return (free_b + c->znorm_elems * sizeof(T)) / 2 < c->znorm_cap_fail_bytes;
+}
+
 template <class T>
 int64_t nuts_batch(Ctx<T>* c) {
   // transitions per launch of k_nuts (sampling AND fused warm-up): more = less tree-size tail per launch (round 1, cfg2:
@@ -731,7 +744,7 @@ int64_t nuts_batch(Ctx<T>* c) {
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<size_t>(budget, (free_b + c->znorm_elems * sizeof(T)) / 2);
   (void)hipGetLastError();
   int64_t cap = (int64_t)budget / (int64_t)(sizeof(T) * c->D * c->N);
-  if (c->znorm_cap_trans > 0) cap = std::min<int64_t>(cap, c->znorm_cap_trans);
+  if (normals_cap_holds(c, free_b)) cap = std::min<int64_t>(cap, c->znorm_cap_trans);
   return std::max<int64_t>(1, std::min<int64_t>(1024, cap));
 }
 
@@ -741,7 +754,11 @@ int64_t nuts_batch(Ctx<T>* c) {
 template <class T>
 int reserve_normals(Ctx<T>* c, int64_t n_trans) {
   if (n_trans < 1) n_trans = 1;
-  if (c->znorm_cap_trans > 0) n_trans = std::min<int64_t>(n_trans, c->znorm_cap_trans);
+  const int64_t requested = n_trans;  // (before the cap: what decides whether a success lifts it)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  (void)hipGetLastError();
+  if (normals_cap_holds(c, free_b)) n_trans = std::min<int64_t>(n_trans, c->znorm_cap_trans);
   size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
   if (need <= c->znorm_elems) return AHMC_OK;
   if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
@@ -753,13 +770,18 @@ int reserve_normals(Ctx<T>* c, int64_t n_trans) {
     (void)hipGetLastError();
     c->znorm = nullptr;
     if (e != hipErrorOutOfMemory || n_trans <= 1) return fail(c, AHMC_ERR_RUNTIME, std::string("momentum normals: hipMalloc: ") + hipGetErrorString(e));
+    c->znorm_cap_fail_bytes = need * sizeof(T);
     n_trans = (n_trans + 1) / 2;
     c->znorm_cap_trans = n_trans;
     need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
   }
   c->znorm_elems = need;
-  // (the cap is what the device could hold THEN: a later reserve that gets everything it asked for lifts it again)
-  if (c->znorm_cap_trans > 0 && n_trans > c->znorm_cap_trans) c->znorm_cap_trans = 0;
+  // The cap is what the device could hold THEN.  Once memory has been freed (normals_cap_holds: twice the failed allocation is
+  // on offer) the request is no longer clamped, and getting all of it lifts the cap for good.
+  if (c->znorm_cap_trans > 0 && n_trans == requested && requested > c->znorm_cap_trans) {
+    c->znorm_cap_trans = 0;
+    c->znorm_cap_fail_bytes = 0;
+  }
   return AHMC_OK;
 }
 
@@ -1306,6 +1328,11 @@ int32_t ahmc_set_target_plugin(ahmc_ctx* ctx, const char* plugin_so, const void*
       return reject(std::string("compiled from other kernel sources (") + std::string(d->sources_digest).substr(0, 12) + "…) than this library (" +
                     std::string(AHMC_KERNEL_SOURCES_DIGEST).substr(0, 12) + "…): rebuild it (build_target_plugin)");
     if (d->dtype != (sizeof(T) == 4 ? AHMC_F32 : AHMC_F64)) return reject("built for the other element type");
+    {  // (checked whatever the digests say — an empty one skips that check: -D flags can change the layout without changing a source)
+      const TargetOps<T>* po = static_cast<const TargetOps<T>*>(d->ops);
+      if (!po || !po->scratch_layout || po->scratch_layout() != nuts_scratch_layout())
+        return reject("its kernels index another k_nuts scratch layout (AHMC_CKPT / NUTS_* constants) than this library allocates: rebuild it");
+    }
     if (d->G != c->G || d->E != c->E)
       return reject("built for thread geometry (" + std::to_string(d->G) + "," + std::to_string(d->E) + "), the context uses (" + std::to_string(c->G) + "," +
                     std::to_string(c->E) + ")");
@@ -1675,6 +1702,7 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
     if (i_first > 1 && c->adapt_kind == AHMC_ADAPT_STAN && c->adapting && i_first <= n_adapts && c->stan_i != i_first - 1)
       return fail(c, AHMC_ERR_STATE, "sample_from: i_first = " + std::to_string(i_first) + " but the adaptor has seen " + std::to_string(c->stan_i) +
                                          " iterations (restore the checkpoint taken after iteration i_first - 1: ahmc_set_adaptor_state)");
+    c->sched.g_left = 0;  // a timed group of launches never spans two calls (the host time between them would be in its interval)
     T* so = static_cast<T*>(samples_out);
     // the accumulators are reset at the first kept transition — unless the run is being RESUMED beyond it (ahmc_sample_from):
     // then they continue (a checkpoint carries them: ahmc_get/set_accum_state)
@@ -1761,8 +1789,8 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         bool probing = false;   // this launch belongs to a group that is being timed
         auto& sc = c->sched;
         if (draw_batch_env <= 0 && sched_env != 0 && order_refresh && sc.phase != 4 && batch >= 2 * SCHED_MIN) {
-          if (sc.g_left > 0 && sc.g_len > left) sc.g_left = 0;   // a group an earlier call left unfinished (it returned an error, or
-                                                                   // ended inside the group): abandoned, never a launch longer than what is left
+          if (sc.g_left > 0 && sc.g_len > left) sc.g_left = 0;   // (never a launch longer than what is left; a group an earlier call left
+                                                                   // unfinished was dropped at this call's entry)
           if (sc.g_left > 0) {                       // inside a group
             k = sc.g_len; probing = true;
           } else if (!sc.primed && !c->order_from_work && left >= 4 * SCHED_START) {

@@ -84,6 +84,11 @@ void Inst<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t sm
   if (nuts_in_part_b(G, mode)) InstB<T, TK>::nuts(G, E, mode, grid, wpb, smem, s, p);
   else nuts_impl<T, TK, false>(G, E, mode, grid, wpb, smem, s, p);
 }
+template <class T, int TK>
+int64_t Inst<T, TK>::scratch_layout() {
+  const int64_t b = InstB<T, TK>::scratch_layout();
+  return b == nuts_scratch_layout() ? b : -1;
+}
 #endif
 #if !defined(AHMC_INST_PART) || AHMC_INST_PART == 1
 template <class T, int TK>
@@ -94,6 +99,8 @@ template <class T, int TK>
 void InstB<T, TK>::nuts(int G, int E, int mode, unsigned grid, int wpb, size_t smem, hipStream_t s, const KP<T>& p) {
   nuts_impl<T, TK, true>(G, E, mode, grid, wpb, smem, s, p);
 }
+template <class T, int TK>
+int64_t InstB<T, TK>::scratch_layout() { return nuts_scratch_layout(); }
 template struct InstB<AHMC_INST_T, AHMC_INST_TK>;
 #endif
 

@@ -44,6 +44,7 @@ struct Inst {
   static int nuts_occupancy(int G, int E, int mode, size_t smem);  // single-wave workgroups per CU
   static void nuts_set_smem(int G, int E, int mode, size_t smem);
   static void nuts(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
+  static int64_t scratch_layout();  // nuts_scratch_layout() as THIS unit's kernels were compiled (both parts)
 };
 
 // The NUTS kernels come in two PARTS that are compiled with different optimiser settings (round 4, build.py): part B — the
@@ -59,6 +60,7 @@ struct InstB {
   static int nuts_occupancy(int G, int E, int mode, size_t smem);
   static void nuts_set_smem(int G, int E, int mode, size_t smem);
   static void nuts(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
+  static int64_t scratch_layout();
 };
 
 // The launch table of one Inst<T, TK> as plain function pointers: what the host API calls.  The four built-in families
@@ -74,14 +76,15 @@ struct TargetOps {
   int (*nuts_occupancy)(int G, int E, int mode, size_t smem);
   void (*nuts_set_smem)(int G, int E, int mode, size_t smem);
   void (*nuts)(int G, int E, int mode, unsigned grid, int waves_per_block, size_t smem, hipStream_t s, const KP<T>& p);
+  int64_t (*scratch_layout)();   // (AHMC_PLUGIN_ABI 2) the k_nuts scratch layout these kernels index: −1 if the unit's two parts disagree
 };
 template <class T, int TK>
 inline TargetOps<T> make_target_ops() {
   return TargetOps<T>{&Inst<T, TK>::fill_caches, &Inst<T, TK>::refresh, &Inst<T, TK>::leapfrog, &Inst<T, TK>::hmc, &Inst<T, TK>::find_eps,
-                      &Inst<T, TK>::nuts_occupancy, &Inst<T, TK>::nuts_set_smem, &Inst<T, TK>::nuts};
+                      &Inst<T, TK>::nuts_occupancy, &Inst<T, TK>::nuts_set_smem, &Inst<T, TK>::nuts, &Inst<T, TK>::scratch_layout};
 }
 
-constexpr int AHMC_PLUGIN_ABI = 1;  // bump when KP<T>, TargetP<T> or TargetOps<T> change meaning without changing size
+constexpr int AHMC_PLUGIN_ABI = 2;  // bump when KP<T>, TargetP<T> or TargetOps<T> change meaning without changing size
 constexpr int AHMC_TK_PLUGIN = 4;  // the TK of a plugin's instantiation (not an AHMC_TARGET_* code: the API kind is AHMC_TARGET_PLUGIN)
 // what a plugin .so exports under the C name `ahmc_target_plugin_v1` (built by advancedhmc.jl_amd/build.py: build_target_plugin)
 struct TargetPluginDesc {

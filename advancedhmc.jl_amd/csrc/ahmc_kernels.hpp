@@ -90,6 +90,12 @@ constexpr int NUTS_DORMANT = 7;  // vector slots OTH_TH, OTH_R, OTH_G, TREE_A, Z
 #define AHMC_CKPT 1              // k_nuts re-integrates to the candidate from the EDGE its subtree grew from instead of from z0 (ahmc_nuts.hpp); 0: from z0 (rounds 1–4)
 #endif
 constexpr int NUTS_CKPT = AHMC_CKPT ? 6 : 0;   // two (θ, r, g) triples behind the dormant slots, always in global scratch
+// The layout as ONE number: the host's launch plan (ahmc_api.hip, plan_nuts) sizes the scratch the kernels index, and the two may
+// come from different compilations (the instantiation units of a variant build with other -D flags; a target plugin built on
+// another machine).  Every launch table carries the word of ITS translation unit; plan_nuts refuses a table whose word is not the host's.
+constexpr int64_t nuts_scratch_layout() {
+  return (int64_t)NUTS_NSC | (int64_t)NUTS_NSI << 8 | (int64_t)NUTS_NAT << 16 | (int64_t)NUTS_NAI << 24 | (int64_t)NUTS_DORMANT << 32 | (int64_t)NUTS_CKPT << 40;
+}
 
 template <class T, int G, int E>
 struct Geo {

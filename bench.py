@@ -424,6 +424,9 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
                 dom = both[0]
                 roof = {"bound": "valu", "unit": "Gwave-instr/s", "peak": dom.get("peak", VALU_PEAK_GINSTR), "achieved": dom["achieved"], "frac": dom["frac"],
                         "traffic": dom["traffic"], "kernel": dom["kernel"], "counters": counters_src,
+                        # the HBM roof beside the issue roof: SURVEY 8(d)'s state-through-memory model at this kernel's rate, and
+                        # the bytes the counters saw beyond L2 at the same rate, both as fractions of 8 TB/s
+                        "hbm_model_frac": dom.get("hbm_model_frac"), "hbm_measured_frac": dom.get("hbm_measured_frac"),
                         "useful_valu_floor_per_leapfrog": dom.get("useful_valu_floor_per_leapfrog"), "valu_efficiency": dom.get("valu_efficiency"),
                         "peak_definition": ("mix-weighted VALU issue peak of this kernel: N / sum_c n_c * cycles_c over its dynamic instruction classes at 2.4 GHz x "
                                             "1024 SIMDs, cycles_c in {2,4,8,16} per wave64 instruction = the class of each instruction type by its MEASURED rate "
@@ -443,6 +446,8 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
                                     "steps per launch; k_dgemm / k_d_tree2 for the tails of the batches"),
                     "launches_since_create": runs[-1].get("dense_launches"),
                     "hbm_bytes_per_leapfrog_by_counters": dense_bytes, "counters": dense_src,
+                    "hbm_model_frac": (med["leap_adapt"] + med["leap_draw"]) / med["dt"] * algorithmic_bytes_per_leapfrog(D, "dense", itemsize) / 1e9 / HBM_PEAK_GBS,
+                    "hbm_measured_frac": dense_bytes and (med["leap_adapt"] + med["leap_draw"]) / med["dt"] * dense_bytes / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_flops_per_leapfrog": F_lf,
                     "note": "useful leapfrogs x 4 D^2 / wall time of the whole loop (tree kernel, momenta and adaptation included)"}
         out = {
@@ -552,7 +557,7 @@ def _roof_compact(r, with_launches):
         return None
     o = {k: r.get(k) for k in ("bound", "unit", "peak", "achieved", "frac", "traffic")}
     o["kernel"] = (r.get("kernel") or "")[:64]
-    for k in ("valu_efficiency", "device_time_share_of_timed_region", "hbm_bytes_per_leapfrog_by_counters"):
+    for k in ("valu_efficiency", "device_time_share_of_timed_region", "hbm_bytes_per_leapfrog_by_counters", "hbm_model_frac", "hbm_measured_frac"):
         if r.get(k) is not None:
             o[k] = r[k]
     if with_launches:
@@ -633,6 +638,16 @@ def compact_line(full, detail_path=None):
     if len(json.dumps(out)) > LINE_BUDGET:
         for o in out["config"].get("secondary", {}).values():
             o.pop("workload", None)
+    if len(json.dumps(out)) > LINE_BUDGET:
+        # last resort — a record must ALWAYS come out: the contract's headline keys, the roofline's and the CPU baseline's numbers,
+        # the workload and where the rest is
+        out = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                   "dtype", "data")}
+        out["config"] = {"workload": c["workload"][:200], "detail": detail_path, "line_shortened": "over the size budget: headline only"}
+        r, b = full.get("roofline") or {}, full.get("cpu_baseline") or {}
+        out["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        out["cpu_baseline"] = {k: b.get(k) for k in ("value", "unit", "cores", "kind")}
+        out = _sig(out)
     return out
 
 
@@ -713,36 +728,47 @@ def main():
             except Exception as ex:  # a secondary config must never take the headline down with it
                 o = {"error": repr(ex)} if rank == 0 else None
                 if dist is not None and not isinstance(ex, SetupFailed):
-                    # one rank failing INSIDE the loop leaves the others waiting in its collectives: no way to agree any more — say so
-                    # on stderr and stop running secondaries on this rank (the headline is already computed; setup failures — the
-                    # likely ones: memory — are agreed on by all ranks before the first collective, see run_config)
+                    # one rank failing INSIDE the loop leaves the others waiting in its collectives: no way to agree any more (setup
+                    # failures — the likely ones: memory — are agreed on by all ranks before the first collective, see run_config).
+                    # Rank 0 still prints the headline it has (computed by all ranks before any secondary); every other rank that
+                    # fails exits non-zero, which makes the launcher (torch.distributed.run) end the whole job instead of leaving
+                    # the others in a collective for ever.
                     print(f"bench.py rank {rank}: {name} failed after setup: {ex!r}", file=sys.stderr, flush=True)
-                    break
+                    if rank != 0:
+                        os._exit(3)
+                    out["config"]["secondary"] = dict(sec, **{name: o})
+                    out["config"]["aborted"] = f"{name} failed after setup on rank 0"
+                    _print_line(out, args)
+                    os._exit(3)
             if rank == 0:
                 sec[name] = o
         if rank == 0:
             out["config"]["secondary"] = sec
     if rank == 0:
-        try:  # RCCL writes its version banner to the C stdout when the first communicator is made: push it out first, so
-            ctypes.CDLL(None).fflush(None)  # that the JSON line is the LAST line of stdout whatever the buffering
-        except Exception:
-            pass
-        detail = None
-        if args.detail:
-            try:  # the full record (instruction mixes, every run, definitions, ESS prose): a side file, named in the line
-                detail = args.detail if os.path.isabs(args.detail) else os.path.join(ROOT, args.detail)
-                os.makedirs(os.path.dirname(detail), exist_ok=True)
-                with open(detail, "w") as f:
-                    json.dump(out, f, indent=1)
-            except OSError as ex:
-                detail = None
-                print(f"bench.py: cannot write {args.detail}: {ex}", file=sys.stderr)
-        line = json.dumps(compact_line(out, os.path.relpath(detail, ROOT) if detail else None))
-        assert len(line) <= LINE_BUDGET, len(line)
-        print(line, flush=True)             # flushed NOW: with a process group alive the interpreter's exit path (RCCL / c10d
-        sys.stdout.flush()                  # teardown) was seen to drop a block-buffered stdout — the line must not depend on it
+        _print_line(out, args)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _print_line(out, args):
+    """rank 0: the full record to the detail file, its compact form as the LAST line of stdout"""
+    try:  # RCCL writes its version banner to the C stdout when the first communicator is made: push it out first, so
+        ctypes.CDLL(None).fflush(None)  # that the JSON line is the LAST line of stdout whatever the buffering
+    except Exception:
+        pass
+    detail = None
+    if args.detail:
+        try:  # the full record (instruction mixes, every run, definitions, ESS prose): a side file, named in the line
+            detail = args.detail if os.path.isabs(args.detail) else os.path.join(ROOT, args.detail)
+            os.makedirs(os.path.dirname(detail), exist_ok=True)
+            with open(detail, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as ex:
+            detail = None
+            print(f"bench.py: cannot write {args.detail}: {ex}", file=sys.stderr)
+    line = json.dumps(compact_line(out, os.path.relpath(detail, ROOT) if detail else None))  # (never over LINE_BUDGET: compact_line's last resort)
+    print(line, flush=True)             # flushed NOW: with a process group alive the interpreter's exit path (RCCL / c10d
+    sys.stdout.flush()                  # teardown) was seen to drop a block-buffered stdout — the line must not depend on it
 
 
 if __name__ == "__main__":

@@ -422,13 +422,24 @@ end
 #     defining the C symbol of include/ahmc_user_target_object.h (`ahmc_user_logdensity_f64` / `_f32`).  The build helper links it with the
 #     engine's fused kernels under device LTO (the density is inlined into the leaf loop: built-in speed, INTEGRATION.md §3c) and the result
 #     is bound like (2).  (G, E) of the context: AHMC_INFO_GROUP_LANES = 0, AHMC_INFO_ELEMS_PER_LANE = 1 of ahmc_get_info.
-function set_target_object!(z::MI355XChains{T}, object_or_bitcode::AbstractString, params::Vector{T}=T[]; python::AbstractString="python") where {T}
+function set_target_object!(z::MI355XChains{T}, object_or_bitcode::AbstractString, params::Vector{T}=T[]; python::AbstractString="python",
+                            repo::AbstractString=get(ENV, "AHMC_REPO", normpath(joinpath(@__DIR__, "..")))) where {T}
+    isfile(object_or_bitcode) || throw(ArgumentError("set_target_object!: no such file: $(repr(object_or_bitcode))"))
     G, E = Ref{Int64}(0), Ref{Int64}(0)
     check(z.ctx, ccall((:ahmc_get_info, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), z.ctx, 0, G))
     check(z.ctx, ccall((:ahmc_get_info, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), z.ctx, 1, E))
     dt = T === Float32 ? "float32" : "float64"
-    code = "from ahmc_amd.build import build_target_plugin_from_object as b; print(b(r'$(object_or_bitcode)', '$(dt)', $(G[]), $(E[]), $(length(params))))"
-    plugin_so = strip(read(`$python -c $code`, String))
+    # the path and every number travel as ARGUMENTS (sys.argv), never inside the program text: a quote in a path is a quote in a path.
+    # `repo` (the checkout that holds ahmc_amd.py) goes on sys.path, so the helper does not depend on what the `python` on PATH can import.
+    code = "import sys; sys.path.insert(0, sys.argv[6]); from ahmc_amd.build import build_target_plugin_from_object as b; " *
+           "print(b(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])))"
+    out, err = IOBuffer(), IOBuffer()
+    cmd = `$python -c $code $(abspath(object_or_bitcode)) $dt $(G[]) $(E[]) $(length(params)) $repo`
+    proc = run(pipeline(ignorestatus(cmd); stdout=out, stderr=err))
+    success(proc) || error("set_target_object!: the build helper failed (exit $(proc.exitcode)):\n" * String(take!(err)))
+    lines = split(strip(String(take!(out))), '\n')
+    plugin_so = isempty(lines) ? "" : String(strip(lines[end]))
+    isfile(plugin_so) || error("set_target_object!: the build helper returned $(repr(plugin_so)), which is not a file")
     set_target_plugin!(z, plugin_so, params)
 end
 

@@ -464,6 +464,20 @@ inline Termination operator*(Termination a, Termination b) {
 }
 inline bool isterminated(Termination t) { return t.dynamic || t.numerical; }
 
+// ---- decision margins (round 6; the checker's own instrument, no counterpart in the reference) ----
+// Every data-dependent decision of a transition is a comparison `a < b` of two floating-point quantities.  Another correct
+// implementation (other summation order, FMA contraction, a last-ulp libm difference) may take the other branch ONLY where the two
+// sides are within rounding of each other.  The oracle therefore records, per chain, the smallest RELATIVE distance |a − b| / scale
+// any decision had since the record was last reset (`ahmco_decision_margin`), and the parity tests allow a chain to differ from
+// the oracle only if that distance is below a stated bound — everything else must match exactly.  `scale` is the magnitude the
+// rounding error of the comparison scales with: Σ|ρ_d·v_d| for a U-turn dot product, max(1, |H0|, |H′|) for energy tests,
+// n for the slice sampler's integer rule.  A comparison with a non-finite side is decided by the non-finiteness: not recorded.
+inline void note_margin(double* acc, double a, double b, double scale) {
+  if (!acc || !std::isfinite(a) || !std::isfinite(b) || !std::isfinite(scale)) return;
+  const double m = std::abs(a - b) / (scale > 1e-300 ? scale : 1e-300);
+  if (m < *acc) *acc = m;
+}
+
 template <class T>
 inline T maxabs(T a, T b) {  // :526
   return std::abs(a) > std::abs(b) ? a : b;
@@ -519,6 +533,8 @@ struct NutsEnv {
   const NutsCfg<T>* cfg;
   const Rng* rng;
   uint32_t draw = 0;  // sequential index of the scalar draws of this transition
+  double* margin = nullptr;  // per-chain decision-margin record (note_margin), or none
+  double h_scale = 1.0;      // max(1, |H0|) of the transition: the scale of its energy comparisons' rounding error
 };
 
 template <class T>
@@ -529,9 +545,19 @@ inline T dot(const Vec<T>& a, const Vec<T>& b) {
 }
 
 template <class T>
+inline double absdot(const Vec<T>& a, const Vec<T>& b) {  // Σ|a_d·b_d|: what the rounding error of dot(a, b) scales with
+  double s = 0;
+  for (size_t d = 0; d < a.size(); ++d) s += std::abs((double)a[d] * (double)b[d]);
+  return s;
+}
+
+template <class T>
 inline bool generalised_uturn_criterion(const Vec<T>& rho, const Vec<T>& pm,
-                                        const Vec<T>& pp) {  // :619-621
-  return (dot(rho, pm) <= 0) || (dot(rho, pp) <= 0);
+                                        const Vec<T>& pp, double* margin = nullptr) {  // :619-621
+  const T dm = dot(rho, pm), dp = dot(rho, pp);
+  note_margin(margin, (double)dm, 0.0, absdot(rho, pm));
+  note_margin(margin, (double)dp, 0.0, absdot(rho, pp));
+  return (dm <= 0) || (dp <= 0);
 }
 
 template <class T>
@@ -554,10 +580,14 @@ Termination uturn(const NutsEnv<T>& e, const BinaryTree<T>& t, const BinaryTree<
       ndth[d] = -dth[d];
       nr0[d] = -t.zleft->r[d];
     }
-    bool s = (dot(dth, dHdr_vec(m, nr0)) >= 0) || (dot(ndth, dHdr_vec(m, t.zright->r)) >= 0);
+    const Vec<T> v0 = dHdr_vec(m, nr0), v1 = dHdr_vec(m, t.zright->r);
+    const T d0 = dot(dth, v0), d1 = dot(ndth, v1);
+    note_margin(e.margin, (double)d0, 0.0, absdot(dth, v0));
+    note_margin(e.margin, (double)d1, 0.0, absdot(ndth, v1));
+    bool s = (d0 >= 0) || (d1 >= 0);
     return Termination{s, false};
   }
-  bool s1 = generalised_uturn_criterion(t.rho, dHdr_vec(m, t.zleft->r), dHdr_vec(m, t.zright->r));  // :566-570
+  bool s1 = generalised_uturn_criterion(t.rho, dHdr_vec(m, t.zleft->r), dHdr_vec(m, t.zright->r), e.margin);  // :566-570
   if (e.cfg->criterion == AHMC_TC_GENERALISED) return Termination{s1, false};
   // Strict (:579-617)
   Vec<T> rho2(m.D), rho3(m.D);
@@ -565,8 +595,8 @@ Termination uturn(const NutsEnv<T>& e, const BinaryTree<T>& t, const BinaryTree<
     rho2[d] = tl.rho[d] + tr.zleft->r[d];   // check_left_subtree :597-601
     rho3[d] = tl.zright->r[d] + tr.rho[d];  // check_right_subtree :609-615
   }
-  bool s2 = generalised_uturn_criterion(rho2, dHdr_vec(m, t.zleft->r), dHdr_vec(m, tr.zleft->r));
-  bool s3 = generalised_uturn_criterion(rho3, dHdr_vec(m, tl.zright->r), dHdr_vec(m, t.zright->r));
+  bool s2 = generalised_uturn_criterion(rho2, dHdr_vec(m, t.zleft->r), dHdr_vec(m, tr.zleft->r), e.margin);
+  bool s3 = generalised_uturn_criterion(rho3, dHdr_vec(m, tl.zright->r), dHdr_vec(m, t.zright->r), e.margin);
   return Termination{s1, false} * Termination{s2, false} * Termination{s3, false};
 }
 
@@ -578,6 +608,7 @@ Sampler<T> leaf_sampler(const NutsEnv<T>& e, const Sampler<T>& s, T H0, const PR
   if (e.cfg->sampler == AHMC_TS_SLICE) {
     o.lu = s.lu;
     o.n = (s.lu <= -energy(*z)) ? 1 : 0;  // Int(s.ℓu <= neg_energy(zcand))
+    note_margin(e.margin, (double)s.lu, (double)-energy(*z), std::max(1.0, std::max(std::abs((double)H0), std::abs((double)s.lu))));
   } else {
     o.lw = H0 + (-energy(*z));  // H0 + neg_energy(zcand)
   }
@@ -593,10 +624,13 @@ Sampler<T> combine_rng(NutsEnv<T>& e, const Sampler<T>& s1, const Sampler<T>& s2
     o.lu = s1.lu;
     T u = (T)e.rng->seq_uniform(e.draw++);
     o.zcand = (T(o.n) * u < T(s1.n)) ? s1.zcand : s2.zcand;
+    if (o.n > 0) note_margin(e.margin, (double)(T(o.n) * u), (double)T(s1.n), (double)o.n);   // (n = 0: 0 < 0, exact on any implementation)
   } else {
     o.lw = logaddexp(s1.lw, s2.lw);
     T ex = (T)e.rng->seq_randexp(e.draw++);
     o.zcand = (o.lw < s1.lw + ex) ? s1.zcand : s2.zcand;
+    // (log weights are energy DIFFERENCES H0 − H′: their rounding error scales with the energies, |H0| — passed in by the caller)
+    note_margin(e.margin, (double)o.lw, (double)(s1.lw + ex), e.h_scale);
   }
   return o;
 }
@@ -604,7 +638,12 @@ Sampler<T> combine_rng(NutsEnv<T>& e, const Sampler<T>& s1, const Sampler<T>& s2
 // Termination(sampler, nt, H0, H′): divergence test (:500-507)
 template <class T>
 Termination leaf_termination(const NutsEnv<T>& e, const Sampler<T>& s, T H0, T Hp) {
-  if (e.cfg->sampler == AHMC_TS_SLICE) return Termination{false, !(s.lu < e.cfg->delta_max + -Hp)};
+  const double sc = std::max(std::max(e.h_scale, std::abs((double)Hp)), std::abs((double)e.cfg->delta_max));
+  if (e.cfg->sampler == AHMC_TS_SLICE) {
+    note_margin(e.margin, (double)s.lu, (double)(e.cfg->delta_max + -Hp), sc);
+    return Termination{false, !(s.lu < e.cfg->delta_max + -Hp)};
+  }
+  note_margin(e.margin, (double)-H0, (double)(e.cfg->delta_max + -Hp), sc);
   return Termination{false, !(-H0 < e.cfg->delta_max + -Hp)};
 }
 
@@ -673,6 +712,7 @@ PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0v, TStat<T>&
   PRef<T> z0p = std::make_shared<PhasePoint<T>>(z0v);
   const PhasePoint<T>& z0 = *z0p;
   T H0 = energy(z0);
+  e.h_scale = std::isfinite((double)H0) ? std::max(1.0, std::abs((double)H0)) : 1.0;
   BinaryTree<T> tree;
   tree.zleft = z0p;
   tree.zright = z0p;
@@ -710,9 +750,11 @@ PhasePoint<T> nuts_transition(NutsEnv<T>& e, const PhasePoint<T>& z0v, TStat<T>&
       if (e.cfg->sampler == AHMC_TS_SLICE) {
         T u = (T)e.rng->seq_uniform(e.draw++);
         acc = T(sampler.n) * u < T(sub.sampler.n);  // :202
+        if (sampler.n > 0) note_margin(e.margin, (double)(T(sampler.n) * u), (double)T(sub.sampler.n), (double)sampler.n);
       } else {
         T ex = (T)e.rng->seq_randexp(e.draw++);
         acc = sampler.lw < sub.sampler.lw + ex;  // :203-206
+        note_margin(e.margin, (double)sampler.lw, (double)(sub.sampler.lw + ex), e.h_scale);
       }
       if (acc) zcand = sub.sampler.zcand;
     }
@@ -797,6 +839,8 @@ struct Ctx : CtxBase {
   uint64_t seed = 0, chain_offset = 0, chain_stride = 1, iteration = 0;
   // stats of the last transition
   std::vector<TStat<T>> stat;
+  // smallest relative margin of any decision a chain took since the record was last reset (note_margin, ahmco_decision_margin)
+  std::vector<double> margin;
   // adaptation
   int adapt_kind = AHMC_ADAPT_NONE;
   T da_delta = T(0.8), da_gamma = T(0.05), da_t0 = T(10), da_kappa = T(0.75);
@@ -987,8 +1031,9 @@ PhasePoint<T> refresh(Ctx<T>* c, int64_t i, const PhasePoint<T>& z, T alpha) {
 
 // mh_accept_ratio (src/trajectory.jl:855-880)
 template <class T>
-inline void mh_accept_ratio(const Rng& rng, uint32_t draw, T H, T Hp, bool& accept, T& alpha) {
+inline void mh_accept_ratio(const Rng& rng, uint32_t draw, T H, T Hp, bool& accept, T& alpha, double* margin = nullptr) {
   accept = Hp < H + (T)rng.randexp(RNG_TRANSITION, draw);
+  note_margin(margin, (double)Hp, (double)(H + (T)rng.randexp(RNG_TRANSITION, draw)), std::max(1.0, std::max(std::abs((double)H), std::abs((double)Hp))));
   alpha = jl_min(T(1), std::exp(H - Hp));
 }
 
@@ -1009,7 +1054,7 @@ void hmc_transition_chain(Ctx<T>* c, int64_t i, int64_t L, int sampler, int64_t 
   if (sampler == AHMC_TS_ENDPOINT) {
     int64_t nst = (stop_at >= 0 && stop_at < L) ? stop_at : L;
     zp = leapfrog_step(lf, c->target, m, z, nst, true);
-    mh_accept_ratio(rng, 0, energy(z), energy(zp), is_accept, alpha);
+    mh_accept_ratio(rng, 0, energy(z), energy(zp), is_accept, alpha, &c->margin[i]);
   } else {
     std::vector<PhasePoint<T>> fwd, bwd;
     leapfrog_step(lf, c->target, m, z, n_fwd_coupled, true, &fwd);
@@ -1031,7 +1076,11 @@ void hmc_transition_chain(Ctx<T>* c, int64_t i, int64_t L, int sampler, int64_t 
     T u = (T)rng.uniform(RNG_TRANSITION, 0);
     T cum = 0;
     size_t idx = 0;
-    while (cum < u && idx < zs.size()) cum += std::exp(lw[idx++] - lse);
+    while (cum < u && idx < zs.size()) {
+      note_margin(&c->margin[i], (double)cum, (double)u, 1.0);   // (probabilities: the cumulative sums live on [0, 1])
+      cum += std::exp(lw[idx++] - lse);
+    }
+    if (idx < zs.size()) note_margin(&c->margin[i], (double)cum, (double)u, 1.0);   // the comparison that ended the scan
     if (idx < 1) idx = 1;
     zp = *zs[idx - 1];
     is_accept = true;
@@ -1156,6 +1205,7 @@ int nuts_transition_all(Ctx<T>* c, int max_depth, double delta_max, int criterio
     Rng rng = c->rng(i, c->iteration);
     PhasePoint<T> z = refresh(c, i, c->load(i), refresh_alpha);
     NutsEnv<T> e{&lf, &c->target, &m, &cfg, &rng, 0};
+    e.margin = &c->margin[i];
     PhasePoint<T> zc = nuts_transition(e, z, c->stat[i]);
     c->store(i, zc);
   }
@@ -1180,13 +1230,17 @@ T find_good_stepsize_chain(Ctx<T>* c, int64_t i, T init, int max_n_iters) {
     lf.eps = e;
     return energy(leapfrog_step(lf, c->target, m, z, 1, true));
   };
+  double* mg = &c->margin[i];
+  const double hs = std::isfinite((double)H) ? std::max(1.0, std::abs((double)H)) : 1.0;
   T Hp = A(eps);
   T dH = H - Hp;
   bool too_high = dH > log_a_cross;
+  note_margin(mg, (double)dH, (double)log_a_cross, hs);
   for (int it = 0; it < max_n_iters; ++it) {
     epsp = too_high ? d * eps : invd * eps;
     Hp = A(eps);  // Q3: evaluated at ϵ, not ϵ′ (src/trajectory.jl:799-800)
     dH = H - Hp;
+    note_margin(mg, (double)dH, (double)log_a_cross, hs);
     if (too_high != (dH > log_a_cross)) break;
     eps = epsp;
   }
@@ -1196,6 +1250,8 @@ T find_good_stepsize_chain(Ctx<T>* c, int64_t i, T init, int max_n_iters) {
     T mid = eps / 2 + epsp / 2;  // Statistics.middle
     Hp = A(mid);
     dH = H - Hp;
+    note_margin(mg, (double)dH, (double)log_a_max, hs);
+    note_margin(mg, (double)dH, (double)log_a_min, hs);
     if (dH > log_a_max) eps = mid;
     else if (dH < log_a_min) epsp = mid;
     else { eps = mid; break; }
@@ -1271,6 +1327,7 @@ void ext_chain_body(Ctx<T>* c, int64_t i) {
       Rng rng = c->rng(i, c->iteration);
       PhasePoint<T> z = refresh(c, i, c->load(i), (T)x.cfg.refresh_alpha);
       NutsEnv<T> e{&lf, &c->target, &m, &cfg, &rng, 0};
+      e.margin = &c->margin[i];
       PhasePoint<T> zc = nuts_transition(e, z, c->stat[i]);
       c->store(i, zc);
     } else {
@@ -1647,6 +1704,7 @@ int32_t ahmc_create(int32_t device, int32_t dtype, int64_t D, int64_t N, void* s
     c->lp.assign(N, T(0)); c->lk.assign(N, T(0));
     c->eps_nom.assign(N, T(0.1)); c->eps_cur.assign(N, T(0.1));
     c->stat.assign(N, TStat<T>());
+    c->margin.assign(N, std::numeric_limits<double>::infinity());
   };
   if (dtype == AHMC_F32) { auto* c = new Ctx<float>(); init(c); *out = reinterpret_cast<ahmc_ctx*>(static_cast<CtxBase*>(c)); }
   else { auto* c = new Ctx<double>(); init(c); *out = reinterpret_cast<ahmc_ctx*>(static_cast<CtxBase*>(c)); }
@@ -1679,6 +1737,19 @@ int32_t ahmco_set_num_threads(int32_t n) {
 
 int32_t ahmco_set_ref_compat(ahmc_ctx* ctx, int32_t on) {
   FOR_CTX(ctx, { c->ref_compat = on != 0; return AHMC_OK; });
+}
+
+// oracle-only: out[N] = per chain, the smallest relative margin (note_margin) of any decision taken since the record was last
+// reset — U-turn dot products against 0, `ℓw < ℓw₁ + e` (progressive sampling, both levels), the slice rules, the divergence test,
+// the MH test, the multinomial index scan, the crossings of find_good_stepsize — +inf if none; reset != 0 starts a new record.
+int32_t ahmco_decision_margin(ahmc_ctx* ctx, double* out, int32_t reset) {
+  FOR_CTX(ctx, {
+    for (int64_t i = 0; i < c->N; ++i) {
+      if (out) out[i] = c->margin[(size_t)i];
+      if (reset) c->margin[(size_t)i] = std::numeric_limits<double>::infinity();
+    }
+    return AHMC_OK;
+  });
 }
 
 int32_t ahmc_set_target(ahmc_ctx* ctx, int32_t kind, const void* params, int64_t n_params) {

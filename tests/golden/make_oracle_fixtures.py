@@ -37,13 +37,22 @@ def build_case(name, lib):
     return e, mk(lf), n
 
 
-def run_case(name, lib):
+def run_case(name, lib, with_margin=False):
+    """with_margin (the oracle only): per transition, the chains' smallest decision margin (tests/parity_util.py) — what lets the GPU
+    test demand exact agreement except at the oracle's own near-ties"""
     e, k, n = build_case(name, lib)
     out = {}
+    if with_margin:
+        sys.path.insert(0, os.path.join(HERE, ".."))
+        import parity_util as PU
+
+        PU.reset_margin(e)
     for it in range(n):
         e.transition(k)
         s = e.stats()
         z = e.phasepoint()
+        if with_margin:
+            out[f"{name}/margin{it}"] = PU.decision_margin(e)
         out[f"{name}/theta{it}"] = z.theta.copy()
         out[f"{name}/n_steps{it}"] = s["n_steps"].copy()
         out[f"{name}/H{it}"] = s["hamiltonian_energy"].copy()
@@ -56,7 +65,7 @@ if __name__ == "__main__":
     lib = _capi.CLib(build())
     data = {}
     for name in CASES:
-        data.update(run_case(name, lib))
+        data.update(run_case(name, lib, with_margin=True))
     path = os.path.join(HERE, "oracle_fixtures.npz")
     np.savez_compressed(path, **data)
     print("wrote", path, os.path.getsize(path), "bytes")

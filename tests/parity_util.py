@@ -1,0 +1,104 @@
+"""Margin-aware parity (round 6): a chain may differ from the oracle ONLY where the oracle itself was within rounding of a tie.
+
+Every data-dependent decision of a transition is a comparison of two floating-point numbers: a U-turn dot product against 0
+(src/trajectory.jl:551-623), `ℓw < ℓw₁ + e` of the progressive sampling (:178-206), the slice rules (:163-176,:202), the divergence
+test (:500-507), the MH test (:855-880), the multinomial index scan (src/utilities.jl:92-103), the crossings of find_good_stepsize
+(:768-837).  Two correct implementations — the oracle's scalar loop and the HIP kernels' wave reductions with FMA contraction — can
+take different branches only where the two sides of such a comparison are within the rounding error of each other.  The oracle
+records the smallest RELATIVE distance |a − b| / scale of any decision a chain took (oracle/ahmc_oracle.cpp: note_margin,
+`ahmco_decision_margin`); the tests here demand
+
+    differs(chain)  ⇒  margin(chain) < MARGIN_BOUND[dtype]
+
+and EXACT agreement of every discrete statistic everywhere else.  That replaces round 1–5's "≥ 99.9 % / 97 % / 90 % of the chains
+agree" thresholds, which would have hidden a rare real defect.  `MAX_NEAR_TIES` keeps the filter honest: if more than that share
+of the chains sat on a near-tie, the bound is explaining too much and the test fails.
+
+Every comparison is also logged (`RECORDS`): tests/conftest.py prints the suite's totals and writes them to
+gpurun_out/parity_margins.json — flips seen, the largest margin among them (how close the bound is to being needed) and the
+smallest margin among the chains that AGREED (how far the implementations are from flipping unexplained).
+"""
+import ctypes as C
+
+import numpy as np
+
+# a chain may differ from the oracle only if one of its decisions had a relative margin below this
+MARGIN_BOUND = {np.dtype(np.float64): 1e-9, np.dtype(np.float32): 1e-3}
+# … and at most this share of the chains of one comparison may sit on such a near-tie (f32: ~10² decisions per transition at a
+# per-decision probability of ~1e-3 each)
+MAX_NEAR_TIES = {np.dtype(np.float64): 0.002, np.dtype(np.float32): 0.35}
+
+RECORDS = []  # (what, dtype name, n_chains, n_differ, n_near_tie, max margin among differing, min margin among agreeing)
+
+
+def _bind(lib):
+    f = lib.dll.ahmco_decision_margin  # (the CPU checker only: the product library has no such symbol — AttributeError on it)
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    return f
+
+
+def decision_margin(o, reset=True):
+    """per chain: the smallest relative margin of any decision the ORACLE engine `o` took since the last reset (+inf: none)"""
+    out = np.empty(o.N, dtype=np.float64)
+    rc = _bind(o.lib)(o._ctx, out.ctypes.data_as(C.c_void_p), 1 if reset else 0)
+    assert rc == 0, rc
+    return out
+
+
+def reset_margin(o):
+    rc = _bind(o.lib)(o._ctx, None, 1)
+    assert rc == 0, rc
+
+
+def bound(dtype):
+    return MARGIN_BOUND[np.dtype(dtype)]
+
+
+def check_flips(same, margin, dtype, what="", sel=None, max_near_ties=None):
+    """`same`: per chain, did the HIP engine agree with the oracle on everything discrete; `margin`: decision_margin(o) over the
+    same span of transitions.  Fails unless every disagreeing chain had a near-tie.  `sel` restricts the check to a subset of the
+    chains (e.g. the numerically stable ones of a warm-up iteration).  Returns the mask of chains that may be compared further."""
+    same = np.asarray(same, dtype=bool)
+    margin = np.asarray(margin, dtype=np.float64)
+    dt = np.dtype(dtype)
+    b = MARGIN_BOUND[dt]
+    on = np.ones_like(same) if sel is None else np.asarray(sel, dtype=bool)
+    near = margin < b
+    differ = ~same & on
+    unexplained = differ & ~near
+    n = int(on.sum())
+    RECORDS.append((what, dt.name, n, int(differ.sum()), int((near & on).sum()),
+                    float(margin[differ].max()) if differ.any() else None,
+                    float(margin[same & on].min()) if (same & on).any() else None))
+    assert not unexplained.any(), (
+        f"{what}: {int(unexplained.sum())} of {n} chains took another decision than the oracle although no decision of theirs was within "
+        f"{b:g} of a tie (chains {np.flatnonzero(unexplained)[:8].tolist()}, their margins {margin[unexplained][:8].tolist()})")
+    cap = MAX_NEAR_TIES[dt] if max_near_ties is None else max_near_ties
+    # (small batches: one near-tie among 24 chains is 4 % — allow two whatever N is)
+    assert (near & on).sum() <= max(2, cap * n), (
+        f"{what}: {int((near & on).sum())} of {n} chains sat within {b:g} of a tie — the bound explains too much")
+    return same & on
+
+
+def check_equal_or_near_tie(a, b, margin, dtype, what=""):
+    """element-wise results that follow from decisions alone (find_good_stepsize's powers of two and bisection midpoints):
+    identical unless the chain had a near-tie"""
+    return check_flips(np.asarray(a) == np.asarray(b), margin, dtype, what)
+
+
+def summary():
+    """suite totals per dtype: comparisons, chains, flips, near-ties, the largest margin a flip needed, the smallest margin that still agreed"""
+    out = {}
+    for what, dt, n, nd, nn, mx, mn in RECORDS:
+        o = out.setdefault(dt, {"comparisons": 0, "chains": 0, "flips": 0, "near_ties": 0, "largest_margin_of_a_flip": None,
+                                "smallest_margin_that_agreed": None, "bound": MARGIN_BOUND[np.dtype(dt)]})
+        o["comparisons"] += 1
+        o["chains"] += n
+        o["flips"] += nd
+        o["near_ties"] += nn
+        if mx is not None:
+            o["largest_margin_of_a_flip"] = mx if o["largest_margin_of_a_flip"] is None else max(o["largest_margin_of_a_flip"], mx)
+        if mn is not None:
+            o["smallest_margin_that_agreed"] = mn if o["smallest_margin_that_agreed"] is None else min(o["smallest_margin_that_agreed"], mn)
+    return out

@@ -67,6 +67,20 @@ def test_product_loader_has_no_fallback(monkeypatch, tmp_path):
     monkeypatch.setattr(A.capi, "_HIP_LIB", None)
 
 
+def test_dry_run_on_the_oracle_is_never_green():
+    """AHMC_TEST_DRYRUN_ON_ORACLE=1 binds the `hip` fixture to the CPU checker (to debug test code without a GPU): such a run
+    must not produce a single PASSED gpu test (tests/conftest.py: every one that ran through is a skip with the reason)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, AHMC_TEST_DRYRUN_ON_ORACLE="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-k",
+                          "test_refresh_momentum", "-rs", "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    tail = out.stdout.strip().splitlines()[-1]
+    assert "skipped" in tail and "passed" not in tail and "failed" not in tail, out.stdout[-2000:]
+    assert "says nothing about the HIP engine" in out.stdout
+
+
 def test_package_never_references_the_oracle():
     pkg = os.path.join(ROOT, "advancedhmc.jl_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -2,15 +2,18 @@
 
 Tolerances (north_star: "within a stated fp tolerance"):
   Float64: 1e-9 relative on energies/positions after a transition (the two sides differ only by
-           FMA contraction and libm-vs-ocml last-ulp differences in log/exp/sincos); discrete
-           statistics (n_steps, tree_depth, is_accept) must agree on >= 99.9 % of chains.
-  Float32: 2e-3 relative on single leapfrog trajectories; discrete statistics >= 90 % per
-           transition (decisions sit within 1e-7 of a tie far more often), plus moment checks.
+           FMA contraction and libm-vs-ocml last-ulp differences in log/exp/sincos).
+  Float32: 2e-3 relative on single leapfrog trajectories, plus moment checks.
+  Discrete statistics (n_steps, tree_depth, is_accept, numerical_error), both types, since round 6: EXACT on every chain —
+           except a chain one of whose decisions the oracle itself took within 1e-9 (f64) / 1e-3 (f32) RELATIVE of a tie
+           (tests/parity_util.py: the oracle reports the margin of every U-turn, sampling, divergence and MH comparison).
+           Rounds 1–5 accepted "≥ 99.9 % / 97 % / 90 % of the chains agree"; those thresholds are gone.
 """
 import numpy as np
 import pytest
 
 import ahmc_amd as A
+import parity_util as PU
 
 pytestmark = pytest.mark.gpu
 
@@ -183,10 +186,13 @@ def realign(g, o, same):
         o.set_position(th)
 
 
-def compare_transition_stats(sg, so, dtype, min_match):
-    same = (sg["n_steps"] == so["n_steps"]) & (sg["is_accept"] == so["is_accept"]) & (sg["tree_depth"] == so["tree_depth"])
-    frac = same.mean()
-    assert frac >= min_match, f"only {frac:.4f} of chains took the same discrete decisions"
+def compare_transition_stats(sg, so, dtype, o, what="transition", sel=None):
+    """stats of the HIP engine against the oracle engine `o`'s after the same transition(s): every discrete statistic identical on
+    every chain unless the oracle took one of that chain's decisions within PU.bound(dtype) of a tie (the margin record of `o` is
+    read AND reset: one comparison per span of transitions); the continuous statistics to tolerance on the agreeing chains."""
+    same = ((sg["n_steps"] == so["n_steps"]) & (sg["is_accept"] == so["is_accept"]) & (sg["tree_depth"] == so["tree_depth"])
+            & (sg["numerical_error"] == so["numerical_error"]))
+    same = PU.check_flips(same, PU.decision_margin(o), dtype, what, sel=sel)
     rt = RTOL[dtype] * 100
     for k in ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error",
               "max_hamiltonian_energy_error", "step_size"):
@@ -195,10 +201,10 @@ def compare_transition_stats(sg, so, dtype, min_match):
     return same
 
 
-@pytest.mark.parametrize("dtype,min_match", [(np.float64, 0.999), (np.float32, 0.9)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("TS", [A.EndPointTS, A.MultinomialTS])
 @pytest.mark.parametrize("metric", ["unit", "diag_chain"])
-def test_static_hmc_transitions(hip, oracle, rng, dtype, min_match, TS, metric):
+def test_static_hmc_transitions(hip, oracle, rng, dtype, TS, metric):
     """static transition (src/trajectory.jl:271-390, :855-880): 5 consecutive transitions"""
     D, N = 5, 512
     h = A.Hamiltonian(make_metric(metric, D, N, rng), A.IsoGaussian(D))
@@ -210,7 +216,7 @@ def test_static_hmc_transitions(hip, oracle, rng, dtype, min_match, TS, metric):
     for it in range(5):
         for e in (g, o):
             e.transition(k)
-        same = compare_transition_stats(g.stats(), o.stats(), dtype, min_match)
+        same = compare_transition_stats(g.stats(), o.stats(), dtype, o, "static hmc")
         if dtype == np.float64:
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
@@ -218,10 +224,10 @@ def test_static_hmc_transitions(hip, oracle, rng, dtype, min_match, TS, metric):
         realign(g, o, same)
 
 
-@pytest.mark.parametrize("dtype,min_match", [(np.float64, 0.999), (np.float32, 0.9)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("TS", [A.MultinomialTS, A.SliceTS])
 @pytest.mark.parametrize("TC", [A.GeneralisedNoUTurn, A.ClassicNoUTurn, A.StrictGeneralisedNoUTurn])
-def test_nuts_transitions(hip, oracle, rng, dtype, min_match, TS, TC):
+def test_nuts_transitions(hip, oracle, rng, dtype, TS, TC):
     """dynamic transition + build_tree (src/trajectory.jl:626-742): iterative kernel == recursion"""
     D, N = 10, 1024
     h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), A.IsoGaussian(D))
@@ -234,7 +240,7 @@ def test_nuts_transitions(hip, oracle, rng, dtype, min_match, TS, TC):
         for e in (g, o):
             e.transition(k)
         sg, so = g.stats(), o.stats()
-        same = compare_transition_stats(sg, so, dtype, min_match)
+        same = compare_transition_stats(sg, so, dtype, o, "nuts")
         assert sg["tree_depth"].max() >= 3  # the trees are non-trivial
         if dtype == np.float64:
             zg, zo = g.phasepoint(), o.phasepoint()
@@ -259,7 +265,7 @@ def test_nuts_geometries_and_targets(hip, oracle, rng, D, target):
         for e in (g, o):
             e.transition(k)
         sg, so = g.stats(), o.stats()
-        same = compare_transition_stats(sg, so, np.float64, 0.995)
+        same = compare_transition_stats(sg, so, np.float64, o, f"nuts {target} D={D}")
         n_div += int(sg["numerical_error"].sum())
         realign(g, o, same)
     if target == "funnel":
@@ -270,9 +276,8 @@ def test_nuts_geometries_and_targets(hip, oracle, rng, D, target):
 def test_multiwave_chains(hip, oracle, rng, D, target):
     """D > 512: a chain spans 2-8 wavefronts of one workgroup (cross-wave reductions through LDS).
     Every transition kind on those geometries — BASELINE.json configs[4] is D = 2048 hierarchical Gaussian: that
-    very pair runs with 64 chains (every chain must agree: 0.999 × 64 > 63)."""
+    very pair runs with 64 chains."""
     N = 64 if (D, target) == (2048, "hier") else 24
-    bar = 0.999 if N == 64 else 0.95
     dtype = np.float64
     h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), make_target(target, D, rng))
     eps = 0.3 * D ** -0.25
@@ -301,15 +306,16 @@ def test_multiwave_chains(hip, oracle, rng, D, target):
             sg = g.stats()
             if dbg: print("[trace]   hip stats done", file=sys.stderr, flush=True)
             so = o.stats()
-            same = compare_transition_stats(sg, so, dtype, bar)
+            same = compare_transition_stats(sg, so, dtype, o, f"multiwave D={D} {target} kernel {ik}")
             if dbg: print(f"[trace]   same {same.mean()}", file=sys.stderr, flush=True)
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             realign(g, o, same)
         for e in (g, o):  # re-synchronise the two engines for the next kernel
             e.set_position(o.phasepoint().theta)
+    PU.reset_margin(o)
     eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
-    assert np.mean(eg == eo) >= 0.95
+    PU.check_equal_or_near_tie(eg, eo, PU.decision_margin(o), dtype, f"find_good_stepsize multiwave D={D}")
 
 
 def _spd(D, rng, cond=4.0):
@@ -369,7 +375,7 @@ def test_dense_transitions(hip, oracle, rng, metric, target):
             for e in (g, o):
                 e.transition(k)
             sg, so = g.stats(), o.stats()
-            same = compare_transition_stats(sg, so, dtype, 0.99)
+            same = compare_transition_stats(sg, so, dtype, o, f"dense {metric}/{target}")
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(zg.r[:, same], zo.r[:, same], rtol=1e-8, atol=1e-8)
@@ -381,8 +387,10 @@ def test_dense_transitions(hip, oracle, rng, metric, target):
             e.set_position(o.phasepoint().theta)
     # find_good_stepsize (src/trajectory.jl:768-837) as a state machine over global steps; the point survives it
     z_before = g.phasepoint()
+    PU.reset_margin(o)
     eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
-    assert np.mean(eg == eo) >= 0.99 and len(np.unique(eo)) > 1
+    PU.check_equal_or_near_tie(eg, eo, PU.decision_margin(o), dtype, f"find_good_stepsize dense {metric}/{target}")
+    assert len(np.unique(eo)) > 1
     z_after = g.phasepoint()
     np.testing.assert_array_equal(z_before.theta, z_after.theta)
     np.testing.assert_array_equal(z_before.r, z_after.r)
@@ -542,9 +550,12 @@ def test_against_committed_fixtures(hip, name):
     ref = np.load(os.path.join(here, "oracle_fixtures.npz"))
     got = mod.run_case(name, hip)
     n = mod.CASES[name][6]
+    margin = np.full(mod.CASES[name][2], np.inf)
     for it in range(n):
         same = got[f"{name}/n_steps{it}"] == ref[f"{name}/n_steps{it}"]
-        assert same.mean() >= (0.99 if it == 0 else 0.9)
+        # free-running transitions: a chain that took another branch stays off — allowed only from the oracle's first near-tie on
+        margin = np.minimum(margin, ref[f"{name}/margin{it}"])
+        same = PU.check_flips(same, margin, np.float64, f"fixture {name} transition {it}")
         np.testing.assert_allclose(got[f"{name}/theta{it}"][:, same], ref[f"{name}/theta{it}"][:, same], rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(got[f"{name}/H{it}"][same], ref[f"{name}/H{it}"][same], rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(got[f"{name}/acc{it}"][same], ref[f"{name}/acc{it}"][same], rtol=1e-7, atol=1e-9)
@@ -562,7 +573,7 @@ def test_max_depth_and_single_leaf(hip, oracle, rng):
             e.set_position(th)
             e.transition(k)
         sg, so = g.stats(), o.stats()
-        compare_transition_stats(sg, so, np.float64, 1.0)
+        compare_transition_stats(sg, so, np.float64, o, f"max_depth {md}")
         if eps < 0.01:
             assert np.all(sg["tree_depth"] == md) and np.all(sg["n_steps"] == 2 ** md - 1)
 
@@ -594,8 +605,7 @@ def test_find_good_stepsize(hip, oracle, rng):
     for e in (g, o):
         e.set_position(th)
         out.append(e.find_good_stepsize())
-    same = out[0] == out[1]
-    assert same.mean() >= 0.99
+    PU.check_equal_or_near_tie(out[0], out[1], PU.decision_margin(o), np.float64, "find_good_stepsize")
     assert np.all(out[0] > 0) and len(np.unique(out[0])) > 1
 
 
@@ -916,11 +926,10 @@ def test_cfg2_pipeline_against_oracle(hip, oracle):
     for e in (g, o):
         e.set_position(th0)
     eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
-    assert (eg == eo).mean() >= 0.99
+    PU.check_equal_or_near_tie(eg, eo, PU.decision_margin(o), np.float64, "cfg2 pipeline find_good_stepsize")
     g.set_integrator(A.Leapfrog(eo))   # (a chain that sat on a tie of the search would start from another ϵ)
     for e in (g, o):
         e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf)))
-    worst = 1.0
     for lo in range(1, n_total + 1, chunk):
         hi = min(lo + chunk - 1, n_total)
         so = o.get_state()
@@ -931,8 +940,8 @@ def test_cfg2_pipeline_against_oracle(hip, oracle):
         assert sg["adaptor"] == so2["adaptor"]              # iteration / window / Welford counters
         # a chain is "on track" if it took the same decisions throughout the chunk: its θ then agrees to rounding
         on = np.isclose(sg["theta"], so2["theta"], rtol=1e-7, atol=1e-7).all(axis=0)
-        worst = min(worst, on.mean())
-        assert on.mean() >= 0.97, (lo, hi, on.mean())       # ≤ 3 % of the chains flip a decision somewhere in 10 transitions
+        # … and may be off it only if the oracle took one of its decisions of this chunk within 1e-9 of a tie
+        on = PU.check_flips(on, PU.decision_margin(o), np.float64, f"cfg2 pipeline iterations {lo}..{hi}")
         np.testing.assert_allclose(sg["stepsize"][on], so2["stepsize"][on], rtol=1e-6, err_msg=f"ϵ after iterations {lo}..{hi}")
         np.testing.assert_allclose(sg["metric"][:, on], so2["metric"][:, on], rtol=1e-6, err_msg=f"M⁻¹ after {lo}..{hi}")
         if sg["da"] is not None:
@@ -954,8 +963,8 @@ def test_cfg2_pipeline_against_oracle_f32(hip, oracle):
     oracle: fused warm-up (adapt! inside k_nuts<float,32,4,3,0> … the f32 geometry of D = 128) through a whole Stan schedule —
     init buffer 9, window splits at 24 and 54 with metric update + dual-averaging restart, term buffer, finalize! at 60 — and the first
     draws, ONE iteration per chunk from the oracle's complete state: in single precision a rounding is 1e-7 and dual averaging doubles
-    it every iteration, so only the single transition + adapt! is held to the Float32 bar of this file (2e-3, ≥ 90 % of the chains on
-    identical discrete decisions), every iteration of the schedule."""
+    it every iteration, so only the single transition + adapt! is held to the Float32 bar of this file (2e-3; identical discrete
+    decisions on every chain the oracle did not take within 1e-3 of a tie), every iteration of the schedule."""
     D, N, n_adapts, n_total = 128, 256, 60, 66
     metric = A.DiagEuclideanMetric(np.ones((D, N), order="F"))
     h = A.Hamiltonian(metric, A.IsoGaussian(D))
@@ -966,12 +975,12 @@ def test_cfg2_pipeline_against_oracle_f32(hip, oracle):
     for e in (g, o):
         e.set_position(th0)
     eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
-    assert (eg == eo).mean() >= 0.9
+    PU.check_equal_or_near_tie(eg, eo, PU.decision_margin(o), np.float32, "cfg2 f32 pipeline find_good_stepsize")
     g.set_integrator(A.Leapfrog(eo))
     ad = A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf), init_buffer=9, term_buffer=6, window_size=15)
     for e in (g, o):
         e.adaptor_init(ad)
-    worst, updated = 1.0, False
+    updated = False
     for i in range(1, n_total + 1):
         g.set_state(o.get_state())
         for e in (g, o):
@@ -981,8 +990,7 @@ def test_cfg2_pipeline_against_oracle_f32(hip, oracle):
         stg, sto = g.stats(), o.stats()
         same = (stg["n_steps"] == sto["n_steps"]) & (stg["tree_depth"] == sto["tree_depth"]) & (stg["numerical_error"] == sto["numerical_error"])
         on = same & np.isclose(sg["theta"], so["theta"], rtol=2e-3, atol=2e-3).all(axis=0)
-        worst = min(worst, on.mean())
-        assert on.mean() >= 0.90, (i, on.mean())
+        on = PU.check_flips(on, PU.decision_margin(o), np.float32, f"cfg2 f32 pipeline iteration {i}")
         np.testing.assert_allclose(stg["hamiltonian_energy"][on], sto["hamiltonian_energy"][on], rtol=2e-3, err_msg=f"H at iteration {i}")
         np.testing.assert_allclose(stg["acceptance_rate"][on], sto["acceptance_rate"][on], rtol=2e-2, atol=2e-3, err_msg=f"α at iteration {i}")
         np.testing.assert_allclose(sg["stepsize"][on], so["stepsize"][on], rtol=5e-3, err_msg=f"ϵ after adapt! {i}")
@@ -1023,7 +1031,8 @@ def test_full_size_slice_against_oracle(hip, oracle, cfg, offset):
     same = (sg["n_steps"][sl] == so["n_steps"]) & (sg["tree_depth"][sl] == so["tree_depth"])
     zg, zo = g.phasepoint(), o.phasepoint()
     on = np.isclose(zg.theta[:, sl], zo.theta, rtol=1e-8, atol=1e-8).all(axis=0)
-    assert on.mean() >= 0.98, on.mean()                      # 4 free-running transitions: a flipped decision stays flipped
+    # 4 free-running transitions: a flipped decision stays flipped — allowed only where the oracle was within 1e-9 of a tie
+    on = PU.check_flips(on, PU.decision_margin(o), np.float64, f"{cfg} full-size slice at {offset}")
     assert (same | ~on).all()
     np.testing.assert_allclose(sg["hamiltonian_energy"][sl][on], so["hamiltonian_energy"][on], rtol=1e-9)
     np.testing.assert_allclose(sg["acceptance_rate"][sl][on], so["acceptance_rate"][on], rtol=1e-8, atol=1e-10)
@@ -1065,10 +1074,12 @@ def test_cfg5_full_size_slices_against_oracle(hip, oracle):
         o.set_position(th0[:, sl])
         o.run(k_of(eps[sl]), 4)
         so, zo, ao = o.stats(), o.phasepoint(), o.accum()
+        margin = PU.decision_margin(o)
         o.close()
         same = (sg["n_steps"][sl] == so["n_steps"]) & (sg["tree_depth"][sl] == so["tree_depth"])
         on = np.isclose(zg.theta[:, sl], zo.theta, rtol=1e-8, atol=1e-8).all(axis=0)
-        assert on.sum() >= n - 2, (offset, int(on.sum()))      # 4 free-running transitions of up to 512 leaves: a flipped decision stays flipped
+        # 4 free-running transitions of up to 512 leaves: a flipped decision stays flipped — allowed only at the oracle's near-ties
+        on = PU.check_flips(on, margin, np.float64, f"cfg5 full-size slice at {offset}")
         assert (same | ~on).all(), offset
         np.testing.assert_allclose(sg["hamiltonian_energy"][sl][on], so["hamiltonian_energy"][on], rtol=1e-9)
         # (α = mean of exp(min(0, −ΔH)) over up to 512 leaves with |H| ≈ 10⁴: the rounding of ΔH after four free-running transitions
@@ -1093,7 +1104,7 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
     half), the two chain pipelines on two streams, compaction, `k_d_tree<T,256>`.  The oracle replays the FIRST and the LAST
     64 chains (one in each pipeline) through `chain_offset` (src/hamiltonian.jl:60-68,179-184, src/metric.jl:311-320,
     src/trajectory.jl:626-742 per chain).  Every iteration (transition + adapt!) starts from the oracle's state for those
-    chains and is held to the bar: identical discrete decisions on ≥ 99.9 % of them (i.e. all 128), 1e-8 on θ, r, ∇ℓπ.
+    chains and is held to the bar: identical discrete decisions on every one of them (unless the oracle was within 1e-9 of a tie), 1e-8 on θ, r, ∇ℓπ.
     `engine`: "step" = the step-synchronous kernels (`k_dgemm` → `k_d_tree2` per global step); "epoch" = round 4's chain-complete
     `k_dense_epoch` (what the bench runs at 8 192 chains; here its threshold is lowered so that 1 152 chains per pipeline take it);
     "epoch_full_shard" = cfg4's own 8 192 chains per GPU with the engine's defaults, exactly the bench's pipeline;
@@ -1160,7 +1171,7 @@ def test_cfg4_shape_against_oracle(hip, oracle, metric, engine, monkeypatch):
             sl = slice(off, off + n)
             st_o, zo = o.stats(), o.phasepoint()
             sub = {key: v[sl] for key, v in st_g.items()}
-            same = compare_transition_stats(sub, st_o, np.float64, 0.999)
+            same = compare_transition_stats(sub, st_o, np.float64, o, f"cfg4 {engine}/{metric} D={D} iteration {i} offset {off}")
             np.testing.assert_allclose(zg.theta[:, sl][:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(zg.r[:, sl][:, same], zo.r[:, same], rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(zg.lp.gradient[:, sl][:, same], zo.lp.gradient[:, same], rtol=1e-8, atol=1e-8)
@@ -1246,7 +1257,7 @@ def test_fixed_integration_time_hmcda(hip, oracle, rng):
                 e.transition(k)
             sg, so = g.stats(), o.stats()
             assert (sg["n_steps"] == L).all() and (so["n_steps"] == L).all()
-            same = compare_transition_stats(sg, so, np.float64, 0.999)
+            same = compare_transition_stats(sg, so, np.float64, o, f"hmcda λ={lam}")
             zg, zo = g.phasepoint(), o.phasepoint()
             np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
             realign(g, o, same)

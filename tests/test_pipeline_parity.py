@@ -20,6 +20,7 @@ import numpy as np
 import pytest
 
 import ahmc_amd as A
+import parity_util as PU
 
 pytestmark = pytest.mark.gpu
 
@@ -103,18 +104,19 @@ def test_bench_pipeline_against_oracle_in_chunks(hip, oracle, D, target, N, geom
     o, _, _ = _setup(oracle, D, N, target, 0x5EED0005)
     assert hip.backend != "hip:gfx950" or (g.info("group_lanes"), g.info("elems_per_lane")) == geom
     eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
-    assert (eg == eo).mean() >= 0.98, (eg == eo).mean()
+    PU.check_equal_or_near_tie(eg, eo, PU.decision_margin(o), np.float64, f"pipeline {target} D={D} find_good_stepsize")
     g.set_integrator(A.Leapfrog(eo))
     for e in (g, o):
         e.adaptor_init(ad)
-    floor = (N - 2) / N if N <= 128 else 0.97       # at most 2 chains (3 %) flip a decision somewhere in a chunk
-    worst, n_div, max_depth, n_stable_checked, n_short_div = 1.0, 0, 0, 0, 0
+    n_div, max_depth, n_stable_checked, n_short_div = 0, 0, 0, 0
     # Chunks: ONE iteration each through the warm-up, five for the draws.  From θ0 ~ U(0,1) the first iterations integrate
     # with step sizes that are still far too large (and again after each dual-averaging restart) — energy errors of 10³ … 10⁶⁹, hundreds of leapfrogs per tree: such a
     # trajectory is numerically unstable (that is what the divergence test detects), a last-bit difference between the two
     # sides grows by orders of magnitude INSIDE one transition, and where a chain is declared divergent can legitimately differ.
     # There the bar is applied to the chains whose transition was stable on the oracle (|ΔH|_max < 2); every chain is compared
     # again from the oracle's state at the next iteration, so all of the schedule's early part is still covered one step at a time.
+    # The bar (round 6): a comparable chain may be off the oracle's track ONLY if the oracle took one of its decisions of the chunk
+    # within 1e-9 (relative) of a tie — rounds 4–5 allowed 2 chains or 3 % per chunk without asking why.
     bounds, lo = [], 1
     while lo <= n_total:
         hi = min(lo if lo <= n_adapts else lo + 4, n_total)
@@ -127,6 +129,11 @@ def test_bench_pipeline_against_oracle_in_chunks(hip, oracle, D, target, N, geom
         sg, so = g.get_state(), o.get_state()
         assert sg["adaptor"] == so["adaptor"]
         on = np.isclose(sg["theta"], so["theta"], rtol=1e-7, atol=1e-7).all(axis=0)
+        stg, sto = g.stats(), o.stats()
+        # the chunk's LAST transition belongs to the track: same tree
+        on &= (stg["n_steps"] == sto["n_steps"]) & (stg["tree_depth"] == sto["tree_depth"])
+        margin = PU.decision_margin(o)
+        what = f"pipeline {target} D={D} iterations {lo}..{hi}"
         if lo == hi:
             # Round 5: no iteration passes unchecked.  A transition is comparable when it was stable on the oracle (|ΔH|_max < 2) OR SHORT
             # (≤ 8 leapfrogs: the first iterations and the one after each dual-averaging restart diverge on the first or third leaf —
@@ -137,16 +144,12 @@ def test_bench_pipeline_against_oracle_in_chunks(hip, oracle, D, target, N, geom
             stable = (np.abs(sto1["max_hamiltonian_energy_error"]) < 2.0) | (sto1["n_steps"] <= 8)
             n_stable_checked += int(stable.sum())
             assert stable.sum() >= 8, (lo, int(stable.sum()))
-            allowed = max(2, int(np.ceil((1.0 - floor) * stable.sum())))       # at most 2 chains (3 %) flip a decision
-            assert int((~on[stable]).sum()) <= allowed, (lo, int((~on[stable]).sum()), int(stable.sum()))
+            PU.check_flips(on, margin, np.float64, what, sel=stable)
             n_short_div += int(((sto1["n_steps"] <= 8) & (sto1["numerical_error"] != 0)).sum())
         else:
-            worst = min(worst, on.mean())
-            assert on.mean() >= floor, (lo, hi, on.mean())
-        stg, sto = g.stats(), o.stats()
+            PU.check_flips(on, margin, np.float64, what)
         # the chunk's LAST transition, on the chains still on track: every statistic
-        last_same = (stg["n_steps"] == sto["n_steps"]) & (stg["tree_depth"] == sto["tree_depth"])
-        assert (last_same | ~on).mean() >= floor
+        last_same = on
         # (the statistics of a trajectory that blew up — ΔH of 10³ … 10⁶⁹ in the first iterations from θ0 ~ U(0,1) — carry the
         # amplified rounding of both sides: they are compared on the transitions that stayed within |ΔH| < 50; the decisions,
         # the positions and the whole adaptation state are compared for every chain)

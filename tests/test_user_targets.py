@@ -302,7 +302,8 @@ def test_plugin_from_other_kernel_sources_is_refused(hip, tmp_path):
 @pytest.mark.parametrize("D", [10, 128, 300])
 def test_plugin_banana_against_oracle(hip, oracle, D):
     """a density that is no built-in family, compiled into the fused kernels, vs the oracle evaluating the same density as a
-    numpy callback through ask / tell: every transition at the 0.999 bar with re-alignment"""
+    numpy callback through ask / tell: every transition, every chain (a chain may differ only at the oracle's own near-ties,
+    tests/parity_util.py), with re-alignment"""
     N = 256
     a_, b_ = 0.5, 0.05
     rs = np.random.default_rng(D + 1)
@@ -327,7 +328,7 @@ def test_plugin_banana_against_oracle(hip, oracle, D):
         g.transition(k)
         o.transition(k)
         sg, so = g.stats(), o.stats()
-        same = compare_transition_stats(sg, so, np.float64, 0.999 if N >= 1000 else 0.99)
+        same = compare_transition_stats(sg, so, np.float64, o, f"plugin banana D={D}")
         zg, zo = g.phasepoint(), o.phasepoint()
         np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=1e-8, atol=1e-8)
         depth = max(depth, int(so["tree_depth"].max()))
@@ -382,13 +383,16 @@ def test_kernel_target_against_oracle(hip, oracle, name, D, metric):
     for k in (hmc, nuts, nuts):
         for e in (g, o):
             e.transition(k)
-        same = compare_transition_stats(g.stats(), o.stats(), np.float64, 0.99)
+        same = compare_transition_stats(g.stats(), o.stats(), np.float64, o, f"kernel target {name} {metric}")
         np.testing.assert_allclose(g.phasepoint().theta[:, same], o.phasepoint().theta[:, same], rtol=1e-8, atol=1e-8)
         th = o.phasepoint().theta
         for e in (g, o):
             e.set_position(th)
+    import parity_util as PU
+
+    PU.reset_margin(o)
     eg, eo = g.find_good_stepsize(), o.find_good_stepsize()
-    assert np.mean(eg == eo) >= 0.99
+    PU.check_equal_or_near_tie(eg, eo, PU.decision_margin(o), np.float64, f"kernel target {name} find_good_stepsize")
     # the bulk driver: batches of transitions, the engine launching the user's kernel once per global step, no host round trip
     g.set_integrator(A.Leapfrog(eo))
     o.set_integrator(A.Leapfrog(eo))
@@ -396,6 +400,6 @@ def test_kernel_target_against_oracle(hip, oracle, name, D, metric):
         e.set_position(th0)
         e.run(nuts, 3)
     on = np.isclose(g.phasepoint().theta, o.phasepoint().theta, rtol=1e-8, atol=1e-8).all(axis=0)
-    assert on.mean() >= 0.97, on.mean()
+    PU.check_flips(on, PU.decision_margin(o), np.float64, f"kernel target {name} bulk run of 3")   # (free-running: a flip stays)
     assert g.accum()["n_transitions"] == 3
     g.close(); o.close()

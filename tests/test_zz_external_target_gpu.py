@@ -1,6 +1,6 @@
 """GPU side of the ask / tell protocol (ahmc_ext_*): the HIP engine driven with a user log-density must
 reproduce the oracle running the same density built in (Float64: 1e-9 on energies / positions, discrete
-statistics identical on >= 99.9 % of chains — the bars of test_gpu_parity.py), plus the step-synchronous engine's
+statistics identical on every chain except at the oracle's own near-ties — the bars of test_gpu_parity.py), plus the step-synchronous engine's
 variants (static MultinomialTS, partial refreshment, TemperedLeapfrog, Classic / Strict U-turn) and the split-step
 pair ahmc_lf_pre / ahmc_lf_post.
 
@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 import ahmc_amd as A
+import parity_util as PU
 from test_external_target import TARGETS, iso_fn, make_metric
 
 pytestmark = [pytest.mark.gpu,
@@ -35,10 +36,12 @@ def engines(hip, oracle, target, metric, N, lf, seed=7):
     return e_ext, e_ref
 
 
-def assert_close_state(e_ext, e_ref, min_match=0.999):
+def assert_close_state(e_ext, e_ref, what="external target"):
+    """`e_ref` is the ORACLE engine: identical discrete decisions on every chain that the oracle did not take within 1e-9 of a tie
+    (tests/parity_util.py; its margin record is read and reset here — one call per span of transitions)"""
     sa, sb = e_ext.stats(), e_ref.stats()
     same = (sa["n_steps"] == sb["n_steps"]) & (sa["is_accept"] == sb["is_accept"]) & (sa["tree_depth"] == sb["tree_depth"])
-    assert same.mean() >= min_match, same.mean()
+    same = PU.check_flips(same, PU.decision_margin(e_ref), np.float64, what)
     za, zb = e_ext.phasepoint(), e_ref.phasepoint()
     np.testing.assert_allclose(za.theta[:, same], zb.theta[:, same], rtol=RT, atol=RT)
     np.testing.assert_allclose(za.r[:, same], zb.r[:, same], rtol=RT, atol=RT)
@@ -75,7 +78,7 @@ def test_dense_engine_classic_and_strict_uturn(hip, oracle, rng, metric, target,
     for _ in range(4):
         e_g.transition(kernel)
         e_o.transition(kernel)
-        same = assert_close_state(e_g, e_o, min_match=0.99)
+        same = assert_close_state(e_g, e_o)
         if not same.all():
             e_g.set_position(e_o.phasepoint().theta)
     e_g.close(); e_o.close()
@@ -97,7 +100,7 @@ def test_hip_nuts_with_user_density(hip, oracle, rng, target, metric, TS, TC):
     for _ in range(3):
         e_ext.transition(kernel)
         e_ref.transition(kernel)
-        same = assert_close_state(e_ext, e_ref, min_match=0.99)
+        same = assert_close_state(e_ext, e_ref)
         if not same.all():  # a chain that took another decision carries on from another state: re-align it
             e_ext.set_position(e_ref.phasepoint().theta)
     assert e_ext.info("iteration") == e_ref.info("iteration") == 3
@@ -153,7 +156,7 @@ def test_dense_engine_static_multinomial(hip, oracle, rng, metric, target):
         sa, sb = e_g.stats(), e_o.stats()
         za, zb = e_g.phasepoint(), e_o.phasepoint()
         close = np.all(np.isclose(za.theta, zb.theta, rtol=1e-8, atol=1e-8), axis=0)  # (a different categorical pick shows as a different point)
-        assert close.mean() >= 0.99, close.mean()
+        close = PU.check_flips(close, PU.decision_margin(e_o), np.float64, f"dense static multinomial {metric}/{target}")
         np.testing.assert_allclose(sa["acceptance_rate"], sb["acceptance_rate"], rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(sa["hamiltonian_energy"][close], sb["hamiltonian_energy"][close], rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(za.r[:, close], zb.r[:, close], rtol=1e-8, atol=1e-8)
@@ -172,7 +175,8 @@ def test_hip_find_good_stepsize_with_user_density(hip, oracle, rng, metric):
     e_ext.set_position(th0)
     e_ref.set_position(th0)
     eps_a, eps_b = e_ext.find_good_stepsize(), e_ref.find_good_stepsize()
-    assert (eps_a == eps_b).mean() >= 0.99  # powers of two times bisection midpoints: equal unless a test sat on a tie
+    # powers of two times bisection midpoints: equal unless a test of the search sat on a tie
+    PU.check_equal_or_near_tie(eps_a, eps_b, PU.decision_margin(e_ref), np.float64, f"find_good_stepsize, user density, {metric}")
     np.testing.assert_allclose(e_ext.phasepoint().theta, th0, rtol=0, atol=0)
     assert e_ext.info("iteration") == 0
     e_ext.close(); e_ref.close()
@@ -208,7 +212,7 @@ def test_hip_batch_of_transitions_and_device_arrays(hip, oracle, rng):
     for _ in range(4):
         e_ref.transition(kernel)
     assert e_ext.info("iteration") == 4 and trips > 4
-    assert_close_state(e_ext, e_ref, min_match=0.99)  # (torch's reduction order differs from the oracle's loop)
+    assert_close_state(e_ext, e_ref)  # (torch's reduction order differs from the oracle's loop)
     e_ext.close(); e_ref.close()
 
 
@@ -260,7 +264,7 @@ def test_dense_engine_partial_refreshment(hip, oracle, rng, metric, target, nuts
         e_o.run(kernel, 1)
         sa, sb = e_g.stats(), e_o.stats()
         same = (sa["n_steps"] == sb["n_steps"]) & (sa["is_accept"] == sb["is_accept"])
-        assert same.mean() >= 0.99, same.mean()
+        same = PU.check_flips(same, PU.decision_margin(e_o), np.float64, f"partial refreshment {metric}/{target}")
         za, zb = e_g.phasepoint(), e_o.phasepoint()
         np.testing.assert_allclose(za.theta[:, same], zb.theta[:, same], rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(za.r[:, same], zb.r[:, same], rtol=1e-8, atol=1e-8)
@@ -282,7 +286,7 @@ def test_hip_user_density_partial_refreshment(hip, oracle, rng):
         for _ in range(2):
             e_ext.transition(kernel)
             e_ref.run(kernel, 1)
-            assert_close_state(e_ext, e_ref, min_match=0.99)
+            assert_close_state(e_ext, e_ref)
     e_ext.close(); e_ref.close()
 
 
@@ -320,7 +324,7 @@ def test_dense_engine_tempered_leapfrog(hip, oracle, rng, metric, target):
             sa, sb = e_g.stats(), e_o.stats()
             za, zb = e_g.phasepoint(), e_o.phasepoint()
             close = np.all(np.isclose(za.theta, zb.theta, rtol=1e-8, atol=1e-8), axis=0) & (sa["is_accept"] == sb["is_accept"])
-            assert close.mean() >= 0.99, close.mean()
+            close = PU.check_flips(close, PU.decision_margin(e_o), np.float64, f"tempered static {TS.__name__}")
             np.testing.assert_allclose(sa["hamiltonian_energy"][close], sb["hamiltonian_energy"][close], rtol=1e-8, atol=1e-8)
             if not close.all():
                 e_g.set_position(zb.theta, zb.r)
@@ -330,7 +334,7 @@ def test_dense_engine_tempered_leapfrog(hip, oracle, rng, metric, target):
         for _ in range(3):
             e_g.transition(kernel)
             e_o.transition(kernel)
-            same = assert_close_state(e_g, e_o, min_match=0.98)
+            same = assert_close_state(e_g, e_o)
             if not same.all():
                 e_g.set_position(e_o.phasepoint().theta, e_o.phasepoint().r)
     e_g.close(); e_o.close()
@@ -349,7 +353,7 @@ def test_hip_user_density_tempered(hip, oracle, rng, TS, TC):
     for _ in range(3):
         e_ext.transition(kernel)
         e_ref.transition(kernel)
-        assert_close_state(e_ext, e_ref, min_match=0.99)
+        assert_close_state(e_ext, e_ref)
     e_ext.close(); e_ref.close()
 
 
@@ -369,7 +373,7 @@ def test_hip_batch_of_static_transitions(hip, oracle, rng, TS):
     for _ in range(3):
         e_ref.transition(kernel)
     assert e_ext.info("iteration") == 3
-    assert_close_state(e_ext, e_ref, min_match=0.98)
+    assert_close_state(e_ext, e_ref)
     e_ext.close(); e_ref.close()
 
 
@@ -389,8 +393,7 @@ def test_baseline_cfg1_on_the_gpu(hip, oracle):
         e_g.transition(kernel)
         e_o.transition(kernel)
         sa, sb = e_g.stats(), e_o.stats()
-        same = sa["is_accept"] == sb["is_accept"]
-        assert same.mean() >= 0.999
+        same = PU.check_flips(sa["is_accept"] == sb["is_accept"], PU.decision_margin(e_o), np.float64, "cfg1 on the GPU")
         np.testing.assert_allclose(e_g.phasepoint().theta[:, same], e_o.phasepoint().theta[:, same], rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(sa["hamiltonian_energy"][same], sb["hamiltonian_energy"][same], rtol=1e-9, atol=1e-9)
         if not same.all():
