@@ -449,20 +449,26 @@ __device__ __forceinline__ void block_allsum2(T& a, T& b) {
 // pairs (i·DT + l)·2, +1: the loads of a chunk of up to 8 pairs per lane (4 with five vectors) are ALL issued before the first element is used (and
 // before any store of the pass, which the compiler could not prove not to alias), so a pass costs one memory round trip per
 // chunk — the loops over a run-time D take one per element.  f(d, x): the element pair at d, x[v] its values in vector v.
-template <class T, int DT, int DC, int NV, class F>
+template <class T, int DT, int DC, int NV, int CHCAP = 8, class F>
 __device__ __forceinline__ void dn_vec_pass(int lane, const T* const (&src)[NV], F&& f) {
   typedef T T2 __attribute__((ext_vector_type(2)));
-  constexpr int NP = DC / (2 * DT), CHM = NV >= 5 ? 4 : 8, CH = NP < CHM ? NP : CHM;  // (≤ 128 registers of operands in flight per lane)
-  static_assert(NP >= 1 && NP % CH == 0, "dn_vec_pass: DC must be a multiple of 2·DT (and of 16·DT beyond that)");
+  // CHCAP: pairs per lane and vector in flight at most (8: ≤ 128 registers of operands with four vectors; k_dense_epoch2 compiled for
+  // four waves per SIMD passes 4).  Round 6: NP need not be a multiple of the chunk — the last chunk is shorter (D = 384: 12 = 8 + 4);
+  // a lane still meets its elements in ascending order, so the sums have the bits of any other chunking.
+  constexpr int NP = DC / (2 * DT), CHM = NV >= 5 ? CHCAP / 2 : CHCAP, CH = NP < CHM ? NP : CHM;
+  static_assert(NP >= 1 && DC % (2 * DT) == 0, "dn_vec_pass: DC must be a multiple of 2·DT");
 #pragma unroll
   for (int c0 = 0; c0 < NP; c0 += CH) {
     T2 val[CH][NV];
 #pragma unroll
     for (int i = 0; i < CH; ++i)
+      if (c0 + i < NP) {
 #pragma unroll
-      for (int v = 0; v < NV; ++v) val[i][v] = *reinterpret_cast<const T2*>(src[v] + ((c0 + i) * DT + lane) * 2);
+        for (int v = 0; v < NV; ++v) val[i][v] = *reinterpret_cast<const T2*>(src[v] + ((c0 + i) * DT + lane) * 2);
+      }
 #pragma unroll
-    for (int i = 0; i < CH; ++i) f(((c0 + i) * DT + lane) * 2, val[i]);
+    for (int i = 0; i < CH; ++i)
+      if (c0 + i < NP) f(((c0 + i) * DT + lane) * 2, val[i]);
   }
 }
 
@@ -1164,7 +1170,8 @@ __device__ __forceinline__ void dn_chain_barrier() {
 // scalars against the other threads' reads become wave-local fences
 // DC > 0: D at compile time — the vector passes go through dn_vec_pass (other element order: the sums differ in the last bits
 // from the run-time loops')
-template <class T, int DT, bool WV = false, int DC = 0>
+// VCH: dn_vec_pass's chunk cap (registers of operands in flight)
+template <class T, int DT, bool WV = false, int DC = 0, int VCH = 8>
 __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, int64_t c, int lane, T lp_in, T lk_in, const DHot<T>& hot, int& src,
                                              uint64_t& used, bool& rewritten /* the point `src` was given a fresh momentum in this call */) {
   rewritten = false;
@@ -1274,7 +1281,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       if constexpr (DC > 0) {
         typedef T T2 __attribute__((ext_vector_type(2)));
         const T* const srcs[4] = {p_rho, rho_v, p_vf, Vc};
-        dn_vec_pass<T, DT, DC, 4>(lane, srcs, [&](int d, const T2 (&x)[4]) {
+        dn_vec_pass<T, DT, DC, 4, VCH>(lane, srcs, [&](int d, const T2 (&x)[4]) {
           const T2 rho = x[0] + x[1];
           dots[0] += rho[0] * x[2][0] + rho[1] * x[2][1];
           dots[1] += rho[0] * x[3][0] + rho[1] * x[3][1];
@@ -1360,7 +1367,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       if constexpr (DC > 0) {
         typedef T T2 __attribute__((ext_vector_type(2)));
         const T* const srcs[4] = {t_rho, rho_v, Vc, o_v};
-        dn_vec_pass<T, DT, DC, 4>(lane, srcs, [&](int d, const T2 (&x)[4]) {
+        dn_vec_pass<T, DT, DC, 4, VCH>(lane, srcs, [&](int d, const T2 (&x)[4]) {
           const T2 rho = x[0] + x[1];
           dots[0] += rho[0] * x[2][0] + rho[1] * x[2][1];
           dots[1] += rho[0] * x[3][0] + rho[1] * x[3][1];
@@ -1416,7 +1423,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
         if constexpr (DC > 0) {
           typedef T T2 __attribute__((ext_vector_type(2)));
           const T* const srcs[5] = {c_th, c_r, c_g, s1, s2};
-          dn_vec_pass<T, DT, DC, 5>(lane, srcs, [&](int d, const T2 (&x)[5]) {
+          dn_vec_pass<T, DT, DC, 5, VCH>(lane, srcs, [&](int d, const T2 (&x)[5]) {
             const T2 t = x[0];
             if (p.accum) {
               *reinterpret_cast<T2*>(s1 + d) = x[3] + t;
@@ -1510,7 +1517,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
     if constexpr (DC > 0) {
       typedef T T2 __attribute__((ext_vector_type(2)));
       const T* const srcs[4] = {rb, vb, th, g};
-      dn_vec_pass<T, DT, DC, 4>(lane, srcs, [&](int d, const T2 (&x)[4]) {
+      dn_vec_pass<T, DT, DC, 4, VCH>(lane, srcs, [&](int d, const T2 (&x)[4]) {
         dots[0] += x[0][0] * x[1][0] + x[0][1] * x[1][1];
         *reinterpret_cast<T2*>(s_r + d) = x[0];
         *reinterpret_cast<T2*>(s_v + d) = x[1];
@@ -1950,6 +1957,343 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
             const T* const srcs[5] = {ppt(q, p, src, PV_TH, c), ppt(q, p, src, PV_R, c), ppt(q, p, src, PV_G, c), ppt(q, p, src, PV_V, c), ppt(q, p, src, PV_W, c)};
             if (l16 == 0) spec_pt[slot] = __builtin_ctzll(~(used | ((uint64_t)1 << dst)));
             if (!hit) dn_vec_pass<T, GL, D, 5>(l16, srcs, [&](int d, const T2 (&x)[5]) {
+              T2 rh, vh, tn;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                rh[h] = x[1][h] - e / 2 * x[2][h];
+                vh[h] = x[3][h] - e / 2 * x[4][h];
+                tn[h] = x[0][h] + e * vh[h];
+              }
+              *reinterpret_cast<T2*>(dR + d) = rh;
+              *reinterpret_cast<T2*>(dV + d) = vh;
+              *reinterpret_cast<T2*>(dTH + d) = tn;
+            });
+            if (l16 == 0) {
+              S.cur = (int8_t)dst;
+              q.ptcur[c] = dst;
+            }
+            chain_active = true;
+          } else {
+            if (l16 == 0) {
+              q.ptcur[c] = src;  // motionless / idle: the products serve the point the chain sits on
+              spec_pt[slot] = -1;
+            }
+            dn_chain_barrier<true>();        // (thread 0 may just have set the phase)
+            if (S.phase != DPH_IDLE) chain_active = true;
+          }
+        }
+      }
+      if (chain_active && l16 == 0) any_active[step & 1] = 1;
+    }
+    AHMC_EPOCH_TICK(4)
+    __syncthreads();  // (B) every chain's next point, step and phase are visible to the whole workgroup
+    AHMC_EPOCH_TICK(5)
+#ifdef AHMC_EPOCH_PROF
+    pt_[7] += 1;
+#endif
+    if (!any_active[step & 1]) break;
+  }
+#ifdef AHMC_EPOCH_PROF
+  if (threadIdx.x == 0 && q.prof)
+    for (int i = 0; i < 8; ++i) atomicAdd(q.prof + i, pt_[i]);
+#endif
+}
+
+// ================================================================================================
+// k_dense_epoch2 (round 6): the chain-complete kernel for ANY D = 64·NW (NW = 4 … 16 waves per workgroup), Float64 and Float32,
+// with one or two MFMA column tiles (16 or 32 chains) per workgroup.
+//
+// Why.  k_dense_epoch multiplies 60 % of a workgroup-step: its 8 waves hold 16 accumulators each (256 VGPRs: one workgroup, two waves
+// per SIMD, per CU), and while they are in the epilogue / the trees / the barriers nothing issues an MFMA.  profiles/r5_mfma_clock.jsonl
+// says what fills the pipe: TWO multiplying waves per SIMD with 8 accumulators each.  So: a workgroup of NW waves owns ONE column tile —
+// 16 chains, wave w the rows [64w, 64w + 64) of both matrices = 8 accumulators —, fits 128 registers (WPE = 4 waves per SIMD) and
+// 8.4 KB of LDS per wave, and TWO such workgroups share a CU: one's memory phases run beside the other's products, with two
+// multiplying waves per SIMD either way.  The price is the matrices streamed from L2 once per 16 chain-steps instead of once per 32.
+//
+// What changed against k_dense_epoch, beside the shape:
+//  * the transposition tile holds ONE matrix at a time (tile[NW][16][66]): pass G turns g′ into r ← r½ − ϵ/2·g′ (and the speculative
+//    next r½), pass W turns w′ into v (and v½, θ″); r stays in registers between the two for r·v, θ is read again in pass W;
+//  * the tree phase serves 4 chains per wave and round: waves 0 … (chains / 4 − 1) of a round, the others go to the barrier;
+//  * the fragment order of the matrices follows the element type (k_dense_swizzle2): an f64 accumulator of lane (q, n) holds MFMA rows
+//    q + 4v, an f32 one rows 4q + v — either way the lane ends up with 16 consecutive elements of chain n.
+// Same products in the same order as k_dgemm, the same per-element arithmetic as k_dense_epoch: chains take the decisions of the
+// step-synchronous kernels (tests/test_gpu_parity.py: test_dense_epoch_kernel_equals_step_synchronous_kernels, all shapes).
+// ================================================================================================
+constexpr int DE2_RT = 4, DE2_RW = 16 * DE2_RT;
+
+// matrices in fragment order: out[(((kk·NW + w)·RT + j)·64 + lane)·2 + e], fragment f = 2j + e of wave w: m = f / RT (0: A0 → g′, 1: A1 → w′),
+// row tile t = f % RT; MFMA row i = lane mod 16 ↦ matrix row w·16RT + 4RT·iq + 4t + iv with (iq, iv) = (i mod 4, i / 4) for f64 and
+// (i / 4, i mod 4) for f32 (Mfma<T>::row): the accumulators of lane (q, n) are rows w·16RT + 4RT·q + 4t + v of chain n
+template <class T>
+__global__ __launch_bounds__(256) void k_dense_swizzle2(const T* __restrict__ A0, const T* __restrict__ A1, T* __restrict__ out, int D, int NW) {
+  constexpr int RT = DE2_RT;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * (int64_t)D * D) return;
+  const int e = (int)(idx & 1), l = (int)((idx >> 1) & 63);
+  int64_t rest = idx >> 7;
+  const int j = (int)(rest % RT);
+  rest /= RT;
+  const int w = (int)(rest % NW), kk = (int)(rest / NW);
+  const int f = 2 * j + e, m = f / RT, t = f % RT, i = l & 15;
+  const int iq = sizeof(T) == 8 ? (i & 3) : (i >> 2), iv = sizeof(T) == 8 ? (i >> 2) : (i & 3);
+  const int row = w * 16 * RT + 4 * RT * iq + 4 * t + iv, k = 4 * kk + (l >> 4);
+  out[idx] = (m ? A1 : A0)[row + (int64_t)k * D];
+}
+
+template <class T, int NW, int NCT, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_dense_epoch2(KP<T> p, DP2<T> q, const T* __restrict__ Asw, int max_steps) {
+  using M = Mfma<T>;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  constexpr int RT = DE2_RT, RW = DE2_RW, D = RW * NW, NK = D / 4, NF = 2 * RT;
+  constexpr int CH = 16 * NCT;  // chains of the workgroup
+  constexpr int LPC = RW / 2;   // lanes per chain in the coalesced passes of the epilogue (one element pair per lane)
+  constexpr int CPI = 64 / LPC; // chains per instruction there
+  constexpr int TP = RW + 2;    // pitch of the transposition tile: conflict-free columns
+  constexpr int GL = 16;        // tree phase: lanes per chain, four chains per wave at once
+  constexpr int VCH = WPE >= 4 ? 4 : 8;  // pairs per lane and vector in flight in the tree phase's vector passes
+  constexpr int NIT = 16 / CPI, NB = WPE >= 4 ? 2 : (NIT < AHMC_EPOCH_NB ? NIT : AHMC_EPOCH_NB);  // epilogue: chains per half-wave whose loads are in flight together
+  static_assert(NW >= 4 && NW <= 16 && (NCT == 1 || NCT == 2), "k_dense_epoch2: D = 256 … 1024 in steps of 64");
+  __shared__ T tile[NW][16][TP];
+  __shared__ DEMeta<T> meta[NW][CH];
+  __shared__ double red[NW][CH][2];
+  __shared__ int any_active[2];
+  __shared__ int spec_pt[CH];  // per chain: the pool point its speculative half-step goes to (−1: none), set by the tree phase
+  const int64_t j0 = (int64_t)blockIdx.x * CH;
+  if (j0 >= q.n_list) return;
+  const int64_t c_safe = q.list ? (int64_t)q.list[j0] : j0;
+  if (threadIdx.x == 0) any_active[0] = any_active[1] = 0;
+  if (threadIdx.x < CH) spec_pt[threadIdx.x] = -1;
+  __syncthreads();
+  constexpr size_t AKS = (size_t)NW * RT * 64;  // T2 elements per k-step
+#ifdef AHMC_EPOCH_PROF
+  unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc_ = __builtin_readcyclecounter();
+#endif
+  for (int step = 0; step < max_steps; ++step) {
+    // (as in k_dense_epoch: every per-lane quantity is derived anew per step and per phase from a thread index the compiler cannot
+    // trace, so that nothing a lane holds lives across the divergent tree phase)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, w = tid >> 6, qd = lane >> 4, n16 = lane & 15;
+    const T2* Ap = reinterpret_cast<const T2*>(Asw) + (size_t)w * RT * 64 + lane;
+    // ---- the columns of this step: the point each chain's leapfrog in flight sits on ----
+    const T* Bp[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int64_t jc = j0 + 16 * ct + n16;
+      const int64_t colc = jc < q.n_list ? (q.list ? (int64_t)q.list[jc] : jc) : -1;
+      const int64_t cc = colc >= 0 ? colc : c_safe;
+      const int cur = q.ptcur[cc];
+      const DChain2<T>& Sc = q.S[cc];
+      int act = (colc >= 0 && Sc.phase != DPH_IDLE) ? 1 : 0;
+      const T ec = act ? q.es[cc] : T(0);
+      if (!q.lazy_gw || ec == T(0) || Sc.leaf == (1 << Sc.jw) || Sc.it + 1 >= q.n_trans) act |= 2 * act;   // (g′, w′ go on record: k_dense_epoch)
+      Bp[ct] = ppt(q, p, cur, PV_TH, cc) + qd;
+      if (qd == 0) meta[w][16 * ct + n16] = DEMeta<T>{(long long)cc, ec, cur, act};
+    }
+    // ---- g′ = Pθ′, w′ = (M⁻¹P)θ′: 2·RT row tiles × NCT column tiles per wave, operands two k-steps ahead in registers ----
+    typename M::acc_t acc[NF][NCT];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[f][ct] = typename M::acc_t{0, 0, 0, 0};
+    AHMC_EPOCH_TICK(0)
+    {
+      T2 a[3][RT];
+      T b[3][NCT];
+      auto load = [&](int kk, T2 (&aa)[RT], T (&bb)[NCT]) {
+        kk = kk < NK ? kk : NK - 1;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) aa[j] = Ap[(size_t)kk * AKS + (size_t)j * 64];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) bb[ct] = Bp[ct][4 * kk];
+      };
+      auto mult = [&](const T2 (&aa)[RT], const T (&bb)[NCT]) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[2 * j + e][ct] = M::mma(aa[j][e], bb[ct], acc[2 * j + e][ct]);
+      };
+      load(0, a[0], b[0]);
+      load(1, a[1], b[1]);
+      for (int kk = 0; kk < NK; kk += 3) {
+        load(kk + 2, a[2], b[2]);
+        mult(a[0], b[0]);
+        if (kk + 1 < NK) {
+          load(kk + 3, a[0], b[0]);
+          mult(a[1], b[1]);
+        }
+        if (kk + 2 < NK) {
+          load(kk + 4, a[1], b[1]);
+          mult(a[2], b[2]);
+        }
+      }
+    }
+    AHMC_EPOCH_TICK(1)
+    // ---- epilogue: second half of the leapfrog (src/integrator.jl:243-250), one matrix at a time through the wave's tile.  The
+    // accumulators hold 4·RT consecutive rows of ONE chain per lane and sixteen chains per instruction; read back they are one
+    // element pair per lane with LPC consecutive lanes per chain, so every global access below covers whole cache lines ----
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int pos = lane % LPC, dd = w * RW + 2 * pos;
+      T2 rkeep[NIT];
+      T s1keep[NIT];
+      // -- pass G: r ← r½ − ϵ/2·g′ (+ the speculative next r½, the record of g′), θ′·g′ --
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int r0 = 4 * RT * qd + 4 * t;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<T2*>(&tile[w][n16][r0 + 2 * h]) = T2{acc[t][ct][2 * h], acc[t][ct][2 * h + 1]};
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ib = 0; ib < NIT; ib += NB) {
+        T2 r2[NB], th2[NB];
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          const DEMeta<T> m = meta[w][16 * ct + (ib + it) * CPI + lane / LPC];
+          th2[it] = r2[it] = T2{0, 0};  // (defined on every path: a value left undefined for the idle chains' lanes is carried around the step loop)
+          if (m.act) {
+            th2[it] = *reinterpret_cast<const T2*>(ppt(q, p, m.cur, PV_TH, (int64_t)m.c) + dd);
+            r2[it] = *reinterpret_cast<const T2*>(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          const int nn = (ib + it) * CPI + lane / LPC;
+          const DEMeta<T> m = meta[w][16 * ct + nn];
+          T2 rr = r2[it];
+          T s1 = 0;
+          if (m.act) {
+            const T e = m.e;
+            const T2 g2 = *reinterpret_cast<const T2*>(&tile[w][nn][2 * pos]);
+            const int sp = spec_pt[16 * ct + nn];
+            if (e != T(0)) {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) rr[h] = rr[h] - e / 2 * g2[h];
+              DE_STORE(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd, rr);
+              if (sp >= 0) {  // the first half of the NEXT leapfrog if the tree goes on from this point with this step (k_dense_epoch)
+                T2 rh;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) rh[h] = rr[h] - e / 2 * g2[h];
+                DE_STORE(ppt(q, p, sp, PV_R, (int64_t)m.c) + dd, rh);
+              }
+            }
+            if ((m.act & 2) || e == T(0) || sp < 0) DE_STORE(ppt(q, p, m.cur, PV_G, (int64_t)m.c) + dd, g2);
+            s1 = th2[it][0] * g2[0] + th2[it][1] * g2[1];
+          }
+          rkeep[ib + it] = rr;
+          s1keep[ib + it] = s1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // -- pass W: v ← v½ − ϵ/2·w′ (+ the speculative v½ and θ″ = θ′ + ϵ·v½, the record of w′), r·v --
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int r0 = 4 * RT * qd + 4 * t;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<T2*>(&tile[w][n16][r0 + 2 * h]) = T2{acc[RT + t][ct][2 * h], acc[RT + t][ct][2 * h + 1]};
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ib = 0; ib < NIT; ib += NB) {
+        T2 v2[NB], th2[NB];
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          const DEMeta<T> m = meta[w][16 * ct + (ib + it) * CPI + lane / LPC];
+          th2[it] = v2[it] = T2{0, 0};
+          if (m.act) {
+            v2[it] = *reinterpret_cast<const T2*>(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd);
+            if (m.e != T(0) && spec_pt[16 * ct + (ib + it) * CPI + lane / LPC] >= 0) th2[it] = *reinterpret_cast<const T2*>(ppt(q, p, m.cur, PV_TH, (int64_t)m.c) + dd);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          const int nn = (ib + it) * CPI + lane / LPC;
+          const DEMeta<T> m = meta[w][16 * ct + nn];
+          T s0 = 0, s1 = s1keep[ib + it];
+          if (m.act) {
+            const T e = m.e;
+            const T2 w2 = *reinterpret_cast<const T2*>(&tile[w][nn][2 * pos]);
+            const int sp = spec_pt[16 * ct + nn];
+            T2 vv = v2[it];
+            if (e != T(0)) {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) vv[h] = vv[h] - e / 2 * w2[h];
+              DE_STORE(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd, vv);
+              if (sp >= 0) {
+                T2 vh, tn;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  vh[h] = vv[h] - e / 2 * w2[h];
+                  tn[h] = th2[it][h] + e * vh[h];
+                }
+                DE_STORE(ppt(q, p, sp, PV_V, (int64_t)m.c) + dd, vh);
+                DE_STORE(ppt(q, p, sp, PV_TH, (int64_t)m.c) + dd, tn);
+              }
+            }
+            if ((m.act & 2) || e == T(0) || sp < 0) DE_STORE(ppt(q, p, m.cur, PV_W, (int64_t)m.c) + dd, w2);
+            const T2 rr = rkeep[ib + it];
+            s0 = rr[0] * vv[0] + rr[1] * vv[1];
+          }
+          wave_allsum2<LPC>(s0, s1);
+          if (pos == 0) { red[w][16 * ct + nn][0] = (double)s0; red[w][16 * ct + nn][1] = (double)s1; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    AHMC_EPOCH_TICK(2)
+    __syncthreads();  // (A) the points are complete, the partial sums are in LDS
+    AHMC_EPOCH_TICK(3)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    if (tid2 == 0) any_active[(step + 1) & 1] = 0;
+    // ---- trees: a wave serves four chains AT ONCE, GL lanes each (k_d_tree2 from the reduction on; the groups of a wave follow their own
+    // control flow — every exchange of d_tree_advance2 stays inside a 16-lane row); round rd: chains 4·NW·rd … of the workgroup ----
+#pragma unroll 1
+    for (int base = 0; base < CH; base += 4 * NW) {
+      const int lane2 = tid2 & 63, w2 = tid2 >> 6;
+      const int grp = lane2 / GL, l16 = lane2 % GL;
+      const int slot = base + w2 * 4 + grp;
+      const int64_t jj = j0 + slot;
+      bool chain_active = false;
+      if (slot < CH && jj < q.n_list) {
+        const int64_t c = q.list ? (int64_t)q.list[jj] : jj;
+        DChain2<T>& S = q.S[c];
+        if (S.phase != DPH_IDLE) {
+          T sa = 0, sb = 0;
+#pragma unroll
+          for (int k = 0; k < NW; ++k) { sa += (T)red[k][slot][0]; sb += (T)red[k][slot][1]; }
+          const T lk = sanitize(-sa / 2), lp = sanitize(-sb / 2);
+          DHot<T> hot;
+          hot.H0 = S.H0; hot.eps = S.eps; hot.lu = S.lu;
+          hot.phase = S.phase; hot.it = S.it; hot.jw = S.jw; hot.leaf = S.leaf; hot.v = S.v; hot.cur_is_left = S.cur_is_left; hot.numerical = S.numerical;
+          hot.k = S.k;
+          hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand;
+          if (l16 == 0) {
+            p.lk()[c] = lk;
+            p.lp()[c] = lp;
+          }
+          int src = hot.cur;
+          uint64_t used = 0;
+          bool rewritten = false;
+          dn_chain_barrier<true>();
+          const T e = d_tree_advance2<T, GL, true, D, VCH>(p, q, c, l16, lp, lk, hot, src, used, rewritten);
+          if (l16 == 0) q.es[c] = e;
+          if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237): src → a fresh point
+            const DEMeta<T> m = meta[w2][slot];
+            const int sp = spec_pt[slot];
+            // the epilogue has already taken it if the leapfrog goes on from the point just completed with the same signed step
+            const bool hit = sp >= 0 && m.e != T(0) && src == hot.cur && e == m.e && !rewritten;
+            const int dst = hit ? sp : __builtin_ctzll(~used);
+            T* dTH = ppt(q, p, dst, PV_TH, c);
+            T* dR = ppt(q, p, dst, PV_R, c);
+            T* dV = ppt(q, p, dst, PV_V, c);
+            dn_chain_barrier<true>();  // (the start of a transition has just written r, v of `src`)
+            const T* const srcs[5] = {ppt(q, p, src, PV_TH, c), ppt(q, p, src, PV_R, c), ppt(q, p, src, PV_G, c), ppt(q, p, src, PV_V, c), ppt(q, p, src, PV_W, c)};
+            if (l16 == 0) spec_pt[slot] = __builtin_ctzll(~(used | ((uint64_t)1 << dst)));
+            if (!hit) dn_vec_pass<T, GL, D, 5, VCH>(l16, srcs, [&](int d, const T2 (&x)[5]) {
               T2 rh, vh, tn;
 #pragma unroll
               for (int h = 0; h < 2; ++h) {

@@ -496,6 +496,52 @@ void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, cons
 }
 
 // n_trans NUTS transitions of every chain (asynchronous chains, see ahmc_dense.hpp)
+// k_dense_epoch2's compiled shapes: (D, element type) → column tiles per workgroup (16 chains each) and the waves per SIMD the kernel is
+// compiled for (its register budget is 512 / WPE).  `want_nct` ≠ 0 picks the other shape where two are compiled (experiments).
+// f64: 16 accumulators of 8 registers need the 256-register budget (one 8-wave workgroup per CU), 8 fit 128 and two workgroups share a
+// CU; f32 accumulators are half as wide, so 32 chains per workgroup fit the 128-register budget as well.
+// Measured (profiles/r6_experiments.md, cfg4's pipeline at 8 192 chains, TFLOP/s at 4D² per leapfrog; step-synchronous kernels in brackets):
+//   f64  D = 384: (6,2,2) 30.5 [23.1];  D = 512: (8,2,2) 42.9 and (8,1,4) 25.8 against round 4's k_dense_epoch 43.9 — two 16-chain workgroups per CU
+//        stream the matrices twice as often and serve half as many chains per latency-bound phase: kept as the record of that experiment;
+//   f32  D = 256: (4,1,4) 35.1 [21.1];  384: (6,2,3) 41.8 [29.8];  512: (8,1,4) 51.5, (8,2,2) 50.9, (8,2,4) 30.5 [34.1];  768: (12,2,3) 54.2 [42.3].
+#define AHMC_EPOCH2_SHAPES(X) \
+  X(double, 6, 2, 2) X(double, 8, 1, 4) X(double, 8, 2, 2) \
+  X(float, 4, 1, 4) X(float, 6, 2, 3) X(float, 8, 1, 4) X(float, 12, 2, 3)
+template <class T>
+inline bool epoch2_shape(int D, int want_nct, int& nct, int& wpe, int want_wpe = 0) {
+  if (D % DE2_RW != 0) return false;
+  const int nw = D / DE2_RW;
+  nct = wpe = 0;
+  // the default of a (T, NW) is its LAST listed shape unless `want_nct` / `want_wpe` (AHMC_DENSE_EPOCH_NCT / _WPE) name another
+#define AHMC_E2_PICK(TT, NW_, NCT_, WPE_) \
+  if (std::is_same<T, TT>::value && nw == NW_ && (want_nct == 0 || want_nct == NCT_) && (want_wpe == 0 || want_wpe == WPE_)) { nct = NCT_; wpe = WPE_; }
+  AHMC_EPOCH2_SHAPES(AHMC_E2_PICK)
+#undef AHMC_E2_PICK
+  if (!nct && (want_nct || want_wpe)) return epoch2_shape<T>(D, 0, nct, wpe, 0);
+  return nct != 0;
+}
+template <class T>
+inline void launch_epoch2(int D, int nct, int wpe, unsigned grid, hipStream_t st, const KP<T>& p, const DP2<T>& q2, const T* Asw, int steps) {
+  const int nw = D / DE2_RW;
+#define AHMC_E2_LAUNCH(TT, NW_, NCT_, WPE_) \
+  if constexpr (std::is_same<T, TT>::value) { \
+    if (nw == NW_ && nct == NCT_ && wpe == WPE_) { \
+      static const bool dbg_ = getenv("AHMC_DEBUG") != nullptr; \
+      static bool said_ = false; \
+      if (dbg_ && !said_) { \
+        said_ = true; \
+        int occ_ = 0; \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_, reinterpret_cast<const void*>(&k_dense_epoch2<T, NW_, NCT_, WPE_>), 64 * NW_, 0); \
+        fprintf(stderr, "[ahmc] k_dense_epoch2<%s,%d,%d,%d>: %d workgroups of %d waves per CU, grid %u\n", sizeof(T) == 8 ? "double" : "float", NW_, NCT_, WPE_, occ_, NW_, grid); \
+      } \
+      hipLaunchKernelGGL((k_dense_epoch2<T, NW_, NCT_, WPE_>), dim3(grid), dim3(64 * NW_), 0, st, p, q2, Asw, steps); \
+      return; \
+    } \
+  }
+  AHMC_EPOCH2_SHAPES(AHMC_E2_LAUNCH)
+#undef AHMC_E2_LAUNCH
+}
+
 template <class T>
 int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, double refresh_alpha, bool accum,
                        int n_trans, T* samples_dev, int64_t adapt_i0 = -1, int64_t adapt_n = 0) {  // adapt_i0 >= 0: StepSizeAdaptor inside the kernel
@@ -603,12 +649,25 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // the next first half-step of 32 chains per workgroup); fewer chains — the tail of a batch — keep the step-synchronous kernels.
   const int epoch_env = getenv("AHMC_DENSE_EPOCH") ? atoi(getenv("AHMC_DENSE_EPOCH")) : 1;
   const int64_t epoch_min = getenv("AHMC_DENSE_EPOCH_MIN") ? atoll(getenv("AHMC_DENSE_EPOCH_MIN")) : 2048;
-  const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && sizeof(T) == 8 && (c->D == 512 || c->D == 256);
+  // Round 6: k_dense_epoch2 serves D = 256 / 384 / 512 / 768 / 1 024 in Float64 and Float32 (AHMC_DENSE_EPOCH_V=1: round 4's k_dense_epoch,
+  // D = 256 / 512 in Float64 only — kept for A/B runs).  Its shape — column tiles per workgroup, waves per SIMD it is compiled for — comes from
+  // epoch2_shape (AHMC_DENSE_EPOCH_NCT=1|2 picks among the compiled ones).
+  // default: round 4's kernel where it exists (f64 D = 512: 43.9 against 42.9 TFLOP/s, D = 256: 28.4 against 18.0 for four 64-row waves —
+  // profiles/r6_experiments.md), k_dense_epoch2 everywhere else
+  const bool v1_has = sizeof(T) == 8 && (c->D == 512 || c->D == 256);
+  const int epoch_v = getenv("AHMC_DENSE_EPOCH_V") ? atoi(getenv("AHMC_DENSE_EPOCH_V")) : (v1_has ? 1 : 2);
+  int e2_nct = 0, e2_wpe = 0;
+  const bool epoch2_ok = epoch_v >= 2 && epoch2_shape<T>((int)c->D, getenv("AHMC_DENSE_EPOCH_NCT") ? atoi(getenv("AHMC_DENSE_EPOCH_NCT")) : 0, e2_nct, e2_wpe,
+                                                                 getenv("AHMC_DENSE_EPOCH_WPE") ? atoi(getenv("AHMC_DENSE_EPOCH_WPE")) : 0);
+  const bool epoch1_ok = !epoch2_ok && v1_has;
+  const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && (epoch2_ok || epoch1_ok);
+  const int epoch_chains = epoch2_ok ? 16 * e2_nct : DE_CHAINS;
   q2.lazy_gw = (epoch_ok && (getenv("AHMC_DENSE_LAZY_GW") ? atoi(getenv("AHMC_DENSE_LAZY_GW")) : 1)) ? 1 : 0;  // (for the whole batch: the step-synchronous kernels of its tail must not trust a record the epoch kernel skipped)
   if (epoch_ok) {
     if (!c->dn_Asw) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->dn_Asw), 2 * sizeof(T) * (size_t)c->D * (size_t)c->D));
     const int64_t tot = 2 * c->D * c->D;
-    hipLaunchKernelGGL((k_dense_swizzle<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->tparams, c->dn_C, c->dn_Asw, (int)c->D, (int)(c->D / 128));
+    if (epoch2_ok) hipLaunchKernelGGL((k_dense_swizzle2<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->tparams, c->dn_C, c->dn_Asw, (int)c->D, (int)(c->D / DE2_RW));
+    else hipLaunchKernelGGL((k_dense_swizzle<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->tparams, c->dn_C, c->dn_Asw, (int)c->D, (int)(c->D / 128));
     HIPCHK(hipGetLastError());
   }
 #ifdef AHMC_EPOCH_PROF
@@ -620,8 +679,13 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   q2.prof = prof_dev;
 #endif
   auto launch_epoch = [&](hipStream_t st, int steps) {
+    const unsigned grid = (unsigned)((q2.n_list + epoch_chains - 1) / epoch_chains);
+    if (epoch2_ok) {
+      launch_epoch2<T>((int)c->D, e2_nct, e2_wpe, grid, st, p, q2, c->dn_Asw, steps);
+      c->dn_epoch_launches += 1;
+      return;
+    }
     if constexpr (sizeof(T) == 8) {
-      const unsigned grid = (unsigned)((q2.n_list + DE_CHAINS - 1) / DE_CHAINS);
       if (c->D == 256) hipLaunchKernelGGL((k_dense_epoch<T, 2>), dim3(grid), dim3(64 * DE_WAVES), 0, st, p, q2, c->dn_Asw, steps);
       else hipLaunchKernelGGL((k_dense_epoch<T, 4>), dim3(grid), dim3(64 * DE_WAVES), 0, st, p, q2, c->dn_Asw, steps);
       c->dn_epoch_launches += 1;
