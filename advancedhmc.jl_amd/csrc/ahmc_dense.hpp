@@ -1603,12 +1603,16 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
     const T* W = q.dense_metric ? ppt(q, p, cur, PV_W, c) : nullptr;
     const T* g_in = q.staged ? p.g() + c * D : G;  // staged: the target kernel left g′ in the context's array
     const T e = q.es[c];
+    // TemperedLeapfrog (src/integrator.jl:198-209), round 6: every NUTS leaf is step(lf, h, z, 1) — r·√α before its first half-step (below),
+    // r/√α after its second; v = M⁻¹r is carried by the same recurrence and scales with r
+    const bool tmp = p.lf.kind == 2;
+    const T sqa = tmp ? p.lf.sqrt_alpha : T(1);
     T s[2] = {0, 0};
     auto second_half = [&](int d, T& o_th, T& o_r, T& o_g, T& o_v, T& o_w) {
       const T gd = g_in[d], td = TH[d], wd = W ? W[d] : T(0);
       T rn = R[d], vn;
-      if (e != T(0)) rn = rn - e / 2 * gd;
-      if (W) vn = e != T(0) ? V[d] - e / 2 * wd : V[d];
+      if (e != T(0)) { rn = rn - e / 2 * gd; if (tmp) rn = rn / sqa; }
+      if (W) { vn = e != T(0) ? V[d] - e / 2 * wd : V[d]; if (tmp && e != T(0)) vn = vn / sqa; }
       else vn = minv ? minv[per_chain ? c * D + d : d] * rn : rn;
       if (e != T(0) || !W) { R[d] = rn; V[d] = vn; }
       if (q.staged) G[d] = gd;
@@ -1648,9 +1652,11 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
     T* dV = ppt(q, p, dst, PV_V, c);
     T* th_st = q.staged ? p.th() + c * D : nullptr;
     const bool dm = q.dense_metric != 0;
+    const bool tmp1 = p.lf.kind == 2;
+    const T sqa1 = tmp1 ? p.lf.sqrt_alpha : T(1);
     auto first_half = [&](int d, T td, T rd, T gd, T vd, T wd) {
-      const T rh = rd - e / 2 * gd;
-      const T vh = dm ? vd - e / 2 * wd : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
+      const T rh = (tmp1 ? rd * sqa1 : rd) - e / 2 * gd;
+      const T vh = dm ? (tmp1 ? vd * sqa1 : vd) - e / 2 * wd : (minv ? minv[per_chain ? c * D + d : d] * rh : rh);
       const T tn = td + e * vh;
       dR[d] = rh;
       dV[d] = vh;
@@ -1773,6 +1779,8 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, w = tid >> 6, qd = lane >> 4, n16 = lane & 15;
+    const bool tmp = p.lf.kind == 2;                      // TemperedLeapfrog (src/integrator.jl:198-209)
+    const T sqa = tmp ? p.lf.sqrt_alpha : T(1);            // √α (not `sa`: the tree phase has a sum of that name)
     const T2* Ap = reinterpret_cast<const T2*>(Asw) + (size_t)w * RT * 64 + lane;
     // ---- the columns of this step: the point each chain's leapfrog in flight sits on ----
     const T* Bp[DE_NCT];
@@ -1877,6 +1885,7 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
             for (int h = 0; h < 2; ++h) {
               rr[h] = rr[h] - e / 2 * g2[h];
               vv[h] = vv[h] - e / 2 * w2[h];
+              if (tmp) { rr[h] = rr[h] / sqa; vv[h] = vv[h] / sqa; }   // TemperedLeapfrog: r/√α after the second half-step (k_d_tree2)
             }
             DE_STORE(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd, rr);
             DE_STORE(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd, vv);
@@ -1885,8 +1894,8 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
               T2 rh, vh, tn;  // holder can name whatever the tree decides; the tree phase adopts it or takes the half-step itself
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
-                rh[h] = rr[h] - e / 2 * g2[h];
-                vh[h] = vv[h] - e / 2 * w2[h];
+                rh[h] = (tmp ? rr[h] * sqa : rr[h]) - e / 2 * g2[h];
+                vh[h] = (tmp ? vv[h] * sqa : vv[h]) - e / 2 * w2[h];
                 tn[h] = th2[it][h] + e * vh[h];
               }
               DE_STORE(ppt(q, p, sp, PV_R, (int64_t)m.c) + dd, rh);
@@ -1960,8 +1969,8 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
               T2 rh, vh, tn;
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
-                rh[h] = x[1][h] - e / 2 * x[2][h];
-                vh[h] = x[3][h] - e / 2 * x[4][h];
+                rh[h] = (tmp ? x[1][h] * sqa : x[1][h]) - e / 2 * x[2][h];
+                vh[h] = (tmp ? x[3][h] * sqa : x[3][h]) - e / 2 * x[4][h];
                 tn[h] = x[0][h] + e * vh[h];
               }
               *reinterpret_cast<T2*>(dR + d) = rh;
@@ -2074,6 +2083,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, w = tid >> 6, qd = lane >> 4, n16 = lane & 15;
+    const bool tmp = p.lf.kind == 2;                      // TemperedLeapfrog (src/integrator.jl:198-209)
+    const T sqa = tmp ? p.lf.sqrt_alpha : T(1);            // √α (not `sa`: the tree phase has a sum of that name)
     const T2* Ap = reinterpret_cast<const T2*>(Asw) + (size_t)w * RT * 64 + lane;
     // ---- the columns of this step: the point each chain's leapfrog in flight sits on ----
     const T* Bp[NCT];
@@ -2171,12 +2182,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             const int sp = spec_pt[16 * ct + nn];
             if (e != T(0)) {
 #pragma unroll
-              for (int h = 0; h < 2; ++h) rr[h] = rr[h] - e / 2 * g2[h];
+              for (int h = 0; h < 2; ++h) {
+                rr[h] = rr[h] - e / 2 * g2[h];
+                if (tmp) rr[h] = rr[h] / sqa;   // TemperedLeapfrog: r/√α after the second half-step (k_d_tree2)
+              }
               DE_STORE(ppt(q, p, m.cur, PV_R, (int64_t)m.c) + dd, rr);
               if (sp >= 0) {  // the first half of the NEXT leapfrog if the tree goes on from this point with this step (k_dense_epoch)
                 T2 rh;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) rh[h] = rr[h] - e / 2 * g2[h];
+                for (int h = 0; h < 2; ++h) rh[h] = (tmp ? rr[h] * sqa : rr[h]) - e / 2 * g2[h];
                 DE_STORE(ppt(q, p, sp, PV_R, (int64_t)m.c) + dd, rh);
               }
             }
@@ -2220,13 +2234,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             T2 vv = v2[it];
             if (e != T(0)) {
 #pragma unroll
-              for (int h = 0; h < 2; ++h) vv[h] = vv[h] - e / 2 * w2[h];
+              for (int h = 0; h < 2; ++h) {
+                vv[h] = vv[h] - e / 2 * w2[h];
+                if (tmp) vv[h] = vv[h] / sqa;
+              }
               DE_STORE(ppt(q, p, m.cur, PV_V, (int64_t)m.c) + dd, vv);
               if (sp >= 0) {
                 T2 vh, tn;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                  vh[h] = vv[h] - e / 2 * w2[h];
+                  vh[h] = (tmp ? vv[h] * sqa : vv[h]) - e / 2 * w2[h];
                   tn[h] = th2[it][h] + e * vh[h];
                 }
                 DE_STORE(ppt(q, p, sp, PV_V, (int64_t)m.c) + dd, vh);
@@ -2297,8 +2314,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
               T2 rh, vh, tn;
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
-                rh[h] = x[1][h] - e / 2 * x[2][h];
-                vh[h] = x[3][h] - e / 2 * x[4][h];
+                rh[h] = (tmp ? x[1][h] * sqa : x[1][h]) - e / 2 * x[2][h];
+                vh[h] = (tmp ? x[3][h] * sqa : x[3][h]) - e / 2 * x[4][h];
                 tn[h] = x[0][h] + e * vh[h];
               }
               *reinterpret_cast<T2*>(dR + d) = rh;

@@ -506,7 +506,7 @@ void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, cons
 //   f32  D = 256: (4,1,4) 35.1 [21.1];  384: (6,2,3) 41.8 [29.8];  512: (8,1,4) 51.5, (8,2,2) 50.9, (8,2,4) 30.5 [34.1];  768: (12,2,3) 54.2 [42.3].
 #define AHMC_EPOCH2_SHAPES(X) \
   X(double, 6, 2, 2) X(double, 8, 1, 4) X(double, 8, 2, 2) \
-  X(float, 4, 1, 4) X(float, 6, 2, 3) X(float, 8, 1, 4) X(float, 12, 2, 3)
+  X(float, 4, 1, 3) X(float, 6, 2, 3) X(float, 8, 1, 4) X(float, 12, 2, 3)
 template <class T>
 inline bool epoch2_shape(int D, int want_nct, int& nct, int& wpe, int want_wpe = 0) {
   if (D % DE2_RW != 0) return false;
@@ -549,8 +549,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   if (rc) return rc;
   if (criterion < AHMC_TC_CLASSIC || criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
   if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");
-  if (adapt_i0 >= 0 && !(criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED && refresh_alpha == 0))
-    return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: the in-kernel StepSizeAdaptor needs the point-pool kernel (GeneralisedNoUTurn, untempered, full refreshment)");
+  if (adapt_i0 >= 0 && !(criterion == AHMC_TC_GENERALISED && refresh_alpha == 0))
+    return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: the in-kernel StepSizeAdaptor needs the point-pool kernel (GeneralisedNoUTurn, full refreshment)");
   if (adapt_i0 >= 0 && getenv("AHMC_DENSE_POOL") && atoi(getenv("AHMC_DENSE_POOL")) == 0)  // (the caller decides from the same variable; checked again here
     return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: AHMC_DENSE_POOL=0 selects the copying tree kernel, which has no in-kernel StepSizeAdaptor");  // because a silent unadapted warm-up is the alternative)
   if (refresh_alpha != 0 && n_trans > 1) {
@@ -582,7 +582,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // The default NUTS (GeneralisedNoUTurn, untempered) runs on the point pool (k_d_tree2: no park / candidate / edge copies);
   // the other criteria and the TemperedLeapfrog on the copying kernel.  AHMC_DENSE_POOL=0 forces the latter (A/B, tests).
   const int pool_env = getenv("AHMC_DENSE_POOL") ? atoi(getenv("AHMC_DENSE_POOL")) : 1;
-  const bool pool = pool_env != 0 && criterion == AHMC_TC_GENERALISED && c->integ_kind != AHMC_INTEGRATOR_TEMPERED;
+  const bool pool = pool_env != 0 && criterion == AHMC_TC_GENERALISED;   // (round 6: TemperedLeapfrog in the pool kernels and the epoch kernels)
   c->dn_last_pool = pool ? 1 : 0;
   DP2<T> q2;
   memset(&q2, 0, sizeof(q2));

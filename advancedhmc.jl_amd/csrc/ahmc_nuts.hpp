@@ -237,7 +237,7 @@ typedef DrawStreamT<false> DrawStream;
 template <class T, int G, int E, int MODE, int TK>
 // (round 3: the warm-up instantiations capped for 3 waves per SIMD instead of 4 — 168 VGPRs, no spills, 12 LDS slots — run at 2.24e9
 // in-kernel against 2.37e9: occupancy matters more than the spills.)
-__global__ __launch_bounds__((G > 256 ? G : 256), (MODE == 2 ? (E <= 2 ? 3 : 2) : (E <= 2 ? 4 : (E <= 4 ? 3 : 2)))) void k_nuts(KP<T> p) {
+__global__ __launch_bounds__((G > 256 ? G : 256), (E >= 16 ? 1 : (MODE == 2 ? (E <= 2 ? 3 : 2) : (E <= 2 ? 4 : (E <= 4 ? 3 : 2))))) void k_nuts(KP<T> p) {
   constexpr int CPW = G >= 64 ? 1 : 64 / G;  // chains per wave (G > 64: one chain per workgroup of G/64 waves)
   // A chain that owns whole waves makes every per-chain predicate wave-uniform; saying so (a ballot is uniform by
   // construction) turns the exec-mask save/restore of divergent branches into scalar branches and keeps the

@@ -1214,11 +1214,15 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
     # the vector passes) and 768 (twelve), in Float32 (v_mfma_f32_16x16x4_f32, two 32-chain workgroups per CU), and the 16-chain shape of D = 512
     cases = ((512, 2304, None, A.MultinomialTS, np.float64, None), (512, 2090, "5", A.MultinomialTS, np.float64, None),
              (512, 1100, None, A.SliceTS, np.float64, None), (256, 1300, None, A.MultinomialTS, np.float64, None),
-             (512, 1200, None, A.MultinomialTS, np.float64, "1"), (384, 1100, None, A.MultinomialTS, np.float64, None),
+             (512, 1200, None, A.MultinomialTS, np.float64, "1"), (512, 1100, None, A.MultinomialTS, np.float64, "2"),
+             (384, 1100, None, A.MultinomialTS, np.float64, None),
              (512, 1300, None, A.MultinomialTS, np.float32, None), (512, 1100, "5", A.SliceTS, np.float32, "1"),
              (256, 1100, None, A.MultinomialTS, np.float32, None), (384, 1100, None, A.MultinomialTS, np.float32, None),
-             (768, 1100, None, A.MultinomialTS, np.float32, None))
-    for D, N, chunk, sampler, dtype, nct in cases:
+             (768, 1100, None, A.MultinomialTS, np.float32, None),
+             # TemperedLeapfrog (src/integrator.jl:198-209) in the epilogues and the speculative half-step: round 4's kernel, k_dense_epoch2, Float32
+             (512, 1100, None, A.MultinomialTS, np.float64, None, 1.05), (384, 1100, "5", A.MultinomialTS, np.float64, None, 1.03),
+             (512, 1100, None, A.SliceTS, np.float32, None, 1.05))
+    for D, N, chunk, sampler, dtype, nct, *temper in cases:
         if D not in mats:
             idx = np.arange(D)
             Pm = np.asfortranarray(np.linalg.inv(0.9 ** np.abs(idx[:, None] - idx[None, :])))
@@ -1238,7 +1242,7 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
                     monkeypatch.setenv(var, val)
                 else:
                     monkeypatch.delenv(var, raising=False)
-            lf = A.Leapfrog(eps0)
+            lf = A.TemperedLeapfrog(eps0, temper[0]) if temper else A.Leapfrog(eps0)
             k = A.HMCKernel(A.Trajectory(sampler, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
             g = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), A.DenseGaussian(P)), N, dtype=dtype, rng=A.PhiloxRNG(78), lib=hip)
             g.set_integrator(lf)
