@@ -1940,7 +1940,7 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
       }
       const int dense_pool_env = getenv("AHMC_DENSE_POOL") ? atoi(getenv("AHMC_DENSE_POOL")) : 1;  // (per call, as dn_nuts_transition reads it)
       if (adapting && fused_adapt && dense_pool_env != 0 && cfg->nuts && dense_engine(c) && c->adapt_kind == AHMC_ADAPT_STEPSIZE &&
-          cfg->criterion == AHMC_TC_GENERALISED && (cfg->sampler == AHMC_TS_MULTINOMIAL || cfg->sampler == AHMC_TS_SLICE) &&
+          (cfg->sampler == AHMC_TS_MULTINOMIAL || cfg->sampler == AHMC_TS_SLICE) &&
           cfg->refresh_alpha == 0 && c->target_kind != AHMC_TARGET_EXTERNAL &&
           (!so || !keep || so_on_device)) {
         // dense engine, StepSizeAdaptor: the warm-up in batches too — every chain adapts its own ϵ at the end of each of its

@@ -1078,11 +1078,13 @@ struct DChain2 {
   int32_t phase, it, jw, leaf, v, cur_is_left, na_tree, depth, numerical;
   uint32_t k;
   int8_t p_first[DN_MAXLEV], p_cand[DN_MAXLEV];  // per pending level: point of its first-built leaf, point of its candidate
-  int8_t cur, oth, cand, pad_;                   // the leaf in flight (moving edge), the other edge, the tree-level candidate
-};
+  int8_t p_last[DN_MAXLEV];                      // … and of its last-built leaf (StrictGeneralisedNoUTurn: the inner ends of a merge, :597-615)
+  int8_t cur, oth, cand, edge;                   // the leaf in flight (moving edge), the other edge, the tree-level candidate; the edge the
+};                                               // doubling in progress grew from (Strict: the old tree's inner end at the top-level merge)
 
-static_assert(offsetof(DChain2<double>, p_first) % 8 == 0 && offsetof(DChain2<double>, p_cand) == offsetof(DChain2<double>, p_first) + DN_MAXLEV && DN_MAXLEV == 16,
-              "d_tree_advance2 reads p_first / p_cand as four 8-byte words");
+static_assert(offsetof(DChain2<double>, p_first) % 8 == 0 && offsetof(DChain2<double>, p_cand) == offsetof(DChain2<double>, p_first) + DN_MAXLEV &&
+                  offsetof(DChain2<double>, p_last) == offsetof(DChain2<double>, p_first) + 2 * DN_MAXLEV && DN_MAXLEV == 16,
+              "d_tree_advance2 reads p_first / p_cand / p_last as six 8-byte words");
 
 // the scalars of a chain every call needs: read at the top of k_d_tree2, together with the energies and the step, so that the
 // tree bookkeeping does not start with a memory round trip of its own after the second half-step's reduction
@@ -1091,7 +1093,7 @@ struct DHot {
   T H0, eps, lu;
   int32_t phase, it, jw, leaf, v, cur_is_left, numerical;
   uint32_t k;
-  int cur, oth, cand;
+  int cur, oth, cand, edge;
 };
 
 template <class T>
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_d_tree2_reset(DChain2<T>* S, T* es, int
   if (c >= N) return;
   S[c].phase = DPH_START;
   S[c].it = 0;
-  S[c].cur = S[c].oth = S[c].cand = 0;
+  S[c].cur = S[c].oth = S[c].cand = S[c].edge = 0;
   es[c] = T(0);
   ptcur[c] = 0;
 }
@@ -1171,7 +1173,12 @@ __device__ __forceinline__ void dn_chain_barrier() {
 // DC > 0: D at compile time — the vector passes go through dn_vec_pass (other element order: the sums differ in the last bits
 // from the run-time loops')
 // VCH: dn_vec_pass's chunk cap (registers of operands in flight)
-template <class T, int DT, bool WV = false, int DC = 0, int VCH = 8>
+// CRIT (round 6): the termination criterion, AHMC_TC_* — 1 GeneralisedNoUTurn (:566-570); 0 ClassicNoUTurn (:551-557): no ρ at all, the
+// test needs θ and v at the two ends of a (sub)tree, which are pool points already; 2 StrictGeneralisedNoUTurn (:579-617): two more
+// index holders — per pending level its LAST-built leaf (p_last), per doubling the edge it grew from (S.edge) — and at every merge the two
+// extra checks (ρ_F + r_S.first ; ends F.first, S.first) and (r_F.last + ρ_S ; ends F.last, S.last) for F = the first-built half, S = the
+// second.  Before round 6 these two criteria ran on the copying kernel k_d_tree_crit only.
+template <class T, int DT, bool WV = false, int DC = 0, int VCH = 8, int CRIT = 1>
 __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, int64_t c, int lane, T lp_in, T lk_in, const DHot<T>& hot, int& src,
                                              uint64_t& used, bool& rewritten /* the point `src` was given a fresh momentum in this call */) {
   rewritten = false;
@@ -1180,12 +1187,18 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
   const bool slice = p.sampler == 2;
   // DC > 0: the points of the pending levels (p_first, p_cand: 32 bytes) come in with the first round trip, so a merge does not
   // start with a dependent load of its own
-  unsigned long long pfw[4] = {0, 0, 0, 0};
+  constexpr int NPFW = CRIT == 2 ? 6 : 4;
+  unsigned long long pfw[NPFW] = {};
   if constexpr (DC > 0) {
     const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(S.p_first);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pfw[i] = pp[i];
+    for (int i = 0; i < NPFW; ++i) pfw[i] = pp[i];
   }
+  auto lvl_last = [&](int l) -> int {   // (Strict only)
+    if constexpr (CRIT != 2) return 0;
+    else if constexpr (DC > 0) return (int)(int8_t)((l < 8 ? pfw[NPFW - 2] : pfw[NPFW - 1]) >> (8 * (l & 7)));
+    else return S.p_last[l];
+  };
   auto lvl_first = [&](int l) -> int {
     if constexpr (DC > 0) return (int)(int8_t)((l < 8 ? pfw[0] : pfw[1]) >> (8 * (l & 7)));
     else return S.p_first[l];
@@ -1276,6 +1289,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       na_c = S.pna[lvl] + na_c;
       const T dh_p = S.pdh[lvl];
       dh_c = v > 0 ? maxabs(dh_p, dh_c) : maxabs(dh_c, dh_p);
+      if constexpr (CRIT == 1) {
       // ρ = ρ_first + ρ_second; generalised_uturn_criterion with v = M⁻¹r at the two ends (:566-570,619-621)
       T dots[2] = {0, 0};
       if constexpr (DC > 0) {
@@ -1299,6 +1313,70 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       first_c = pf;
       block_allsum2<DT>(dots[0], dots[1]);
       sub_term = (dots[0] <= 0) || (dots[1] <= 0);
+      } else if constexpr (CRIT == 0) {
+        // ClassicNoUTurn (:551-557): ends = the pending half's first-built leaf and the current leaf, left / right by the direction;
+        // Δθ = θ_right − θ_left; terminated if Δθ·M⁻¹(−r_left) >= 0 or −Δθ·M⁻¹r_right >= 0 (the products as the reference forms them)
+        const T* th_f = ppt(q, p, pf, PV_TH, c);
+        const T* th_c = ppt(q, p, cur, PV_TH, c);
+        T dots[2] = {0, 0};
+        auto el = [&](T tf, T tc, T vf, T vc) {
+          const T thl = v > 0 ? tf : tc, thr = v > 0 ? tc : tf, vl = v > 0 ? vf : vc, vr = v > 0 ? vc : vf;
+          const T dth = thr - thl;
+          dots[0] += dth * (-vl);
+          dots[1] += (-dth) * vr;
+        };
+        if constexpr (DC > 0) {
+          typedef T T2 __attribute__((ext_vector_type(2)));
+          const T* const srcs[4] = {th_f, th_c, p_vf, Vc};
+          dn_vec_pass<T, DT, DC, 4, VCH>(lane, srcs, [&](int, const T2 (&x)[4]) {
+            el(x[0][0], x[1][0], x[2][0], x[3][0]);
+            el(x[0][1], x[1][1], x[2][1], x[3][1]);
+          });
+        } else {
+          for (int d = lane; d < D; d += DT) el(th_f[d], th_c[d], p_vf[d], Vc[d]);
+        }
+        first_c = pf;  // the merged subtree's first-built leaf is the pending half's
+        block_allsum2<DT>(dots[0], dots[1]);
+        sub_term = (dots[0] >= 0) || (dots[1] >= 0);
+      } else {
+        // StrictGeneralisedNoUTurn (:579-617).  F = the pending (first-built) half — first leaf pf, last leaf pl, ρ_F —, S = the half just
+        // completed — first leaf first_c, last leaf cur, ρ_S:
+        //   (ρ_F + ρ_S ; ends F.first, S.last)   (ρ_F + r_S.first ; ends F.first, S.first)   (r_F.last + ρ_S ; ends F.last, S.last)
+        const int pl = lvl_last(lvl);
+        const T* r_sf = ppt(q, p, first_c, PV_R, c);
+        const T* v_sf = ppt(q, p, first_c, PV_V, c);
+        const T* r_fl = ppt(q, p, pl, PV_R, c);
+        const T* v_fl = ppt(q, p, pl, PV_V, c);
+        T dots[6] = {0, 0, 0, 0, 0, 0};
+        auto el = [&](T rf, T rs, T rsf, T rfl, T vff, T vsl, T vsf, T vfl) -> T {
+          const T rho = rf + rs, rho2 = rf + rsf, rho3 = rfl + rs;
+          dots[0] += rho * vff;
+          dots[1] += rho * vsl;
+          dots[2] += rho2 * vff;
+          dots[3] += rho2 * vsf;
+          dots[4] += rho3 * vfl;
+          dots[5] += rho3 * vsl;
+          return rho;
+        };
+        if constexpr (DC > 0) {
+          typedef T T2 __attribute__((ext_vector_type(2)));
+          const T* const srcs[8] = {p_rho, rho_v, r_sf, r_fl, p_vf, Vc, v_sf, v_fl};
+          dn_vec_pass<T, DT, DC, 8, VCH>(lane, srcs, [&](int d, const T2 (&x)[8]) {
+            T2 rho;
+            rho[0] = el(x[0][0], x[1][0], x[2][0], x[3][0], x[4][0], x[5][0], x[6][0], x[7][0]);
+            rho[1] = el(x[0][1], x[1][1], x[2][1], x[3][1], x[4][1], x[5][1], x[6][1], x[7][1]);
+            *reinterpret_cast<T2*>(out + d) = rho;
+          });
+        } else {
+          for (int d = lane; d < D; d += DT) out[d] = el(p_rho[d], rho_v[d], r_sf[d], r_fl[d], p_vf[d], Vc[d], v_sf[d], v_fl[d]);
+        }
+        rho_v = out;
+        first_c = pf;
+        block_allsum2<DT>(dots[0], dots[1]);
+        block_allsum2<DT>(dots[2], dots[3]);
+        block_allsum2<DT>(dots[4], dots[5]);
+        sub_term = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
+      }
       merged = lvl + 1;
     }
     bool subtree_over = true;
@@ -1317,12 +1395,17 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       // park the finished level-nm subtree until its sibling is built: indices and scalars only (its ρ is the first leaf's r
       // at level 0 and already sits in the level's slot otherwise)
       uint64_t u = bit(cur) | bit(oth) | bit(cand_tree) | bit(first_c) | bit(cand_c);
+      if constexpr (CRIT == 2) u |= bit(hot.edge);   // (cur is the parked subtree's last-built leaf: already in the mask)
       for (int l = 0; l < DN_MAXLEV; ++l)
-        if (l != nm && (((uint32_t)leaf >> l) & 1u)) u |= bit(lvl_first(l)) | bit(lvl_cand(l));
+        if (l != nm && (((uint32_t)leaf >> l) & 1u)) {
+          u |= bit(lvl_first(l)) | bit(lvl_cand(l));
+          if constexpr (CRIT == 2) u |= bit(lvl_last(l));
+        }
       dn_chain_barrier<WV>();  // (all threads have read p_first / p_cand of the pending levels)
       if (lane == 0) {
         S.p_first[nm] = (int8_t)first_c;
         S.p_cand[nm] = (int8_t)cand_c;
+        if constexpr (CRIT == 2) S.p_last[nm] = (int8_t)cur;
         S.pw[nm] = w_c;
         S.psa[nm] = sa_c;
         S.pdh[nm] = dh_c;
@@ -1360,6 +1443,68 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
     w_tree = slice ? w_tree + w_c : logaddexp(w_tree, w_c);
     // isterminated on the whole tree; its edges are `cur` and the other one
     bool turn;
+    if constexpr (CRIT == 0) {
+      // ClassicNoUTurn on the whole tree: ends `oth` and `cur`, left / right by the direction of this doubling
+      const T* th_o = ppt(q, p, oth, PV_TH, c);
+      const T* th_c = ppt(q, p, cur, PV_TH, c);
+      const T* o_v = ppt(q, p, oth, PV_V, c);
+      T dots[2] = {0, 0};
+      auto el = [&](T to, T tc, T vo, T vc) {
+        const T thl = v > 0 ? to : tc, thr = v > 0 ? tc : to, vl = v > 0 ? vo : vc, vr = v > 0 ? vc : vo;
+        const T dth = thr - thl;
+        dots[0] += dth * (-vl);
+        dots[1] += (-dth) * vr;
+      };
+      if constexpr (DC > 0) {
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        const T* const srcs[4] = {th_o, th_c, o_v, Vc};
+        dn_vec_pass<T, DT, DC, 4, VCH>(lane, srcs, [&](int, const T2 (&x)[4]) {
+          el(x[0][0], x[1][0], x[2][0], x[3][0]);
+          el(x[0][1], x[1][1], x[2][1], x[3][1]);
+        });
+      } else {
+        for (int d = lane; d < D; d += DT) el(th_o[d], th_c[d], o_v[d], Vc[d]);
+      }
+      block_allsum2<DT>(dots[0], dots[1]);
+      turn = (dots[0] >= 0) || (dots[1] >= 0);
+    } else if constexpr (CRIT == 2) {
+      // Strict on the whole tree: F = the old tree (first = `oth`, last = the edge this doubling grew from, ρ_F = the tree's ρ), S = the new
+      // subtree (first = first_c, last = `cur`, ρ_S)
+      T* t_rho = prho(q, p, PR_TREE, c);
+      const T* o_v = ppt(q, p, oth, PV_V, c);
+      const int pe = hot.edge;
+      const T* r_sf = ppt(q, p, first_c, PV_R, c);
+      const T* v_sf = ppt(q, p, first_c, PV_V, c);
+      const T* r_fl = ppt(q, p, pe, PV_R, c);
+      const T* v_fl = ppt(q, p, pe, PV_V, c);
+      T dots[6] = {0, 0, 0, 0, 0, 0};
+      auto el = [&](T rf, T rs, T rsf, T rfl, T vff, T vsl, T vsf, T vfl) -> T {
+        const T rho = rf + rs, rho2 = rf + rsf, rho3 = rfl + rs;
+        dots[0] += rho * vsl;   // (the order of the generalised test below: the moving edge first)
+        dots[1] += rho * vff;
+        dots[2] += rho2 * vff;
+        dots[3] += rho2 * vsf;
+        dots[4] += rho3 * vfl;
+        dots[5] += rho3 * vsl;
+        return rho;
+      };
+      if constexpr (DC > 0) {
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        const T* const srcs[8] = {t_rho, rho_v, r_sf, r_fl, o_v, Vc, v_sf, v_fl};
+        dn_vec_pass<T, DT, DC, 8, VCH>(lane, srcs, [&](int d, const T2 (&x)[8]) {
+          T2 rho;
+          rho[0] = el(x[0][0], x[1][0], x[2][0], x[3][0], x[4][0], x[5][0], x[6][0], x[7][0]);
+          rho[1] = el(x[0][1], x[1][1], x[2][1], x[3][1], x[4][1], x[5][1], x[6][1], x[7][1]);
+          *reinterpret_cast<T2*>(t_rho + d) = rho;
+        });
+      } else {
+        for (int d = lane; d < D; d += DT) t_rho[d] = el(t_rho[d], rho_v[d], r_sf[d], r_fl[d], o_v[d], Vc[d], v_sf[d], v_fl[d]);
+      }
+      block_allsum2<DT>(dots[0], dots[1]);
+      block_allsum2<DT>(dots[2], dots[3]);
+      block_allsum2<DT>(dots[4], dots[5]);
+      turn = (dots[0] <= 0) || (dots[1] <= 0) || (dots[2] <= 0) || (dots[3] <= 0) || (dots[4] <= 0) || (dots[5] <= 0);
+    } else
     {
       T* t_rho = prho(q, p, PR_TREE, c);
       const T* o_v = ppt(q, p, oth, PV_V, c);
@@ -1398,6 +1543,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
         S.cand_lp = cand_lp; S.cand_lk = cand_lk;
         S.cand = (int8_t)cand_tree;
         S.oth = (int8_t)new_oth;
+        S.edge = (int8_t)src;   // (Strict: the tree's inner end at this doubling's top-level merge; it stays in `used` while the doubling runs)
         S.numerical = numerical ? 1 : 0;
         S.cur_is_left = vleft ? 1 : 0;
         S.v = vleft ? -1 : 1;
@@ -1561,7 +1707,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
       S.v = vleft ? -1 : 1;
       S.k = ds.k;
       S.it = it;
-      S.cur = S.oth = S.cand = (int8_t)start_pt;
+      S.cur = S.oth = S.cand = S.edge = (int8_t)start_pt;
       S.phase = warm ? DPH_WARM : DPH_RUN;
     }
     src = start_pt;
@@ -1576,7 +1722,7 @@ __device__ __forceinline__ T d_tree_advance2(const KP<T>& p, const DP2<T>& q, in
 // The kernel is a chain of dependent memory round trips (scalars → the point's vectors → [merge operands] → stores); the
 // values of the completed point stay in registers (NE elements per thread) for the first half-step that usually follows from
 // the same point, so that half-step does not read them again.
-template <class T, int DT>
+template <class T, int DT, int CRIT = 1>
 __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __restrict__ minv, int per_chain, int dense_target, int do_post) {
   constexpr int NE = 4;  // elements of a vector a thread keeps in registers (D <= NE·DT: every default thread count)
   const int lane = threadIdx.x;
@@ -1591,7 +1737,7 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
   hot.H0 = S.H0; hot.eps = S.eps; hot.lu = S.lu;
   hot.phase = S.phase; hot.it = S.it; hot.jw = S.jw; hot.leaf = S.leaf; hot.v = S.v; hot.cur_is_left = S.cur_is_left; hot.numerical = S.numerical;
   hot.k = S.k;
-  hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand;
+  hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand; hot.edge = S.edge;
   const int cur = hot.cur;
   const bool in_regs = do_post && D <= NE * DT;
   T k_th[NE], k_r[NE], k_g[NE], k_v[NE], k_w[NE];
@@ -1643,7 +1789,7 @@ __global__ __launch_bounds__(DT) void k_d_tree2(KP<T> p, DP2<T> q, const T* __re
   uint64_t used = 0;
   bool rewritten = false;
   __syncthreads();  // (every thread holds the chain's scalars: from here on thread 0 may update them)
-  const T e = d_tree_advance2<T, DT>(p, q, c, lane, lp, lk, hot, src, used, rewritten);
+  const T e = d_tree_advance2<T, DT, false, 0, 8, CRIT>(p, q, c, lane, lp, lk, hot, src, used, rewritten);
   if (lane == 0) q.es[c] = e;
   if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237): src → a fresh point
     const int dst = __builtin_ctzll(~used);
@@ -1942,7 +2088,7 @@ __global__ __launch_bounds__(64 * DE_WAVES) void k_dense_epoch(KP<T> p, DP2<T> q
           hot.H0 = S.H0; hot.eps = S.eps; hot.lu = S.lu;
           hot.phase = S.phase; hot.it = S.it; hot.jw = S.jw; hot.leaf = S.leaf; hot.v = S.v; hot.cur_is_left = S.cur_is_left; hot.numerical = S.numerical;
           hot.k = S.k;
-          hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand;
+          hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand; hot.edge = S.edge;
           if (l16 == 0) {
             p.lk()[c] = lk;
             p.lp()[c] = lp;
@@ -2049,7 +2195,7 @@ __global__ __launch_bounds__(256) void k_dense_swizzle2(const T* __restrict__ A0
   out[idx] = (m ? A1 : A0)[row + (int64_t)k * D];
 }
 
-template <class T, int NW, int NCT, int WPE>
+template <class T, int NW, int NCT, int WPE, int CRIT = 1>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_dense_epoch2(KP<T> p, DP2<T> q, const T* __restrict__ Asw, int max_steps) {
   using M = Mfma<T>;
   typedef T T2 __attribute__((ext_vector_type(2)));
@@ -2059,7 +2205,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
   constexpr int CPI = 64 / LPC; // chains per instruction there
   constexpr int TP = RW + 2;    // pitch of the transposition tile: conflict-free columns
   constexpr int GL = 16;        // tree phase: lanes per chain, four chains per wave at once
-  constexpr int VCH = WPE >= 4 ? 4 : 8;  // pairs per lane and vector in flight in the tree phase's vector passes
+  constexpr int VCH = (WPE >= 4 || CRIT != 1) ? 4 : 8;  // pairs per lane and vector in flight in the tree phase's vector passes
   constexpr int NIT = 16 / CPI, NB = WPE >= 4 ? 2 : (NIT < AHMC_EPOCH_NB ? NIT : AHMC_EPOCH_NB);  // epilogue: chains per half-wave whose loads are in flight together
   static_assert(NW >= 4 && NW <= 16 && (NCT == 1 || NCT == 2), "k_dense_epoch2: D = 256 … 1024 in steps of 64");
   __shared__ T tile[NW][16][TP];
@@ -2287,7 +2433,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
           hot.H0 = S.H0; hot.eps = S.eps; hot.lu = S.lu;
           hot.phase = S.phase; hot.it = S.it; hot.jw = S.jw; hot.leaf = S.leaf; hot.v = S.v; hot.cur_is_left = S.cur_is_left; hot.numerical = S.numerical;
           hot.k = S.k;
-          hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand;
+          hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand; hot.edge = S.edge;
           if (l16 == 0) {
             p.lk()[c] = lk;
             p.lp()[c] = lp;
@@ -2296,7 +2442,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
           uint64_t used = 0;
           bool rewritten = false;
           dn_chain_barrier<true>();
-          const T e = d_tree_advance2<T, GL, true, D, VCH>(p, q, c, l16, lp, lk, hot, src, used, rewritten);
+          const T e = d_tree_advance2<T, GL, true, D, VCH, CRIT>(p, q, c, l16, lp, lk, hot, src, used, rewritten);
           if (l16 == 0) q.es[c] = e;
           if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237): src → a fresh point
             const DEMeta<T> m = meta[w2][slot];

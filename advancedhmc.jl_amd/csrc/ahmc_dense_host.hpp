@@ -129,8 +129,9 @@ int dn_ensure(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
 // (+ 1: the speculative half-step of k_dense_epoch), and max_depth + 2 ρ vectors (cfg4's shard, D = 512, 8 192 chains, max_depth 10:
 // 3.9 GB + 0.4 GB of the 288)
 template <class T>
-int dn_ensure_pool(Ctx<T>* c, int max_depth) {
-  const int npt = 2 * max_depth + 3, nrho = PR_LEVEL0 + (max_depth > 1 ? max_depth : 2);
+int dn_ensure_pool(Ctx<T>* c, int max_depth, int criterion = AHMC_TC_GENERALISED) {
+  // (StrictGeneralisedNoUTurn holds one more point per pending level — its last-built leaf — and the edge a doubling grew from)
+  const int npt = (criterion == AHMC_TC_STRICT ? 3 * max_depth + 4 : 2 * max_depth + 3), nrho = PR_LEVEL0 + (max_depth > 1 ? max_depth : 2);
   const size_t DN = (size_t)c->D * (size_t)c->N;
   if (npt > c->dn_npt) {
     if (c->dn_P) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->dn_P)); c->dn_P = nullptr; c->dn_npt = 0; }
@@ -507,11 +508,21 @@ void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, cons
 #define AHMC_EPOCH2_SHAPES(X) \
   X(double, 6, 2, 2) X(double, 8, 1, 4) X(double, 8, 2, 2) \
   X(float, 4, 1, 3) X(float, 6, 2, 3) X(float, 8, 1, 4) X(float, 12, 2, 3)
+// … and for ClassicNoUTurn (0) / StrictGeneralisedNoUTurn (2): D = 512 in the one-workgroup shape (the tree phase's vector passes in chunks of four
+// pairs: with eight the register allocator parks spills inside the divergent tree phase and isa_check.py refuses the kernels)
+#define AHMC_EPOCH2_CRIT_SHAPES(X) X(double, 8, 2, 2, 0) X(double, 8, 2, 2, 2) X(float, 8, 2, 2, 0) X(float, 8, 2, 2, 2)
 template <class T>
-inline bool epoch2_shape(int D, int want_nct, int& nct, int& wpe, int want_wpe = 0) {
+inline bool epoch2_shape(int D, int want_nct, int& nct, int& wpe, int want_wpe = 0, int criterion = AHMC_TC_GENERALISED) {
   if (D % DE2_RW != 0) return false;
   const int nw = D / DE2_RW;
   nct = wpe = 0;
+  if (criterion != AHMC_TC_GENERALISED) {
+#define AHMC_E2_PICKC(TT, NW_, NCT_, WPE_, CR_) \
+  if (std::is_same<T, TT>::value && nw == NW_ && criterion == CR_) { nct = NCT_; wpe = WPE_; }
+    AHMC_EPOCH2_CRIT_SHAPES(AHMC_E2_PICKC)
+#undef AHMC_E2_PICKC
+    return nct != 0;
+  }
   // the default of a (T, NW) is its LAST listed shape unless `want_nct` / `want_wpe` (AHMC_DENSE_EPOCH_NCT / _WPE) name another
 #define AHMC_E2_PICK(TT, NW_, NCT_, WPE_) \
   if (std::is_same<T, TT>::value && nw == NW_ && (want_nct == 0 || want_nct == NCT_) && (want_wpe == 0 || want_wpe == WPE_)) { nct = NCT_; wpe = WPE_; }
@@ -521,8 +532,17 @@ inline bool epoch2_shape(int D, int want_nct, int& nct, int& wpe, int want_wpe =
   return nct != 0;
 }
 template <class T>
-inline void launch_epoch2(int D, int nct, int wpe, unsigned grid, hipStream_t st, const KP<T>& p, const DP2<T>& q2, const T* Asw, int steps) {
+inline void launch_epoch2(int D, int nct, int wpe, unsigned grid, hipStream_t st, const KP<T>& p, const DP2<T>& q2, const T* Asw, int steps, int criterion = AHMC_TC_GENERALISED) {
   const int nw = D / DE2_RW;
+  if (criterion != AHMC_TC_GENERALISED) {
+#define AHMC_E2_LAUNCHC(TT, NW_, NCT_, WPE_, CR_) \
+  if constexpr (std::is_same<T, TT>::value) { \
+    if (nw == NW_ && nct == NCT_ && wpe == WPE_ && criterion == CR_) { hipLaunchKernelGGL((k_dense_epoch2<T, NW_, NCT_, WPE_, CR_>), dim3(grid), dim3(64 * NW_), 0, st, p, q2, Asw, steps); return; } \
+  }
+    AHMC_EPOCH2_CRIT_SHAPES(AHMC_E2_LAUNCHC)
+#undef AHMC_E2_LAUNCHC
+    return;
+  }
 #define AHMC_E2_LAUNCH(TT, NW_, NCT_, WPE_) \
   if constexpr (std::is_same<T, TT>::value) { \
     if (nw == NW_ && nct == NCT_ && wpe == WPE_) { \
@@ -549,8 +569,8 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   if (rc) return rc;
   if (criterion < AHMC_TC_CLASSIC || criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
   if (max_depth > DN_MAXLEV + 1) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the dense engine supports max_depth <= 17");
-  if (adapt_i0 >= 0 && !(criterion == AHMC_TC_GENERALISED && refresh_alpha == 0))
-    return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: the in-kernel StepSizeAdaptor needs the point-pool kernel (GeneralisedNoUTurn, full refreshment)");
+  if (adapt_i0 >= 0 && refresh_alpha != 0)
+    return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: the in-kernel StepSizeAdaptor needs full momentum refreshment (the momenta of a batch are drawn up front)");
   if (adapt_i0 >= 0 && getenv("AHMC_DENSE_POOL") && atoi(getenv("AHMC_DENSE_POOL")) == 0)  // (the caller decides from the same variable; checked again here
     return fail(c, AHMC_ERR_UNSUPPORTED, "dense engine: AHMC_DENSE_POOL=0 selects the copying tree kernel, which has no in-kernel StepSizeAdaptor");  // because a silent unadapted warm-up is the alternative)
   if (refresh_alpha != 0 && n_trans > 1) {
@@ -582,7 +602,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // The default NUTS (GeneralisedNoUTurn, untempered) runs on the point pool (k_d_tree2: no park / candidate / edge copies);
   // the other criteria and the TemperedLeapfrog on the copying kernel.  AHMC_DENSE_POOL=0 forces the latter (A/B, tests).
   const int pool_env = getenv("AHMC_DENSE_POOL") ? atoi(getenv("AHMC_DENSE_POOL")) : 1;
-  const bool pool = pool_env != 0 && criterion == AHMC_TC_GENERALISED;   // (round 6: TemperedLeapfrog in the pool kernels and the epoch kernels)
+  const bool pool = pool_env != 0;   // (round 6: every criterion and the TemperedLeapfrog on the pool kernels; AHMC_DENSE_POOL=0: the copying kernels)
   c->dn_last_pool = pool ? 1 : 0;
   DP2<T> q2;
   memset(&q2, 0, sizeof(q2));
@@ -591,12 +611,19 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   T *Pth = nullptr, *Pg = nullptr, *Pw = nullptr;
   const int dtt = dt_threads_for(c->D);
   auto launch_tree2 = [&](unsigned grid, int do_post) {
-    if (dtt == 64) hipLaunchKernelGGL((k_d_tree2<T, 64>), dim3(grid), dim3(64), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);
-    else if (dtt == 128) hipLaunchKernelGGL((k_d_tree2<T, 128>), dim3(grid), dim3(128), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);
-    else hipLaunchKernelGGL((k_d_tree2<T, 256>), dim3(grid), dim3(256), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);
+#define AHMC_TREE2(CR)                                                                                                                        \
+  do {                                                                                                                                        \
+    if (dtt == 64) hipLaunchKernelGGL((k_d_tree2<T, 64, CR>), dim3(grid), dim3(64), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);     \
+    else if (dtt == 128) hipLaunchKernelGGL((k_d_tree2<T, 128, CR>), dim3(grid), dim3(128), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post); \
+    else hipLaunchKernelGGL((k_d_tree2<T, 256, CR>), dim3(grid), dim3(256), 0, c->stream, p, q2, minv_d, pc, dt ? 1 : 0, do_post);             \
+  } while (0)
+    if (criterion == AHMC_TC_CLASSIC) AHMC_TREE2(0);
+    else if (criterion == AHMC_TC_STRICT) AHMC_TREE2(2);
+    else AHMC_TREE2(1);
+#undef AHMC_TREE2
   };
   if (pool) {
-    rc = dn_ensure_pool(c, max_depth);
+    rc = dn_ensure_pool(c, max_depth, criterion);
     if (rc) return rc;
     q2.P = c->dn_P; q2.R = c->dn_R; q2.S = c->dn_S2; q2.ptcur = c->dn_ptcur; q2.es = c->dn_es; q2.RB = c->dn_RB; q2.VB = c->dn_VB;
     q2.n_trans = n_trans; q2.n_pt = c->dn_npt; q2.n_rho = c->dn_nrho; q2.n_active = c->dn_active; q2.list = nullptr; q2.n_list = c->N;
@@ -654,13 +681,13 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   // epoch2_shape (AHMC_DENSE_EPOCH_NCT=1|2 picks among the compiled ones).
   // default: round 4's kernel where it exists (f64 D = 512: 43.9 against 42.9 TFLOP/s, D = 256: 28.4 against 18.0 for four 64-row waves —
   // profiles/r6_experiments.md), k_dense_epoch2 everywhere else
-  const bool v1_has = sizeof(T) == 8 && (c->D == 512 || c->D == 256);
+  const bool v1_has = sizeof(T) == 8 && (c->D == 512 || c->D == 256) && criterion == AHMC_TC_GENERALISED;
   const int epoch_v = getenv("AHMC_DENSE_EPOCH_V") ? atoi(getenv("AHMC_DENSE_EPOCH_V")) : (v1_has ? 1 : 2);
   int e2_nct = 0, e2_wpe = 0;
   const bool epoch2_ok = epoch_v >= 2 && epoch2_shape<T>((int)c->D, getenv("AHMC_DENSE_EPOCH_NCT") ? atoi(getenv("AHMC_DENSE_EPOCH_NCT")) : 0, e2_nct, e2_wpe,
-                                                                 getenv("AHMC_DENSE_EPOCH_WPE") ? atoi(getenv("AHMC_DENSE_EPOCH_WPE")) : 0);
+                                                                 getenv("AHMC_DENSE_EPOCH_WPE") ? atoi(getenv("AHMC_DENSE_EPOCH_WPE")) : 0, criterion);
   const bool epoch1_ok = !epoch2_ok && v1_has;
-  const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && (epoch2_ok || epoch1_ok);
+  const bool epoch_ok = epoch_env != 0 && pool && dt && dm && c->dn_fused_ok && (epoch2_ok || epoch1_ok);   // (epoch2_shape knows the criteria it has kernels for)
   const int epoch_chains = epoch2_ok ? 16 * e2_nct : DE_CHAINS;
   q2.lazy_gw = (epoch_ok && (getenv("AHMC_DENSE_LAZY_GW") ? atoi(getenv("AHMC_DENSE_LAZY_GW")) : 1)) ? 1 : 0;  // (for the whole batch: the step-synchronous kernels of its tail must not trust a record the epoch kernel skipped)
   if (epoch_ok) {
@@ -681,7 +708,7 @@ int dn_nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion
   auto launch_epoch = [&](hipStream_t st, int steps) {
     const unsigned grid = (unsigned)((q2.n_list + epoch_chains - 1) / epoch_chains);
     if (epoch2_ok) {
-      launch_epoch2<T>((int)c->D, e2_nct, e2_wpe, grid, st, p, q2, c->dn_Asw, steps);
+      launch_epoch2<T>((int)c->D, e2_nct, e2_wpe, grid, st, p, q2, c->dn_Asw, steps, criterion);
       c->dn_epoch_launches += 1;
       return;
     }

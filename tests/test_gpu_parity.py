@@ -1221,8 +1221,13 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
              (768, 1100, None, A.MultinomialTS, np.float32, None),
              # TemperedLeapfrog (src/integrator.jl:198-209) in the epilogues and the speculative half-step: round 4's kernel, k_dense_epoch2, Float32
              (512, 1100, None, A.MultinomialTS, np.float64, None, 1.05), (384, 1100, "5", A.MultinomialTS, np.float64, None, 1.03),
-             (512, 1100, None, A.SliceTS, np.float32, None, 1.05))
-    for D, N, chunk, sampler, dtype, nct, *temper in cases:
+             (512, 1100, None, A.SliceTS, np.float32, None, 1.05),
+             # ClassicNoUTurn / StrictGeneralisedNoUTurn (src/trajectory.jl:551-557,579-617) in the epoch kernel's tree phase (k_dense_epoch2<…, CRIT>)
+             (512, 1100, None, A.MultinomialTS, np.float64, None, None, A.ClassicNoUTurn), (512, 1100, "5", A.SliceTS, np.float64, None, None, A.StrictGeneralisedNoUTurn),
+             (512, 1100, None, A.MultinomialTS, np.float32, None, 1.04, A.StrictGeneralisedNoUTurn), (512, 1100, None, A.MultinomialTS, np.float32, None, None, A.ClassicNoUTurn))
+    for D, N, chunk, sampler, dtype, nct, *rest in cases:
+        temper = [rest[0]] if rest and rest[0] else []
+        TC = rest[1] if len(rest) > 1 else A.GeneralisedNoUTurn
         if D not in mats:
             idx = np.arange(D)
             Pm = np.asfortranarray(np.linalg.inv(0.9 ** np.abs(idx[:, None] - idx[None, :])))
@@ -1243,7 +1248,7 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
                 else:
                     monkeypatch.delenv(var, raising=False)
             lf = A.TemperedLeapfrog(eps0, temper[0]) if temper else A.Leapfrog(eps0)
-            k = A.HMCKernel(A.Trajectory(sampler, lf, A.GeneralisedNoUTurn(max_depth=10, delta_max=1000.0)))
+            k = A.HMCKernel(A.Trajectory(sampler, lf, TC(max_depth=10, delta_max=1000.0)))
             g = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), A.DenseGaussian(P)), N, dtype=dtype, rng=A.PhiloxRNG(78), lib=hip)
             g.set_integrator(lf)
             g.set_position(th0)

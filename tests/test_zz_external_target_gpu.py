@@ -81,6 +81,7 @@ def test_dense_engine_classic_and_strict_uturn(hip, oracle, rng, metric, target,
         same = assert_close_state(e_g, e_o)
         if not same.all():
             e_g.set_position(e_o.phasepoint().theta)
+    assert e_g.info("dense_pool") == 1   # (round 6: both criteria on the point-pool kernel k_d_tree2<…, CRIT>, no longer the copying one)
     e_g.close(); e_o.close()
 
 
