@@ -541,6 +541,13 @@ __device__ __forceinline__ double* xwave_buf_f() {
   __shared__ __attribute__((aligned(16))) double buf[8 * 4];
   return buf;
 }
+// Round 6: μ and log τ of the NEXT leaf's position, written by the chain's first lane just before the barrier of THIS leaf's energy
+// exchange (hier_publish_next) and read at the top of the next leaf's target_eval (use_pre) — the broadcast exchange of its own and its
+// barrier are gone for every leaf but the first of a doubling.  Lifetime: read before the next leaf's sums' barrier, written again after it.
+__device__ __forceinline__ double* xwave_buf_p() {
+  __shared__ __attribute__((aligned(16))) double buf[2];
+  return buf;
+}
 template <int G, class T, int K>
 __device__ __forceinline__ void group_allsum_once(T (&v)[K], double* b) {
   static_assert(G == 128 || G == 256 || G == 512, "multi-wave groups only");
@@ -620,8 +627,9 @@ struct TargetP {
 namespace ahmc {
 #endif
 
+// use_pre (multi-wave hierarchical target only): μ, log τ of this position were published by the previous leaf (xwave_buf_p)
 template <class T, int G, int E, int TK>
-__device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E], T (&grad)[E], int lane, int d0) {
+__device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E], T (&grad)[E], int lane, int d0, bool use_pre = false) {
   const T log2pi = (T)AHMC_LOG2PI;
   const int D = tp.D;
   T part = 0;
@@ -688,14 +696,20 @@ __device__ __forceinline__ T target_eval(const TargetP<T>& tp, const T (&th)[E],
         // chain's first lane and wave w = threadIdx.x >> 6 (the launch plan of every multi-wave geometry, ahmc_kernels.hpp: group_grid);
         // θ[0] and θ[1] in that lane; and every leapfrog_allsum<G,3> follows a target_eval, whose barriers separate two uses of a buffer.
         static_assert(E >= 2, "multi-wave hierarchical target: mu and log tau must both sit in the chain's first lane (E >= 2)");
-        double* hb = xwave_buf_h();
-        if (threadIdx.x == 0) {
-          hb[0] = (double)th[0];
-          hb[1] = (double)th[E >= 2 ? 1 : 0];
+        if (use_pre) {   // (chain-uniform: every wave of the workgroup takes the same branch)
+          const double* hp = xwave_buf_p();
+          mu = (T)hp[0];
+          lt = (T)hp[1];
+        } else {
+          double* hb = xwave_buf_h();
+          if (threadIdx.x == 0) {
+            hb[0] = (double)th[0];
+            hb[1] = (double)th[E >= 2 ? 1 : 0];
+          }
+          __syncthreads();
+          mu = (T)hb[0];
+          lt = (T)hb[1];
         }
-        __syncthreads();
-        mu = (T)hb[0];
-        lt = (T)hb[1];
       } else {
         mu = group_bcast<G>(th[0], 0);
         lt = (E >= 2) ? group_bcast<G>(th[E >= 2 ? 1 : 0], 0) : group_bcast<G>(th[0], 1);
@@ -783,13 +797,32 @@ __device__ __forceinline__ T kinetic_partial(const T (&r)[E], const T (&minv)[E]
   return s;
 }
 
+// Multi-wave hierarchical target: the chain's first lane publishes θ′[0], θ′[1] of the leapfrog that would FOLLOW this one from the point
+// just completed with the same signed step — r½ = r − ϵ/2·g, θ′ = θ + ϵ·(M⁻¹·r½), the very expressions (and contractions) of the next
+// leapfrog_step, so the bits are the ones its own lane 0 will compute — into xwave_buf_p, before the barrier of the energy exchange.
+template <class T, int G, int E, int TK>
+__device__ __forceinline__ void hier_publish_next(const Point<T, E>& z, const T (&minv)[E], T eps) {
+  if constexpr (G > 64 && TK == 3 && E >= 2) {
+    if (threadIdx.x == 0) {
+      const T eh = eps / 2;
+      double* hp = xwave_buf_p();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const T rh = z.r[k] - eh * z.g[k];
+        const T tn = z.th[k] + eps * (minv[k] * rh);
+        hp[k] = (double)tn;
+      }
+    }
+  }
+}
+
 // One leapfrog step of step i of n (tempering indices) with signed step size eps:
 //   r -= ϵ/2 g ; θ += ϵ M⁻¹ r ; (ℓπ, g) = ∂H∂θ(θ) ; r -= ϵ/2 g ; ℓκ = -½ rᵀM⁻¹r ; sanitise
 // TEMPER = false compiles the tempering out (the default NUTS kernels: the if-converted r·√α / r/√α
 // select costs 6 VALU per leaf even when unused; TemperedLeapfrog runs the general instantiation)
 template <class T, int G, int E, int TK, bool TEMPER = true>
 __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp,
-                                              const LeapfrogP<T>& lf, int lane, int d0, int64_t i, int64_t n) {
+                                              const LeapfrogP<T>& lf, int lane, int d0, int64_t i, int64_t n, bool use_pre = false) {
   if constexpr (TEMPER) temper(lf, z.r, i, true, n);
   const T eh = eps / 2;
 #pragma unroll
@@ -797,11 +830,12 @@ __device__ __forceinline__ void leapfrog_step(Point<T, E>& z, const T (&minv)[E]
 #pragma unroll
   for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
   T red[2];
-  red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
+  red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0, !TEMPER && use_pre);
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
   if constexpr (TEMPER) temper(lf, z.r, i, false, n);
   red[1] = kinetic_partial(z.r, minv);
+  if constexpr (!TEMPER) hier_publish_next<T, G, E, TK>(z, minv, eps);
   leapfrog_allsum<G, TK>(red);
   z.lp = sanitize(red[0]);
   z.lk = sanitize(-red[1] / 2);
@@ -837,18 +871,19 @@ __device__ __forceinline__ T leapfrog_step_ne(Point<T, E>& z, const T (&minv)[E]
 // Every value takes exactly the additions it would take in a reduction of its own, so the bits do not change.
 template <class T, int G, int E, int TK, class F>
 __device__ __forceinline__ void leapfrog_step_plus2(Point<T, E>& z, const T (&minv)[E], T eps, const TargetP<T>& tp, int lane, int d0,
-                                                    T (&extra)[2], F&& partials) {
+                                                    T (&extra)[2], F&& partials, bool use_pre = false) {
   const T eh = eps / 2;
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
 #pragma unroll
   for (int e = 0; e < E; ++e) z.th[e] = z.th[e] + eps * (minv[e] * z.r[e]);
   T red[4];
-  red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0);
+  red[0] = target_eval<T, G, E, TK>(tp, z.th, z.g, lane, d0, use_pre);
 #pragma unroll
   for (int e = 0; e < E; ++e) z.r[e] = z.r[e] - eh * z.g[e];
   red[1] = kinetic_partial(z.r, minv);
   partials(red[2], red[3]);
+  hier_publish_next<T, G, E, TK>(z, minv, eps);
   leapfrog_allsum<G, TK>(red);
   z.lp = sanitize(red[0]);
   z.lk = sanitize(-red[1] / 2);

@@ -60,6 +60,9 @@
 #define AHMC_LP_TICK(i)
 #define AHMC_LP_COUNT(i, n)
 #endif
+#ifndef AHMC_HIER_PRE
+#define AHMC_HIER_PRE 1   // multi-wave hierarchical target: μ, log τ of the next leaf ride on this leaf's energy exchange (0: round 5's broadcast per leaf)
+#endif
 #ifndef AHMC_CKPT_G64
 #define AHMC_CKPT_G64 0   // 1: the checkpoint also where one chain fills one wave (experiment)
 #endif
@@ -567,14 +570,16 @@ __global__ __launch_bounds__((G > 256 ? G : 256), (E >= 16 ? 1 : (MODE == 2 ? (E
                 s0 += A_c[e] * (minv[e] * RF_m0[e]);
                 s1 += A_c[e] * (minv[e] * cur.r[e]);
               }
-            });
+            }, AHMC_HIER_PRE && leaf > 1);
           } else if constexpr (G > 64) {
             // multi-wave chains keep the (ℓπ, ℓκ) pair reduction.  Round 2: with the single-value form the (128,8) instantiation
             // returned wrong candidates — a register-allocation artefact (a spill stored under the lane-0 mask of the cross-wave
             // exchange; the build now scans for it).  Round 3 measured the single-value leaf with an exchange that has
             // no narrowed block (every lane stores): parity-green, but cfg5 5.92e7 -> 4.70e7 leapfrog/s (the all-lane store alone:
             // 5.36e7) — more scratch traffic in the leaf loop than the barrier pair it saves.  Not taken.
-            leapfrog_step<T, G, E, TK, false>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1);
+            // (round 6: from the second leaf of a doubling on, μ and log τ of the new position were published by the leaf before — no
+            // broadcast exchange of their own)
+            leapfrog_step<T, G, E, TK, false>(cur, minv, v > 0 ? eps : -eps, p.tp, p.lf, lane, d0, 1, 1, AHMC_HIER_PRE && leaf > 1);
             ne_leaf = cur.lp + cur.lk;
           } else {
 #if AHMC_LEAF_PROF
