@@ -79,11 +79,12 @@ CONFIG_FAMILY = {"cfg2": 0, "cfg3": 2, "cfg5": 3}   # the log-density family (TK
 
 
 def dense_counter_bytes_per_leapfrog():
-    """cfg4: bytes beyond L2 per useful chain-leapfrog of ALL the dense engine's kernels, from the committed PMC passes of a short run
-    (profiles/counters_at_head.json: configs.cfg4 — 2 x FETCH_SIZE + WRITE_SIZE; the bench-sized run does not finish under PMC
-    serialisation).  Valid only for the device code it was taken on: the digest of the unit that holds the dense engine's kernels
-    (`api`, libahmc_hip.so.kdigests) must match, else (None, reason) — never a figure from other kernels.  A figure for orientation
-    (matrices missing L2 included; a 10 + 10-transition run), not an in-run counter."""
+    """cfg4: bytes beyond L2 per useful chain-leapfrog of ALL the dense engine's kernels, from the committed PMC passes
+    (profiles/counters_at_head.json: configs.cfg4 — 2 x FETCH_SIZE + WRITE_SIZE over every dispatch; round 6: taken on the bench's own
+    run, 300 + 300 transitions — `command` in that file — so the bytes and the TFLOP/s describe the same workload; rounds 3-5 used a
+    10 + 10-transition run).  Valid only for the device code it was taken on: the digest of the unit that holds the dense engine's
+    kernels (`api`, libahmc_hip.so.kdigests) must match, else (None, reason) — never a figure from other kernels.  Matrices missing
+    L2 included; not an in-run counter (PMC passes serialise the dispatches)."""
     try:
         c = json.load(open(os.path.join(ROOT, "profiles", "counters_at_head.json")))["configs"]["cfg4"]
     except Exception:  # noqa: BLE001

@@ -18,7 +18,7 @@ from ahmc_amd import isa_check  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import valu_mix  # noqa: E402
 
-ROUND = os.environ.get("AHMC_ROUND", "r5")
+ROUND = os.environ.get("AHMC_ROUND", "r6")
 RATES = os.path.join(ROOT, "profiles", "r3_valu_rate.json")   # scripts/probe/valu_rate.hip on the MI355X
 
 
@@ -118,7 +118,8 @@ for cfg in sys.argv[1:]:
                     "k_dense_epoch_share_of_hbm_bytes": sum(k["hbm_gbytes"] for k in ep) * 1e9 / total if ep else None,
                     "k_dense_epoch_mfma_f64_per_useful_leapfrog": sum(k.get("SQ_INSTS_VALU_MFMA_F64", 0) for k in ep) / useful if ep else None,
                     "command": s.get("command"),
-                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a SHORT cfg4 run (scripts/profile_head.sh cfg4 with PROFILE_EXTRA)"}
+                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the cfg4 run named in `command` (scripts/profile_head.sh cfg4; round 6: the "
+                              "bench's own size, PROFILE_STEPS=6 — rounds 3-5 used a 10 + 10-transition run)"}
                 c = out["configs"]["cfg4"]
     keep = {k: s.get(k) for k in ("config", "command", "kernel_digest", "kernel_stats", "mode0_launches", "mode3_launches", "counters", "leapfrogs_by_pass", "per_kernel_counters")}
     keep["bench_plain"] = s.get("bench_plain")
