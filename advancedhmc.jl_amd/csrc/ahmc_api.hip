@@ -155,6 +155,18 @@ struct Ctx : CtxBase {
   size_t znorm_elems = 0;
   int64_t znorm_cap_trans = 0;  // > 0: the device could not hold the normals of a full batch; launches are capped at this many transitions
   size_t znorm_cap_fail_bytes = 0;  // the smallest allocation that failed when the cap was set: the cap holds while the device cannot offer twice that
+  // Round 6: the normals of the NEXT launch are generated on a stream of their own while this launch's k_nuts runs (its tail leaves the chip
+  // half empty; k_normals was 3.8 % of cfg2's device time in series with it).  `znorm2` receives them; a launch that finds its normals there
+  // swaps the two buffers.  The values are a pure function of (seed, chain, iteration, element): which stream made them cannot show.
+  T* znorm2 = nullptr;
+  size_t znorm2_elems = 0;
+  hipStream_t stream_norm = nullptr;
+  hipEvent_t ev_norm_ready = nullptr, ev_z2_free = nullptr;
+  bool z2_has_reader = false;       // ev_z2_free marks the end of the last k_nuts that read what is now znorm2
+  struct NormPre { bool valid = false; uint64_t iter = 0, k0 = 0, k1 = 0, chain_offset = 0, chain_stride = 0; int64_t n = 0; } npre;
+  int64_t norm_hint = 0;            // set by the sampling loop before a launch: transitions of the launch that will follow it (0: unknown)
+  int norm_prefetch = -1;           // -1 undecided, 0 off (AHMC_NORMALS_PREFETCH=0 or no memory for the second buffer), 1 on
+  int64_t norm_prefetch_hits = 0;
   int32_t* redo = nullptr;  // per-chain "redo in the log domain" flags of the NUTS fast pass
   int nuts_blocks = 0;
   // static multinomial
@@ -235,6 +247,10 @@ struct Ctx : CtxBase {
     if (red) (void)hipFree(red);
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    if (stream_norm) { (void)hipStreamSynchronize(stream_norm); (void)hipStreamDestroy(stream_norm); }
+    for (hipEvent_t e : {ev_norm_ready, ev_z2_free})
+      if (e) (void)hipEventDestroy(e);
+    if (znorm2) (void)hipFree(znorm2);
     for (int k = 0; k < 2; ++k) {
       if (stream_x[k]) { (void)hipStreamSynchronize(stream_x[k]); (void)hipStreamDestroy(stream_x[k]); }
       if (ev_join_x[k]) (void)hipEventDestroy(ev_join_x[k]);
@@ -609,19 +625,37 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   p.n_chunks = (unsigned int)((c->N + CPW - 1) / CPW);
   p.redo = c->redo;
   static const bool no_linw = getenv("AHMC_NUTS_LOGW") != nullptr;
-  // standard normals of the n_trans momentum refreshes (rand_momentum, src/metric.jl:290-309)
+  // standard normals of the n_trans momentum refreshes (rand_momentum, src/metric.jl:290-309): already made beside the launch before
+  // (prefetch, below), or made now
+  const int64_t hint = c->norm_hint;
+  c->norm_hint = 0;
+  auto normals_grid = [&](int64_t n) {
+    const int64_t pairs = ((c->D + 1) / 2) * c->N * n;
+    return (unsigned)std::min<int64_t>((pairs + 255) / 256, (int64_t)c->n_cu * 32);
+  };
   {
     const size_t need = (size_t)n_trans * (size_t)c->D * (size_t)c->N;
-    if (need > c->znorm_elems) {
-      if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
-      c->znorm = nullptr;
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->znorm), need * sizeof(T)));
-      c->znorm_elems = need;
+    auto& np = c->npre;
+    const bool hit = np.valid && np.iter == c->iteration && np.n >= n_trans && np.k0 == (uint64_t)p.k0 && np.k1 == (uint64_t)p.k1 &&
+                     np.chain_offset == (uint64_t)p.chain_offset && np.chain_stride == (uint64_t)p.chain_stride && c->znorm2_elems >= need;
+    np.valid = false;   // (used or stale: either way the buffer's content is spent)
+    if (hit) {
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_norm_ready, 0));
+      std::swap(c->znorm, c->znorm2);
+      std::swap(c->znorm_elems, c->znorm2_elems);
+      HIPCHK(hipEventRecord(c->ev_z2_free, c->stream));   // everything that read the buffer that is now znorm2 lies before this point
+      c->z2_has_reader = true;
+      c->norm_prefetch_hits += 1;
+    } else {
+      if (need > c->znorm_elems) {
+        if (c->znorm) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->znorm)); }
+        c->znorm = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->znorm), need * sizeof(T)));
+        c->znorm_elems = need;
+      }
+      hipLaunchKernelGGL((k_normals<T>), dim3(normals_grid(n_trans)), dim3(256), 0, c->stream, p, c->znorm, n_trans, (uint32_t)RNG_MOMENTUM);
+      HIPCHK(hipGetLastError());
     }
-    const int64_t pairs = ((c->D + 1) / 2) * c->N * (int64_t)n_trans;
-    const unsigned grid = (unsigned)std::min<int64_t>((pairs + 255) / 256, (int64_t)c->n_cu * 32);
-    hipLaunchKernelGGL((k_normals<T>), dim3(grid), dim3(256), 0, c->stream, p, c->znorm, n_trans, (uint32_t)RNG_MOMENTUM);
-    HIPCHK(hipGetLastError());
   }
   p.n_trans = n_trans;
   p.znorm = c->znorm;
@@ -693,6 +727,46 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   }
   if (rc) return rc;
   c->iteration += (uint64_t)n_trans;
+  // ---- the normals of the launch that follows, beside this one ----
+  // Measured (profiles/r6_experiments.md r6n): cfg3's 4-transition launches gain 6 % in the sampling phase (3.20 -> 3.40e9: the 0.1 ms of
+  // k_normals and its launch gap no longer sit between two 6 ms launches); cfg2's 256-transition launches lose 0.4 % (a 5.7 ms k_normals beside
+  // a VALU-bound k_nuts takes what it gives) and cfg5's 32 are unchanged — so only launches whose normals are at most 2 GiB are prefetched.
+  static const size_t prefetch_max_bytes = getenv("AHMC_NORMALS_PREFETCH_MAX_MB") ? (size_t)atoll(getenv("AHMC_NORMALS_PREFETCH_MAX_MB")) << 20 : (size_t)2 << 30;
+  if (hint > 0 && refresh_alpha == 0 && (size_t)hint * (size_t)c->D * (size_t)c->N * sizeof(T) <= prefetch_max_bytes) {
+    if (c->norm_prefetch < 0) c->norm_prefetch = (getenv("AHMC_NORMALS_PREFETCH") && atoi(getenv("AHMC_NORMALS_PREFETCH")) == 0) ? 0 : 1;
+    const size_t need2 = (size_t)hint * (size_t)c->D * (size_t)c->N;
+    if (c->norm_prefetch == 1 && need2 > c->znorm2_elems) {
+      // a second buffer only where the device has room to spare (the draws of a run, another context): 2x its size must be free
+      size_t free_b = 0, total_b = 0;
+      const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + c->znorm2_elems * sizeof(T) >= 2 * need2 * sizeof(T);
+      (void)hipGetLastError();
+      if (room) {
+        if (c->znorm2) { HIPCHK(hipStreamSynchronize(c->stream)); if (c->stream_norm) HIPCHK(hipStreamSynchronize(c->stream_norm)); HIPCHK(hipFree(c->znorm2)); c->z2_has_reader = false; }
+        c->znorm2 = nullptr;
+        c->znorm2_elems = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&c->znorm2), need2 * sizeof(T)) == hipSuccess) c->znorm2_elems = need2;
+        else { (void)hipGetLastError(); c->znorm2 = nullptr; c->norm_prefetch = 0; }
+      } else if (!c->znorm2) {
+        c->norm_prefetch = 0;
+      }
+    }
+    if (c->norm_prefetch == 1 && c->znorm2 && need2 <= c->znorm2_elems) {
+      if (!c->stream_norm) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream_norm, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_norm_ready, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_z2_free, hipEventDisableTiming));
+      }
+      if (c->z2_has_reader) HIPCHK(hipStreamWaitEvent(c->stream_norm, c->ev_z2_free, 0));
+      KP<T> p2 = p;
+      p2.iteration = (uint32_t)c->iteration;   // (make_kp's field: the launch that follows starts here)
+      hipLaunchKernelGGL((k_normals<T>), dim3(normals_grid(hint)), dim3(256), 0, c->stream_norm, p2, c->znorm2, (int)hint, (uint32_t)RNG_MOMENTUM);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(c->ev_norm_ready, c->stream_norm));
+      c->npre.valid = true;
+      c->npre.iter = c->iteration; c->npre.n = hint;
+      c->npre.k0 = (uint64_t)p.k0; c->npre.k1 = (uint64_t)p.k1; c->npre.chain_offset = (uint64_t)p.chain_offset; c->npre.chain_stride = (uint64_t)p.chain_stride;
+    }
+  }
   return AHMC_OK;
 }
 
@@ -1844,6 +1918,8 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
           }
           HIPCHK(hipMemcpyAsync(c->work_prev, c->acc_nsteps, sizeof(long long) * (size_t)c->N, hipMemcpyDeviceToDevice, c->stream));
         }
+        // (the launch after this one: the same length unless a timed group ends here or the run does — its normals are made beside this one)
+        c->norm_hint = (left > k && !(probing && sc.g_left == 1)) ? std::min<int64_t>(k, left - k) : 0;
         int rc = nuts_transition(c, cfg->max_depth, cfg->delta_max, cfg->criterion, cfg->sampler, cfg->refresh_alpha, true,
                                  (int)k, dev_dst);
         if (rc) return rc;
@@ -1932,6 +2008,10 @@ static int32_t sample_from_impl(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64
         // transitions on its own stream, so that the slots one group's launch leaves empty at its end would be filled by the others'
         // — cfg3 warm-up 1.81 / 1.10e9 (launches of 32) against 1.94e9 for the one launch, cfg2 2.31–2.38e9 against 2.59e9: the
         // queues do not interleave at workgroup granularity, a group's launch only under-fills the chip)
+        {
+          const int64_t after = std::min(n_adapts, n_samples) - (i + k) + 1;   // adapting transitions left after this launch
+          c->norm_hint = after > 0 ? std::min<int64_t>(k, after) : 0;
+        }
         int rc = nuts_adapt_batch(c, cfg, (int)k, i, n_adapts, keep, dst);
         if (rc) return rc;
         if (keep) c->acc_ntrans += k;
