@@ -11,8 +11,9 @@ records the smallest RELATIVE distance |a − b| / scale of any decision a chain
     differs(chain)  ⇒  margin(chain) < MARGIN_BOUND[dtype]
 
 and EXACT agreement of every discrete statistic everywhere else.  That replaces round 1–5's "≥ 99.9 % / 97 % / 90 % of the chains
-agree" thresholds, which would have hidden a rare real defect.  `MAX_NEAR_TIES` keeps the filter honest: if more than that share
-of the chains sat on a near-tie, the bound is explaining too much and the test fails.
+agree" thresholds, which would have hidden a rare real defect.  `MAX_NEAR_TIES` keeps the filter honest: where a comparison has to
+excuse a differing chain, at most that share of its chains may sit on a near-tie — otherwise the bound explains too much and the
+test fails.
 
 Every comparison is also logged (`RECORDS`): tests/conftest.py prints the suite's totals and writes them to
 gpurun_out/parity_margins.json — flips seen, the largest margin among them (how close the bound is to being needed) and the
@@ -27,8 +28,10 @@ import numpy as np
 # dense engine, the full-size slices — produced NO decision flip at all, and neither did its 35 328 Float32 ones although 2 % of
 # those had a decision within 1e-4 of a tie: the Float32 bound is 1e-4, ten times tighter than the 1e-3 the review asked for.)
 MARGIN_BOUND = {np.dtype(np.float64): 1e-9, np.dtype(np.float32): 1e-4}
-# … and at most this share of the chains of one comparison may sit on such a near-tie (f32: 10² … 10³ decisions per transition at
-# a per-decision probability of ~1e-4 each — 8.6 % of the chains of cfg2's D = 128 trees in one iteration)
+# … and at most this share of the chains of one comparison may sit on such a near-tie.  Float32: the sampling decisions compare
+# log-weights on the scale of |H0| — at cfg2's |H| ≈ 200 a relative 1e-4 is 0.02 in ℓw, which a merge's `ℓw < ℓw₁ + e` meets with a
+# probability of ≈ 2 % —, so a chain of 70 leaves has a near-tie with probability ≈ 1/3 (measured: 87 of 256 chains in the third
+# iteration of cfg2's Float32 pipeline) while NOT ONE of them flipped: the cap only guards against a bound that explains everything.
 MAX_NEAR_TIES = {np.dtype(np.float64): 0.002, np.dtype(np.float32): 0.15}
 
 RECORDS = []  # (what, dtype name, n_chains, n_differ, n_near_tie, max margin among differing, min margin among agreeing)
@@ -58,10 +61,11 @@ def bound(dtype):
     return MARGIN_BOUND[np.dtype(dtype)]
 
 
-def check_flips(same, margin, dtype, what="", sel=None, max_near_ties=None):
+def check_flips(same, margin, dtype, what="", sel=None, max_near_ties=None, n_steps=None):
     """`same`: per chain, did the HIP engine agree with the oracle on everything discrete; `margin`: decision_margin(o) over the
     same span of transitions.  Fails unless every disagreeing chain had a near-tie.  `sel` restricts the check to a subset of the
-    chains (e.g. the numerically stable ones of a warm-up iteration).  Returns the mask of chains that may be compared further."""
+    chains (e.g. the numerically stable ones of a warm-up iteration).  `n_steps`: the oracle's leapfrogs per chain over the span
+    (the near-tie cap also scales with the work: 50·b per leaf).  Returns the mask of chains that may be compared further."""
     same = np.asarray(same, dtype=bool)
     margin = np.asarray(margin, dtype=np.float64)
     dt = np.dtype(dtype)
@@ -77,10 +81,14 @@ def check_flips(same, margin, dtype, what="", sel=None, max_near_ties=None):
     assert not unexplained.any(), (
         f"{what}: {int(unexplained.sum())} of {n} chains took another decision than the oracle although no decision of theirs was within "
         f"{b:g} of a tie (chains {np.flatnonzero(unexplained)[:8].tolist()}, their margins {margin[unexplained][:8].tolist()})")
-    cap = MAX_NEAR_TIES[dt] if max_near_ties is None else max_near_ties
-    # (small batches: one near-tie among 24 chains is 4 % — allow two whatever N is)
-    assert (near & on).sum() <= max(2, cap * n), (
-        f"{what}: {int((near & on).sum())} of {n} chains sat within {b:g} of a tie — the bound explains too much")
+    # The cap on near-ties guards against a bound that explains everything — so it applies where the bound is USED, i.e. when some
+    # chain of this comparison did differ (then the near-ties that excuse it must be rare, or the excuse is worthless).
+    if differ.any():
+        cap = MAX_NEAR_TIES[dt] if max_near_ties is None else max_near_ties
+        by_work = 50.0 * b * float(np.asarray(n_steps)[on].sum()) if n_steps is not None else 0.0
+        # (small batches: one near-tie among 24 chains is 4 % — allow two whatever N is)
+        assert (near & on).sum() <= max(2, cap * n, by_work), (
+            f"{what}: {int(differ.sum())} chains differ and {int((near & on).sum())} of {n} sat within {b:g} of a tie — the bound explains too much")
     return same & on
 
 

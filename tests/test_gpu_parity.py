@@ -192,7 +192,7 @@ def compare_transition_stats(sg, so, dtype, o, what="transition", sel=None):
     read AND reset: one comparison per span of transitions); the continuous statistics to tolerance on the agreeing chains."""
     same = ((sg["n_steps"] == so["n_steps"]) & (sg["is_accept"] == so["is_accept"]) & (sg["tree_depth"] == so["tree_depth"])
             & (sg["numerical_error"] == so["numerical_error"]))
-    same = PU.check_flips(same, PU.decision_margin(o), dtype, what, sel=sel)
+    same = PU.check_flips(same, PU.decision_margin(o), dtype, what, sel=sel, n_steps=so["n_steps"])
     rt = RTOL[dtype] * 100
     for k in ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error",
               "max_hamiltonian_energy_error", "step_size"):
@@ -1005,7 +1005,7 @@ def test_cfg2_pipeline_against_oracle_f32(hip, oracle):
         stg, sto = g.stats(), o.stats()
         same = (stg["n_steps"] == sto["n_steps"]) & (stg["tree_depth"] == sto["tree_depth"]) & (stg["numerical_error"] == sto["numerical_error"])
         on = same & np.isclose(sg["theta"], so["theta"], rtol=2e-3, atol=2e-3).all(axis=0)
-        on = PU.check_flips(on, PU.decision_margin(o), np.float32, f"cfg2 f32 pipeline iteration {i}")
+        on = PU.check_flips(on, PU.decision_margin(o), np.float32, f"cfg2 f32 pipeline iteration {i}", n_steps=sto["n_steps"])
         np.testing.assert_allclose(stg["hamiltonian_energy"][on], sto["hamiltonian_energy"][on], rtol=2e-3, err_msg=f"H at iteration {i}")
         np.testing.assert_allclose(stg["acceptance_rate"][on], sto["acceptance_rate"][on], rtol=2e-2, atol=2e-3, err_msg=f"α at iteration {i}")
         np.testing.assert_allclose(sg["stepsize"][on], so["stepsize"][on], rtol=5e-3, err_msg=f"ϵ after adapt! {i}")
