@@ -422,3 +422,47 @@ def test_oracle_reproduces_committed_fixtures(oracle):
         got = mod.run_case(name, oracle)
         for key, val in got.items():
             np.testing.assert_array_equal(val, ref[key], err_msg=key)
+
+
+def test_decision_margin_explains_what_a_perturbation_flips():
+    """The instrument behind the GPU suite's margin-aware parity (tests/parity_util.py), calibrated on the CPU.  The oracle runs the same
+    transition twice on the same streams, the second time from positions perturbed by a relative δ — a stand-in for another
+    implementation's rounding, only 10¹³ times larger.  Chains DO part ways (the test is not vacuous), and every one that does had a
+    decision whose recorded margin is at most a few δ: measured, the largest margin among the flipped chains is 0.3 … 1.3 δ for
+    δ = 1e-3 and 1e-2 (most near-ties are harmless — a sampling decision in a subtree the final candidate does not come from — so far
+    fewer chains flip than have a margin below δ; what matters is that NO chain with a comfortable margin flips).  For rounding
+    differences of 1e-16 … 1e-13 that puts the flips at margins far below the suite's 1e-9 bound — and is why the MI355X shows none
+    in 228 156 chain-comparisons."""
+    import parity_util as PU
+    from conftest import build_oracle
+
+    lib = A.CLib(build_oracle())
+    D, N = 10, 20000
+    rs = np.random.default_rng(3)
+    h = A.Hamiltonian(A.DiagEuclideanMetric(np.asfortranarray(0.5 + rs.random((D, N)))), A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.25))
+    th0 = rs.normal(size=(D, N))
+    sg = np.sign(rs.normal(size=(D, N)))
+    for TS, TC in ((A.MultinomialTS, A.GeneralisedNoUTurn), (A.SliceTS, A.StrictGeneralisedNoUTurn), (A.MultinomialTS, A.ClassicNoUTurn)):
+        k = A.HMCKernel(A.Trajectory(TS, lf, TC(max_depth=7)))
+        res = {}
+        for pert in (0.0, 1e-3, 1e-2):
+            e = A.Engine(h, N, rng=11, lib=lib)
+            e.set_integrator(lf)
+            e.set_position(th0 * (1.0 + pert * sg))
+            PU.reset_margin(e)
+            e.transition(k)
+            s = e.stats()
+            res[pert] = (s["n_steps"].copy(), s["numerical_error"].copy(), PU.decision_margin(e), e.theta().copy())
+            e.close()
+        n0, e0, m0, t0 = res[0.0]
+        assert np.isfinite(m0).all() and (m0 >= 0).all()
+        n_flips = 0
+        for pert in (1e-3, 1e-2):
+            n1, e1, _, t1 = res[pert]
+            # a chain parted ways: another tree, or another candidate (then θ is O(1) away; a chain on the same track is ≈ δ·|θ| away)
+            differ = (n0 != n1) | (e0 != e1) | (np.abs(t1 - t0).max(axis=0) > 30 * pert * np.abs(t0).max())
+            n_flips += int(differ.sum())
+            assert (m0[differ] < 5 * pert).all(), (TS.__name__, TC.__name__, pert, float(m0[differ].max()))
+            assert differ.mean() < 0.01     # … and flips are rare: far rarer than margins below δ
+        assert n_flips >= 10, n_flips       # (not vacuous)
