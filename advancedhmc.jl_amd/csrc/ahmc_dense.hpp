@@ -2417,38 +2417,56 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll 1
     for (int base = 0; base < CH; base += 4 * NW) {
       const int lane2 = tid2 & 63, w2 = tid2 >> 6;
-      const int grp = lane2 / GL, l16 = lane2 % GL;
-      const int slot = base + w2 * 4 + grp;
-      const int64_t jj = j0 + slot;
+      // (whether a wave has chains in this round is wave-uniform: said so, it is a scalar branch instead of one more exec-mask region for the
+      // register allocator to park a spill in — the 12- and 16-wave shapes were refused by isa_check.py for exactly that)
+      // (NW >= 12 only: the shapes with fewer waves were measured and scanned in the form without it, and every change to this phase moves
+      // the register allocator's spills somewhere else)
+      constexpr bool WIDE = NW >= 12;
+      if constexpr (WIDE) {
+        if (base + 4 * __builtin_amdgcn_readfirstlane(w2) >= CH) continue;
+      }
+      const int grp = lane2 / GL, l16_in = lane2 % GL;
+      const int slot_in = base + w2 * 4 + grp;
+      const int64_t jj = j0 + slot_in;
       bool chain_active = false;
-      if (slot < CH && jj < q.n_list) {
-        const int64_t c = q.list ? (int64_t)q.list[jj] : jj;
-        DChain2<T>& S = q.S[c];
-        if (S.phase != DPH_IDLE) {
+      if ((WIDE || slot_in < CH) && jj < q.n_list) {
+        const int64_t c_in = q.list ? (int64_t)q.list[jj] : jj;
+        const DChain2<T>& S_in = q.S[c_in];
+        if (S_in.phase != DPH_IDLE) {
           T sa = 0, sb = 0;
 #pragma unroll
-          for (int k = 0; k < NW; ++k) { sa += (T)red[k][slot][0]; sb += (T)red[k][slot][1]; }
+          for (int k = 0; k < NW; ++k) { sa += (T)red[k][slot_in][0]; sb += (T)red[k][slot_in][1]; }
           const T lk = sanitize(-sa / 2), lp = sanitize(-sb / 2);
           DHot<T> hot;
-          hot.H0 = S.H0; hot.eps = S.eps; hot.lu = S.lu;
-          hot.phase = S.phase; hot.it = S.it; hot.jw = S.jw; hot.leaf = S.leaf; hot.v = S.v; hot.cur_is_left = S.cur_is_left; hot.numerical = S.numerical;
-          hot.k = S.k;
-          hot.cur = S.cur; hot.oth = S.oth; hot.cand = S.cand; hot.edge = S.edge;
-          if (l16 == 0) {
-            p.lk()[c] = lk;
-            p.lp()[c] = lp;
+          hot.H0 = S_in.H0; hot.eps = S_in.eps; hot.lu = S_in.lu;
+          hot.phase = S_in.phase; hot.it = S_in.it; hot.jw = S_in.jw; hot.leaf = S_in.leaf; hot.v = S_in.v; hot.cur_is_left = S_in.cur_is_left; hot.numerical = S_in.numerical;
+          hot.k = S_in.k;
+          hot.cur = S_in.cur; hot.oth = S_in.oth; hot.cand = S_in.cand; hot.edge = S_in.edge;
+          if (l16_in == 0) {
+            p.lk()[c_in] = lk;
+            p.lp()[c_in] = lp;
           }
           int src = hot.cur;
           uint64_t used = 0;
           bool rewritten = false;
           dn_chain_barrier<true>();
-          const T e = d_tree_advance2<T, GL, true, D, VCH, CRIT>(p, q, c, l16, lp, lk, hot, src, used, rewritten);
+          const int cur_in = hot.cur;
+          const T e = d_tree_advance2<T, GL, true, D, VCH, CRIT>(p, q, c_in, l16_in, lp, lk, hot, src, used, rewritten);
+          // Everything a lane needs from here on is derived AGAIN from a thread index the compiler cannot trace (as at the top of every
+          // phase): the chain index and the address of its record do not live across the tree bookkeeping — where the register allocator
+          // spilled them under the inner exec mask and reloaded them outside it (the 16-wave shapes were refused by isa_check.py).
+          int tid3 = threadIdx.x;
+          if constexpr (WIDE) asm volatile("" : "+v"(tid3));
+          const int w3 = WIDE ? tid3 >> 6 : w2, l16 = WIDE ? (tid3 & 63) % GL : l16_in, slot = WIDE ? base + w3 * 4 + (tid3 & 63) / GL : slot_in;
+          const int64_t jj3 = j0 + slot;
+          const int64_t c = WIDE ? (q.list ? (int64_t)q.list[jj3] : jj3) : c_in;
+          DChain2<T>& S = q.S[c];
           if (l16 == 0) q.es[c] = e;
           if (e != T(0)) {  // first half of the next leapfrog (src/integrator.jl:231-237): src → a fresh point
-            const DEMeta<T> m = meta[w2][slot];
+            const DEMeta<T> m = meta[w3][slot];
             const int sp = spec_pt[slot];
             // the epilogue has already taken it if the leapfrog goes on from the point just completed with the same signed step
-            const bool hit = sp >= 0 && m.e != T(0) && src == hot.cur && e == m.e && !rewritten;
+            const bool hit = sp >= 0 && m.e != T(0) && src == cur_in && e == m.e && !rewritten;
             const int dst = hit ? sp : __builtin_ctzll(~used);
             T* dTH = ppt(q, p, dst, PV_TH, c);
             T* dR = ppt(q, p, dst, PV_R, c);
@@ -2483,7 +2501,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
           }
         }
       }
-      if (chain_active && l16 == 0) any_active[step & 1] = 1;
+      if (chain_active && (WIDE || l16_in == 0)) any_active[step & 1] = 1;   // (WIDE: every lane of an active chain writes the same 1)
     }
     AHMC_EPOCH_TICK(4)
     __syncthreads();  // (B) every chain's next point, step and phase are visible to the whole workgroup

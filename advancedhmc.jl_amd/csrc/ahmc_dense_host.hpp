@@ -504,10 +504,13 @@ void launch_d_tree(Ctx<T>* c, int criterion, unsigned grid, const KP<T>& p, cons
 // Measured (profiles/r6_experiments.md, cfg4's pipeline at 8 192 chains, TFLOP/s at 4D² per leapfrog; step-synchronous kernels in brackets):
 //   f64  D = 384: (6,2,2) 30.5 [23.1];  D = 512: (8,2,2) 42.9 and (8,1,4) 25.8 against round 4's k_dense_epoch 43.9 — two 16-chain workgroups per CU
 //        stream the matrices twice as often and serve half as many chains per latency-bound phase: kept as the record of that experiment;
-//   f32  D = 256: (4,1,4) 35.1 [21.1];  384: (6,2,3) 41.8 [29.8];  512: (8,1,4) 51.5, (8,2,2) 50.9, (8,2,4) 30.5 [34.1];  768: (12,2,3) 54.2 [42.3].
+//   f32  D = 256: (4,1,3) 35.1 [21.1];  384: (6,2,3) 41.8 [29.8];  512: (8,1,4) 51.5, (8,2,2) 50.9, (8,2,4) 30.5 [34.1];  768: (12,2,3) 54.2 [42.3];
+//        1 024: (16,1,4) 55.2 [44.2].
+//   f64  D = 768 / 1 024 run on the step-synchronous kernels (34.6 / 37.2 TFLOP/s = 0.44 / 0.47 of the peak): sixteen waves of 8 accumulators at 128
+//        registers spill 536 VGPRs and lose to them (D = 1 024: 35.7), twelve at 170 registers are refused by the ISA scan.
 #define AHMC_EPOCH2_SHAPES(X) \
   X(double, 6, 2, 2) X(double, 8, 1, 4) X(double, 8, 2, 2) \
-  X(float, 4, 1, 3) X(float, 6, 2, 3) X(float, 8, 1, 4) X(float, 12, 2, 3)
+  X(float, 4, 1, 3) X(float, 6, 2, 3) X(float, 8, 1, 4) X(float, 12, 2, 3) X(float, 16, 1, 4)
 // … and for ClassicNoUTurn (0) / StrictGeneralisedNoUTurn (2): D = 512 in the one-workgroup shape (the tree phase's vector passes in chunks of four
 // pairs: with eight the register allocator parks spills inside the divergent tree phase and isa_check.py refuses the kernels)
 #define AHMC_EPOCH2_CRIT_SHAPES(X) X(double, 8, 2, 2, 0) X(double, 8, 2, 2, 2) X(float, 8, 2, 2, 0) X(float, 8, 2, 2, 2)

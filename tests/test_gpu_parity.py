@@ -1249,6 +1249,7 @@ def test_dense_epoch_kernel_equals_step_synchronous_kernels(hip, monkeypatch):
              (512, 1300, None, A.MultinomialTS, np.float32, None), (512, 1100, "5", A.SliceTS, np.float32, "1"),
              (256, 1100, None, A.MultinomialTS, np.float32, None), (384, 1100, None, A.MultinomialTS, np.float32, None),
              (768, 1100, None, A.MultinomialTS, np.float32, None),
+             (1024, 600, None, A.MultinomialTS, np.float32, None),   # sixteen waves per workgroup
              # TemperedLeapfrog (src/integrator.jl:198-209) in the epilogues and the speculative half-step: round 4's kernel, k_dense_epoch2, Float32
              (512, 1100, None, A.MultinomialTS, np.float64, None, 1.05), (384, 1100, "5", A.MultinomialTS, np.float64, None, 1.03),
              (512, 1100, None, A.SliceTS, np.float32, None, 1.05),
