@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 # --- enums (mirror include/ahmc_hip.h) --------------------------------------------------------
-AHMC_ABI_VERSION = 5
+AHMC_ABI_VERSION = 6
 OK, ERR_ARGUMENT, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_STATE = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 METRIC_UNIT, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
@@ -135,6 +135,7 @@ SIGNATURES = {
     "ahmc_sample": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i32, _vp]),
     "ahmc_sample_from": (_i32, [_vp, C.POINTER(KernelCfg), _i64, _i64, _i64, _i32, _vp]),
     "ahmc_sample_reserve": (_i32, [_vp, C.POINTER(KernelCfg), _i64]),
+    "ahmc_set_ref_compat": (_i32, [_vp, _i32]),
     "ahmc_get_accum": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
     "ahmc_reset_accum": (_i32, [_vp]),
     "ahmc_get_accum_state": (_i32, [_vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),

@@ -629,6 +629,11 @@ class Engine:
         self._call("ahmc_get_phasepoint", capi.as_ptr(th), None, None, None, None)
         return self._shape_out(th)
 
+    def set_ref_compat(self, on=True):
+        """the reference's matrix-mode early exit (src/integrator.jl:252-258: every chain stops at the first step after which ANY chain is
+        non-finite) for `step` and static EndPointTS transitions — off by default (each chain stops at its own first non-finite point)"""
+        self._call("ahmc_set_ref_compat", 1 if on else 0)
+
     def refresh(self, refreshment=None):
         """refresh(rng, refreshment, h, z) (src/hamiltonian.jl:213-254)"""
         self._call("ahmc_refresh_momentum", float(getattr(refreshment, "alpha", 0.0)))

@@ -164,6 +164,10 @@ struct Ctx : CtxBase {
   hipEvent_t ev_norm_ready = nullptr, ev_z2_free = nullptr;
   bool z2_has_reader = false;       // ev_z2_free marks the end of the last k_nuts that read what is now znorm2
   struct NormPre { bool valid = false; uint64_t iter = 0, k0 = 0, k1 = 0, chain_offset = 0, chain_stride = 0; int64_t n = 0; } npre;
+  // (ABI v6) ahmc_set_ref_compat: the reference's matrix-mode early exit (Q1) for ahmc_leapfrog and static EndPointTS transitions
+  bool ref_compat = false;
+  T* compat_save = nullptr;         // θ, r, g (3·D·N) + the scalar slab (14·N): the state a dry run must give back
+  int* compat_flag = nullptr;
   int64_t norm_hint = 0;            // set by the sampling loop before a launch: transitions of the launch that will follow it (0: unknown)
   int norm_prefetch = -1;           // -1 undecided, 0 off (AHMC_NORMALS_PREFETCH=0 or no memory for the second buffer), 1 on
   int64_t norm_prefetch_hits = 0;
@@ -251,6 +255,8 @@ struct Ctx : CtxBase {
     for (hipEvent_t e : {ev_norm_ready, ev_z2_free})
       if (e) (void)hipEventDestroy(e);
     if (znorm2) (void)hipFree(znorm2);
+    if (compat_save) (void)hipFree(compat_save);
+    if (compat_flag) (void)hipFree(compat_flag);
     for (int k = 0; k < 2; ++k) {
       if (stream_x[k]) { (void)hipStreamSynchronize(stream_x[k]); (void)hipStreamDestroy(stream_x[k]); }
       if (ev_join_x[k]) (void)hipEventDestroy(ev_join_x[k]);
@@ -876,6 +882,60 @@ int resolve_integration_time(Ctx<T>* c, double lambda, int64_t& L) {
   return AHMC_OK;
 }
 
+// ---- (ABI v6) the reference's matrix-mode early exit, opt-in (src/integrator.jl:252-258) ----
+template <class T>
+__global__ __launch_bounds__(256) void k_any_nonfinite(const T* __restrict__ lp, const T* __restrict__ lk, int64_t N, int* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // (ℓπ, ℓκ are stored sanitised: a non-finite value is −Inf — `isfinite(z)` of src/hamiltonian.jl:141-142 is false for it)
+  if (i < N && !(is_finite(lp[i]) && is_finite(lk[i]))) atomicOr(flag, 1);
+}
+// one leapfrog step of every chain at a time (k_leapfrog with n = ±1), stopping ALL chains after the first step that left any chain
+// non-finite; `done` = the steps taken.  One launch and one 4-byte read-back per step: a comparison mode.
+template <class T>
+int compat_step_loop(Ctx<T>* c, int64_t n_abs, bool fwd, int64_t& done) {
+  if (c->integ_kind == AHMC_INTEGRATOR_TEMPERED)
+    return fail(c, AHMC_ERR_UNSUPPORTED, "ahmc_set_ref_compat: the coupled early exit is not implemented for TemperedLeapfrog (the step index of a launch of one step)");
+  if (!c->compat_flag) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->compat_flag), sizeof(int)));
+  const TargetOps<T>* o = ops_for(c);
+  if (!o) return fail(c, AHMC_ERR_STATE, "ahmc_set_ref_compat: the context's target has no fused kernels");
+  done = 0;
+  for (int64_t s = 1; s <= n_abs; ++s) {
+    KP<T> p = make_kp(c);
+    p.n_steps = fwd ? 1 : -1;
+    o->leapfrog(c->G, c->E, group_grid(c), c->stream, p);
+    HIPCHK(hipMemsetAsync(c->compat_flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL((k_any_nonfinite<T>), dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, c->lp, c->lk, c->N, c->compat_flag);
+    HIPCHK(hipGetLastError());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, c->compat_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    done = s;
+    if (flag) break;
+  }
+  return AHMC_OK;
+}
+// static EndPointTS transition in compat mode: the step after which the reference's loop would have ended for everybody, found by a DRY RUN
+// of the transition's integration (fresh momentum from the transition's own counter-based stream, one step at a time) on a copy of the state
+template <class T>
+int compat_hmc_stop_step(Ctx<T>* c, int64_t L, double refresh_alpha, int64_t& L_eff) {
+  const size_t DN = (size_t)c->D * (size_t)c->N, nv = 3 * DN, ns = 14 * (size_t)c->N;
+  if (!c->compat_save) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->compat_save), (nv + ns) * sizeof(T)));
+  HIPCHK(hipMemcpyAsync(c->compat_save, c->vbase, nv * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->compat_save + nv, c->tbase, ns * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  const TargetOps<T>* o = ops_for(c);
+  if (!o) return fail(c, AHMC_ERR_STATE, "ahmc_set_ref_compat: the context's target has no fused kernels");
+  KP<T> p = make_kp(c);
+  p.refresh_alpha = (T)refresh_alpha;
+  o->refresh(c->G, c->E, group_grid(c), c->stream, p);   // the momentum k_hmc will draw (same stream, same counters) and the caches
+  HIPCHK(hipGetLastError());
+  int64_t done = 0;
+  int rc = compat_step_loop(c, L, true, done);
+  L_eff = done > 0 ? done : L;
+  HIPCHK(hipMemcpyAsync(c->vbase, c->compat_save, nv * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->tbase, c->compat_save + nv, ns * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  return rc;
+}
+
 template <class T>
 int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refresh_alpha, bool accum) {
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
@@ -888,7 +948,10 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refr
     if (rc2) return rc2;
   }
   if (L < 0) L = -L;
-  if (dense_engine(c)) return dn_hmc_transition(c, L, sampler, refresh_alpha, accum);
+  if (dense_engine(c)) {
+    if (c->ref_compat && sampler == AHMC_TS_ENDPOINT) return fail(c, AHMC_ERR_UNSUPPORTED, "ahmc_set_ref_compat is not implemented on the dense engine");
+    return dn_hmc_transition(c, L, sampler, refresh_alpha, accum);
+  }
   if (sampler == AHMC_TS_MULTINOMIAL) {
     size_t need = (size_t)(L + 1) * (size_t)c->N;
     if (need > c->hmc_H_elems) {
@@ -898,13 +961,22 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, double refr
       c->hmc_H_elems = need;
     }
   }
+  int64_t L_eff = L;
+  if (c->ref_compat && sampler == AHMC_TS_ENDPOINT) {   // Q1, opt-in: every chain integrates as far as the reference's coupled loop would
+    int rc3 = compat_hmc_stop_step(c, L, refresh_alpha, L_eff);
+    if (rc3) return rc3;
+  }
   KP<T> p = make_kp(c);
-  p.L = L;
+  p.L = L_eff;
   p.sampler = sampler;
   p.refresh_alpha = (T)refresh_alpha;
   p.accum = accum ? 1 : 0;
   if (const TargetOps<T>* o = ops_for(c)) o->hmc(c->G, c->E, group_grid(c), c->stream, p);
   HIPCHK(hipGetLastError());
+  if (L_eff != L) {  // (the statistic is the trajectory's nominal length, src/trajectory.jl:288)
+    static_assert(sizeof(int32_t) == 4, "n_steps is a 32-bit statistic");
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->ibase), (int)L, (size_t)c->N, c->stream));   // (KP::st_nsteps() = ibase[0 … N))
+  }
   c->iteration += 1;
   return AHMC_OK;
 }
@@ -1584,9 +1656,16 @@ int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
 int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
   FOR_CTX_MUT(ctx, {
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "leapfrog before set_position");
-    if (dense_engine(c)) return dn_leapfrog(c, n_steps);
+    if (dense_engine(c)) {
+      if (c->ref_compat) return fail(c, AHMC_ERR_UNSUPPORTED, "ahmc_set_ref_compat is not implemented on the dense engine");
+      return dn_leapfrog(c, n_steps);
+    }
     int rc = check_builtin(c, "leapfrog");
     if (rc) return rc;
+    if (c->ref_compat) {   // Q1, opt-in: all chains stop after the first step that left any chain non-finite
+      int64_t done = 0;
+      return compat_step_loop(c, n_steps < 0 ? -n_steps : n_steps, n_steps > 0, done);
+    }
     KP<T> p = make_kp(c);
     p.n_steps = n_steps;
     if (const TargetOps<T>* o = ops_for(c)) o->leapfrog(c->G, c->E, group_grid(c), c->stream, p);
@@ -1750,6 +1829,13 @@ int32_t ahmc_sample_reserve(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n
     if (!cfg) return fail(c, AHMC_ERR_ARGUMENT, "sample_reserve: cfg is NULL");
     if (n_samples < 1 || !cfg->nuts || dense_engine(c) || c->target_kind == AHMC_TARGET_EXTERNAL) return AHMC_OK;  // nothing to reserve ahead of time
     return reserve_normals(c, std::min<int64_t>(nuts_batch(c), n_samples));
+  });
+}
+
+int32_t ahmc_set_ref_compat(ahmc_ctx* ctx, int32_t on) {
+  FOR_CTX_MUT(ctx, {
+    c->ref_compat = on != 0;
+    return AHMC_OK;
   });
 }
 

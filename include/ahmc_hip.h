@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AHMC_ABI_VERSION 5
+#define AHMC_ABI_VERSION 6
 
 typedef struct ahmc_ctx ahmc_ctx;
 
@@ -339,6 +339,14 @@ int32_t ahmc_sample_from(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t i_fi
  * AHMC_INFO_NUTS_BATCH reports the shorter one).  Optional: without it the first call of a run reserves lazily, for its
  * own length.  Static-HMC kernels, the step-synchronous engine and ask / tell runs reserve nothing here.         */
 int32_t ahmc_sample_reserve(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int64_t n_samples);
+/* (ABI v6) The reference's MATRIX-MODE early exit, opt-in.  In vectorised mode `step` ends the integration of EVERY chain at the first
+ * step after which ANY chain's phase point is non-finite — `!isfinite(z) && break` with isfinite over all columns,
+ * src/integrator.jl:252-258, src/hamiltonian.jl:141-142.  By default each chain stops at its own first non-finite point
+ * (the reference's scalar semantics, and what 65 536 independent chains want).  on != 0 reproduces the coupled behaviour for
+ * ahmc_leapfrog and for ahmc_hmc_transition with EndPointTS — one launch per step and a flag read back after each: a mode for bit-level
+ * comparisons with the sampler-vec path, not for throughput.  Not available with TemperedLeapfrog or on the dense engine
+ * (AHMC_ERR_UNSUPPORTED at the call that would need it).                                                                              */
+int32_t ahmc_set_ref_compat(ahmc_ctx* ctx, int32_t on);
 
 /* running accumulators over kept transitions: Σ n_steps (all chains), number of kept
  * transitions, number of divergent transitions, per-chain Σθ and Σθ² (D,N) (may be NULL)     */

@@ -324,6 +324,16 @@ function sample_device(seed::Integer, h::Hamiltonian, κ::HMCKernel, θ::Matrix{
     return out
 end
 
+"""
+    ref_compat!(z, on=true)
+
+ABI v6: the reference's matrix-mode early exit (`!isfinite(z) && break` over ALL columns, `src/integrator.jl:252-258`) for `step` and static
+EndPointTS transitions — off by default (each chain stops at its own first non-finite point, the reference's scalar semantics).  A maintainer
+who compares the device path with the CPU sampler-vec path bit for bit on a batch that contains a diverging chain switches it on.
+"""
+ref_compat!(z::MI355XChains, on::Bool=true) =
+    check(z.ctx, ccall((:ahmc_set_ref_compat, LIB), Cint, (Ptr{Cvoid}, Cint), z.ctx, on ? 1 : 0))
+
 # --- ABI v3 (+ v4: accum_state / restore_accum! below): checkpoint / resume, the final gather, device-side diagnostics ---------------------------------
 # struct ahmc_adaptor_state (include/ahmc_hip.h): the value the reference carries in HMCState.adaptor
 # (src/abstractmcmc.jl:11-27) — isbits, same field order and alignment as the C struct

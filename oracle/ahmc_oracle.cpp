@@ -1738,6 +1738,10 @@ int32_t ahmco_set_num_threads(int32_t n) {
 int32_t ahmco_set_ref_compat(ahmc_ctx* ctx, int32_t on) {
   FOR_CTX(ctx, { c->ref_compat = on != 0; return AHMC_OK; });
 }
+// (ABI v6: the same switch as an entry point of the shared ABI — the HIP engine implements it too)
+int32_t ahmc_set_ref_compat(ahmc_ctx* ctx, int32_t on) {
+  FOR_CTX(ctx, { c->ref_compat = on != 0; return AHMC_OK; });
+}
 
 // oracle-only: out[N] = per chain, the smallest relative margin (note_margin) of any decision taken since the record was last
 // reset — U-turn dot products against 0, `ℓw < ℓw₁ + e` (progressive sampling, both levels), the slice rules, the divergence test,

@@ -169,17 +169,17 @@ def test_external_target_split_step(oracle, rng):
 def test_ref_compat_batch_early_exit(oracle):
     """Q1 (src/integrator.jl:252-258): in matrix mode the reference stops ALL chains at the first
     step where ANY chain is non-finite; per-chain semantics (the engine's, = the reference's scalar
-    path) let the healthy chains finish.  Documented difference, shown on the oracle."""
+    path) let the healthy chains finish.  The engine's default is the per-chain form; `ahmc_set_ref_compat` (ABI v6) switches to the
+    reference's coupled form on both the oracle and the HIP engine."""
     D, N = 3, 4
     h = A.Hamiltonian(A.UnitEuclideanMetric((D, N)), A.IsoGaussian(D))
     th = np.zeros((D, N))
     th[:, 2] = 1e200  # chain 2 overflows on its first step
     r = np.ones((D, N))
     res = {}
-    oracle.dll.ahmco_set_ref_compat.argtypes = [C.c_void_p, C.c_int32]
     for compat in (0, 1):
         e = A.Engine(h, N, lib=oracle)
-        oracle.dll.ahmco_set_ref_compat(e._ctx, compat)
+        e.set_ref_compat(bool(compat))     # (ABI v6: `ahmc_set_ref_compat`, implemented by the HIP engine too — tests/test_gpu_parity.py)
         e.set_integrator(A.Leapfrog(0.1))
         e.set_position(th, r)
         e.step(5)

@@ -1358,3 +1358,51 @@ def test_fixed_integration_time_hmcda(hip, oracle, rng):
     assert res[0][0] == res[1][0] and len(set(res[0][0])) > 2, res[0][0]     # L changed as ϵ adapted, identically
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-8)
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6, atol=1e-8)
+
+
+def test_reference_batch_exit_compat_mode(hip, oracle, rng):
+    """(ABI v6) `ahmc_set_ref_compat`: the reference's MATRIX-MODE early exit — `step` ends the integration of every chain at the first step
+    after which ANY chain's phase point is non-finite (src/integrator.jl:252-258 with isfinite over all columns, src/hamiltonian.jl:141-142;
+    SURVEY quirk Q1) — on the HIP engine against the oracle's literal form of it, for step(lf, h, z, n) both ways and for static EndPointTS
+    transitions; and off (the default) each chain stops at its own first non-finite point on both sides."""
+    D, N = 6, 200
+    h = A.Hamiltonian(make_metric("diag_chain", D, N, rng), A.IsoGaussian(D))
+    eps = np.full(N, 0.2)
+    eps[17] = 1e160          # one chain blows up at its second step (θ ≈ 1e160·r, ℓπ overflows at the next gradient)
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    for compat in (True, False):
+        g, o = pair(hip, oracle, h, N, np.float64, seed=4, eps=eps)
+        for e in (g, o):
+            e.set_ref_compat(compat)
+            e.set_position(th, r)
+            e.step(9)
+        zg, zo = g.phasepoint(), o.phasepoint()
+        ok = np.arange(N) != 17
+        np.testing.assert_allclose(zg.theta[:, ok], zo.theta[:, ok], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(zg.r[:, ok], zo.r[:, ok], rtol=1e-9, atol=1e-9)
+        np.testing.assert_array_equal(np.isfinite(zg.lp.value), np.isfinite(zo.lp.value))
+        assert not np.isfinite(zo.lp.value[17]) or not np.isfinite(zo.lk.value[17])
+        # how far did the OTHER chains get: a chain of the harmonic oscillator after k steps of 0.2 from (θ, r)
+        ref = A.Engine(h, N, rng=4, lib=oracle)
+        ref.set_integrator(A.Leapfrog(np.full(N, 0.2)))
+        ref.set_position(th, r)
+        taken = None
+        for k in range(1, 10):
+            ref.step(1)
+            if np.allclose(ref.phasepoint().theta[:, ok], zo.theta[:, ok], rtol=1e-9, atol=1e-9):
+                taken = k
+                break
+        assert taken is not None and (taken < 9 if compat else taken == 9), (compat, taken)   # coupled: everybody stopped with chain 17
+        # static EndPointTS transitions: the same coupling inside transition (the dry run finds the step, k_hmc integrates that far)
+        kern = A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(eps), A.FixedNSteps(7)))
+        for e in (g, o):
+            e.set_position(th)
+        for _ in range(3):
+            for e in (g, o):
+                e.transition(kern)
+            sg, so = g.stats(), o.stats()
+            same = compare_transition_stats(sg, so, np.float64, o, f"static hmc, batch exit compat={compat}")
+            assert (sg["n_steps"] == 7).all()
+            np.testing.assert_allclose(g.phasepoint().theta[:, same & ok], o.phasepoint().theta[:, same & ok], rtol=1e-9, atol=1e-9)
+            realign(g, o, same)
+        g.close(); o.close(); ref.close()
