@@ -432,7 +432,7 @@ def test_decision_margin_explains_what_a_perturbation_flips():
     δ = 1e-3 and 1e-2 (most near-ties are harmless — a sampling decision in a subtree the final candidate does not come from — so far
     fewer chains flip than have a margin below δ; what matters is that NO chain with a comfortable margin flips).  For rounding
     differences of 1e-16 … 1e-13 that puts the flips at margins far below the suite's 1e-9 bound — and is why the MI355X shows none
-    in 228 156 chain-comparisons."""
+    in 232 428 chain-comparisons."""
     import parity_util as PU
     from conftest import build_oracle
 
