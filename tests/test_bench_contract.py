@@ -165,6 +165,22 @@ def test_default_line_stays_under_the_drivers_capture():
     fat["config"]["secondary"]["cfg5"] = {"error": "RuntimeError('out of memory')" * 30}
     d3 = bench.compact_line(fat, None)
     assert "error" in d3["config"]["secondary"]["cfg5"] and len(json.dumps(d3)) <= bench.LINE_BUDGET
+    # round 6: the HBM roof beside the issue roof in every roofline, the secondaries' too
+    d6 = bench.compact_line(json.load(open(os.path.join(ROOT, "profiles", "r6_bench_default_detail.json"))), "bench_detail.json")   # (a round-6 record)
+    assert len(json.dumps(d6)) <= bench.LINE_BUDGET
+    for r in [d6["roofline"]] + [o["roofline"] for o in d6["config"]["secondary"].values()]:
+        assert "hbm_model_frac" in r and r["hbm_model_frac"] is not None, r
+    assert d6["roofline"].get("hbm_measured_frac") is not None and d6["config"]["secondary"]["cfg4"]["roofline"].get("hbm_measured_frac") is not None
+    # … and a record that NO shedding brings under the budget still comes out: the headline keys alone (the old code asserted and printed nothing)
+    huge = _stub_full_record()
+    for i in range(40):
+        huge["config"]["secondary"][f"extra{i}"] = json.loads(json.dumps(huge["config"]["secondary"]["cfg3"]))
+    d4 = bench.compact_line(huge, "bench_detail.json")
+    line4 = json.dumps(d4)
+    assert len(line4) <= bench.LINE_BUDGET
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d4, k
+    assert d4["value"] == d["value"] and d4["config"]["detail"] == "bench_detail.json" and "line_shortened" in d4["config"]
 
 
 def test_counters_are_refused_when_taken_on_other_kernels(tmp_path, monkeypatch):
