@@ -35,6 +35,8 @@
 extern "C" {
 #endif
 
+/* v6 = v5 + ahmc_set_ref_compat (round 6); v5 = v4 + ahmc_sample_reserve, ahmc_comm_info, AHMC_INFO_NUTS_DRAW_BATCH; v4 = v3 + the
+ * device-side user log-densities (target plugin / kernel), the accumulator checkpoint, the dense engine's launch counters. */
 #define AHMC_ABI_VERSION 6
 
 typedef struct ahmc_ctx ahmc_ctx;
