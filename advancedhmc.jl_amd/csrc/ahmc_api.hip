@@ -737,7 +737,7 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
   // Measured (profiles/r6_experiments.md r6n): cfg3's 4-transition launches gain 6 % in the sampling phase (3.20 -> 3.40e9: the 0.1 ms of
   // k_normals and its launch gap no longer sit between two 6 ms launches); cfg2's 256-transition launches lose 0.4 % (a 5.7 ms k_normals beside
   // a VALU-bound k_nuts takes what it gives) and cfg5's 32 are unchanged — so only launches whose normals are at most 2 GiB are prefetched.
-  static const size_t prefetch_max_bytes = getenv("AHMC_NORMALS_PREFETCH_MAX_MB") ? (size_t)atoll(getenv("AHMC_NORMALS_PREFETCH_MAX_MB")) << 20 : (size_t)2 << 30;
+  const size_t prefetch_max_bytes = getenv("AHMC_NORMALS_PREFETCH_MAX_MB") ? (size_t)atoll(getenv("AHMC_NORMALS_PREFETCH_MAX_MB")) << 20 : (size_t)2 << 30;
   if (hint > 0 && refresh_alpha == 0 && (size_t)hint * (size_t)c->D * (size_t)c->N * sizeof(T) <= prefetch_max_bytes) {
     if (c->norm_prefetch < 0) c->norm_prefetch = (getenv("AHMC_NORMALS_PREFETCH") && atoi(getenv("AHMC_NORMALS_PREFETCH")) == 0) ? 0 : 1;
     const size_t need2 = (size_t)hint * (size_t)c->D * (size_t)c->N;

@@ -195,6 +195,8 @@ SCHEDULES = [
     {"AHMC_NUTS_FIRST_BATCH": "5"},                      # a short first launch, then by measured work
     {"AHMC_NUTS_ORDER_REFRESH": "0", "AHMC_NUTS_DRAW_BATCH": "9", "AHMC_NUTS_FIRST_BATCH": "4"},
     {"AHMC_NUTS_BATCH": "6"},                            # warm-up and draws in short launches
+    {"AHMC_NORMALS_PREFETCH": "0"},                      # round 6: the next launch's normals made in series again (the default makes them beside the launch)
+    {"AHMC_NORMALS_PREFETCH_MAX_MB": "100000", "AHMC_NUTS_DRAW_BATCH": "5"},   # … prefetched for every launch length, ragged launches
 ]
 
 
@@ -205,7 +207,8 @@ def test_dispatch_schedules_leave_the_chains_untouched(hip, monkeypatch, D, targ
     statistics, the adapted step sizes and metric are identical to the default schedule's."""
     n_adapts, n = 40, 340          # 300 draws: the default schedule times groups of launches of 32, 16, … before it settles
     ref = None
-    names = ("AHMC_NUTS_NO_ORDER", "AHMC_NUTS_ORDER_REFRESH", "AHMC_NUTS_DRAW_BATCH", "AHMC_NUTS_FIRST_BATCH", "AHMC_NUTS_BATCH", "AHMC_NUTS_SCHED")
+    names = ("AHMC_NUTS_NO_ORDER", "AHMC_NUTS_ORDER_REFRESH", "AHMC_NUTS_DRAW_BATCH", "AHMC_NUTS_FIRST_BATCH", "AHMC_NUTS_BATCH", "AHMC_NUTS_SCHED",
+             "AHMC_NORMALS_PREFETCH", "AHMC_NORMALS_PREFETCH_MAX_MB")
     for env in SCHEDULES:
         for v in names:
             monkeypatch.delenv(v, raising=False)
