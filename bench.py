@@ -52,6 +52,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md chip table
+HBM_ACHIEVABLE_GBS = 6290.0    # ibid.: the measured copy rate (SURVEY 8d reports the model fraction against both)
 VALU_PEAK_GINSTR = 1024 * 2.4e9 / 4 / 1e9   # 256 CUs × 4 SIMDs, 2.4 GHz, one wave64 VALU instruction per 4 cycles
 F64_MFMA_PEAK_TFLOPS = 78.6    # dense f64 matrix peak
 F32_MFMA_PEAK_TFLOPS = 157.3
@@ -428,6 +429,8 @@ def run_config(ctx, cfg_name, steps, T, warm_trans, repeats, cpu_budget_s, dim=0
                         # the HBM roof beside the issue roof: SURVEY 8(d)'s state-through-memory model at this kernel's rate, and
                         # the bytes the counters saw beyond L2 at the same rate, both as fractions of 8 TB/s
                         "hbm_model_frac": dom.get("hbm_model_frac"), "hbm_measured_frac": dom.get("hbm_measured_frac"),
+                        "hbm_peaks_gbs": {"spec": HBM_PEAK_GBS, "achievable_copy": HBM_ACHIEVABLE_GBS,
+                                          "note": "the two fractions are of the spec peak (SURVEY 8d); x %.3f for the achievable copy rate" % (HBM_PEAK_GBS / HBM_ACHIEVABLE_GBS)},
                         "useful_valu_floor_per_leapfrog": dom.get("useful_valu_floor_per_leapfrog"), "valu_efficiency": dom.get("valu_efficiency"),
                         "peak_definition": ("mix-weighted VALU issue peak of this kernel: N / sum_c n_c * cycles_c over its dynamic instruction classes at 2.4 GHz x "
                                             "1024 SIMDs, cycles_c in {2,4,8,16} per wave64 instruction = the class of each instruction type by its MEASURED rate "
