@@ -781,12 +781,15 @@ class Engine:
         acc["n_transitions"] = ntr.value
         return {"adaptor": {k: getattr(st, k) for k, _ in capi.AdaptorState._fields_}, "da": da, "welford": wv,
                 "theta": z.theta, "r": z.r, "lp": z.lp.value, "grad": z.lp.gradient,
-                "metric": self.get_metric(), "metric_kind": self.metric_kind, "stepsize": self.get_stepsize(), "accum": acc}
+                "metric": self.get_metric(), "metric_kind": self.metric_kind, "stepsize": self.get_stepsize(),
+                "stepsize_scalar": bool(self.info("stepsize_scalar")), "accum": acc}
 
     def set_state(self, state: dict):
         if state["metric"] is not None:
             self._call("ahmc_set_metric", state["metric_kind"], capi.as_ptr(np.asfortranarray(state["metric"], dtype=self.dtype)), state["metric"].size)
         eps = np.ascontiguousarray(state["stepsize"], dtype=self.dtype)
+        if state.get("stepsize_scalar"):   # ONE nominal ϵ stays one (κ's integrator is restored as it was: FixedIntegrationTime needs it, Q6)
+            eps = eps[:1].copy()
         self._call("ahmc_set_stepsize", capi.as_ptr(eps), eps.size)
         th, r = self._mat(state["theta"], "θ"), self._mat(state["r"], "r")
         lp = np.ascontiguousarray(state["lp"], dtype=self.dtype).reshape(self.N)
@@ -863,7 +866,7 @@ class Engine:
 
     INFO = {"group_lanes": 0, "elems_per_lane": 1, "nuts_launches": 2, "nuts_batch": 3, "iteration": 4, "nuts_kernel_ns": 5,
             "nuts_warm_launches": 6, "nuts_warm_kernel_ns": 7, "dense_gemm_launches": 8, "dense_gemm_small_launches": 9, "dense_pipelines": 10,
-            "dense_pool": 11, "nuts_draw_batch": 12, "dense_epoch_launches": 13}
+            "dense_pool": 11, "nuts_draw_batch": 12, "dense_epoch_launches": 13, "stepsize_scalar": 14}
 
     def info(self, key):
         """engine introspection (ahmc_get_info): thread geometry, NUTS launch count / batch, iteration"""

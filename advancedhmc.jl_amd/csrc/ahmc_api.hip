@@ -2203,6 +2203,7 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
       case AHMC_INFO_DENSE_POOL: *out = c->dn_last_pool; break;
       case AHMC_INFO_DENSE_EPOCH_LAUNCHES: *out = c->dn_epoch_launches; break;
       case AHMC_INFO_NUTS_DRAW_BATCH: *out = c->sched.phase == 4 ? c->sched.best_len : 0; break;
+      case AHMC_INFO_STEPSIZE_SCALAR: *out = c->eps_scalar ? 1 : 0; break;
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
     }
     return AHMC_OK;

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-/* v6 = v5 + ahmc_set_ref_compat (round 6); v5 = v4 + ahmc_sample_reserve, ahmc_comm_info, AHMC_INFO_NUTS_DRAW_BATCH; v4 = v3 + the
+/* v6 = v5 + ahmc_set_ref_compat, AHMC_INFO_STEPSIZE_SCALAR (round 6); v5 = v4 + ahmc_sample_reserve, ahmc_comm_info, AHMC_INFO_NUTS_DRAW_BATCH; v4 = v3 + the
  * device-side user log-densities (target plugin / kernel), the accumulator checkpoint, the dense engine's launch counters. */
 #define AHMC_ABI_VERSION 6
 
@@ -466,7 +466,10 @@ typedef enum {
   AHMC_INFO_DENSE_POOL = 11,                /* 1: the last dense NUTS batch ran on the point pool (k_d_tree2), 0: the copying kernel */
   AHMC_INFO_NUTS_DRAW_BATCH = 12,           /* transitions per launch the engine settled on for the sampling phase by timing its own
                                                launches (ahmc_sample, round 4); 0 while it has not settled (then AHMC_INFO_NUTS_BATCH) */
-  AHMC_INFO_DENSE_EPOCH_LAUNCHES = 13       /* launches of the chain-complete dense kernel (k_dense_epoch, round 4) since ahmc_create  */
+  AHMC_INFO_DENSE_EPOCH_LAUNCHES = 13,      /* launches of the chain-complete dense kernel (k_dense_epoch, round 4) since ahmc_create  */
+  AHMC_INFO_STEPSIZE_SCALAR = 14            /* 1: the context holds ONE nominal step size (ahmc_set_stepsize with n = 1, not adapted per chain
+                                               since) — ahmc_get_stepsize always fills N values, so a checkpoint asks here whether to hand
+                                               back one (FixedIntegrationTime takes nothing else, src/trajectory.jl:241-243)          */
 } ahmc_info;
 int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out);
 

@@ -361,6 +361,9 @@ function checkpoint(z::MI355XChains{T}, metric::AbstractMetric) where {T}
     pp = PhasePoint(z)
     ϵ = Vector{T}(undef, z.N)
     check(z.ctx, ccall((:ahmc_get_stepsize, LIB), Cint, (Ptr{Cvoid}, Ptr{T}), z.ctx, ϵ))
+    one = Ref{Int64}(0)                                                      # AHMC_INFO_STEPSIZE_SCALAR = 14: ONE nominal ϵ stays one
+    check(z.ctx, ccall((:ahmc_get_info, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), z.ctx, 14, one))
+    one[] != 0 && (ϵ = ϵ[1:1])
     M = metric isa UnitEuclideanMetric ? nothing : similar(metric.M⁻¹, T)
     kind = metric isa UnitEuclideanMetric ? METRIC_UNIT : metric isa DiagEuclideanMetric ? METRIC_DIAG : METRIC_DENSE
     M === nothing || check(z.ctx, ccall((:ahmc_get_metric, LIB), Cint, (Ptr{Cvoid}, Ptr{T}, Int64), z.ctx, M, length(M)))

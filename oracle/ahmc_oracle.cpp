@@ -1076,11 +1076,14 @@ void hmc_transition_chain(Ctx<T>* c, int64_t i, int64_t L, int sampler, int64_t 
     T u = (T)rng.uniform(RNG_TRANSITION, 0);
     T cum = 0;
     size_t idx = 0;
+    // (margin: the cumulative sums live on [0, 1], each term exp(−H_k − lse) carries the ABSOLUTE rounding of its energy as a relative
+    // error — the scale of the comparison is the transition's energy scale, as for every other weight comparison)
+    const double hs = std::isfinite((double)H0) ? std::max(1.0, std::abs((double)H0)) : 1.0;
     while (cum < u && idx < zs.size()) {
-      note_margin(&c->margin[i], (double)cum, (double)u, 1.0);   // (probabilities: the cumulative sums live on [0, 1])
+      note_margin(&c->margin[i], (double)cum, (double)u, hs);
       cum += std::exp(lw[idx++] - lse);
     }
-    if (idx < zs.size()) note_margin(&c->margin[i], (double)cum, (double)u, 1.0);   // the comparison that ended the scan
+    if (idx < zs.size()) note_margin(&c->margin[i], (double)cum, (double)u, hs);   // the comparison that ended the scan
     if (idx < 1) idx = 1;
     zp = *zs[idx - 1];
     is_accept = true;
@@ -2423,6 +2426,7 @@ int32_t ahmc_get_info(ahmc_ctx* ctx, int32_t what, int64_t* out) {
       case AHMC_INFO_DENSE_GEMM_LAUNCHES: case AHMC_INFO_DENSE_GEMM_SMALL_LAUNCHES: case AHMC_INFO_DENSE_PIPELINES: case AHMC_INFO_DENSE_POOL: case AHMC_INFO_NUTS_DRAW_BATCH: case AHMC_INFO_DENSE_EPOCH_LAUNCHES: *out = 0; break;
       case AHMC_INFO_NUTS_BATCH: *out = 1; break;
       case AHMC_INFO_ITERATION: *out = (int64_t)c->iteration; break;
+      case AHMC_INFO_STEPSIZE_SCALAR: *out = c->eps_scalar ? 1 : 0; break;
       default: return fail(c, AHMC_ERR_ARGUMENT, "get_info: unknown key");
     }
     return AHMC_OK;

@@ -1,0 +1,325 @@
+"""Randomised configurations: HIP engine (through the C ABI) against the CPU oracle on combinations no hand-written test names.
+
+The hand-written parity tests walk the configuration space along its axes (every geometry with one kernel, every kernel on one
+geometry …).  This file draws whole configurations — element type × dimension × chains × target × metric × integrator × trajectory
+sampler × termination criterion × momentum refreshment — from a seeded generator, so that the rare product of two features (a strict
+U-turn criterion on a multi-wave chain with a tempered integrator and partial refreshment, a one-chain dense metric in Float32 …) meets the
+oracle too.  The draw is deterministic (seed = case index): a failure names its case and reproduces.
+
+The bar is the one of tests/test_gpu_parity.py: every discrete statistic identical on every chain unless the oracle took one of that
+chain's decisions within the margin bound of a tie (tests/parity_util.py), continuous results to the tolerances of that file on the agreeing
+chains.  A configuration the reference rejects must be rejected by both engines with the same error class.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ahmc_amd as A
+import parity_util as PU
+from test_gpu_parity import RTOL, compare_transition_stats, make_target, realign, _spd
+
+N_CASES = int(os.environ.get("AHMC_RANDOM_CASES", "96"))   # (a one-off hunt: AHMC_RANDOM_CASES=1000 pytest tests/test_random_configurations.py -m gpu)
+DIMS = [1, 2, 3, 7, 16, 31, 33, 64, 65, 100, 129, 255, 256, 300, 513, 700, 1025, 2048]
+CHAINS = [1, 2, 5, 63, 64, 65, 130, 257]
+
+
+def draw_case(i):
+    """configuration number i — everything a transition depends on"""
+    rs = np.random.default_rng(1000 + i)
+    c = {"i": i, "dtype": (np.float64, np.float64, np.float32)[rs.integers(3)]}
+    c["D"] = D = int(rs.choice(DIMS))
+    c["N"] = N = int(rs.choice(CHAINS if D <= 300 else CHAINS[:6]))
+    targets = ["iso", "diag"] + (["funnel"] if D >= 2 else []) + (["hier"] if D >= 3 else []) + (["dense"] if D <= 129 else [])
+    c["target"] = str(rs.choice(targets))
+    metrics = ["unit", "diag_shared", "diag_chain"] + (["dense"] if D <= 129 else [])
+    c["metric"] = str(rs.choice(metrics))
+    # step size: small enough that trees grow, large enough that some turn early; per chain or one scalar
+    base = (0.35 if c["target"] != "funnel" else 0.2) * D ** -0.25
+    c["eps_per_chain"] = bool(rs.integers(2))
+    c["eps"] = base * (0.5 + rs.random(N)) if c["eps_per_chain"] else float(base * (0.5 + rs.random()))
+    c["integrator"] = str(rs.choice(["leapfrog", "leapfrog", "jittered", "tempered"]))
+    c["jitter"] = float(rs.choice([0.1, 0.5]))
+    c["alpha"] = float(rs.choice([1.02, 1.1]))
+    c["nuts"] = bool(rs.integers(4))   # three in four dynamic
+    if c["nuts"]:
+        c["TS"] = str(rs.choice(["multinomial", "slice"]))
+        c["TC"] = str(rs.choice(["generalised", "generalised", "classic", "strict"]))
+        c["max_depth"] = int(rs.integers(1, 7 if D <= 300 else 6))
+        c["delta_max"] = float(rs.choice([1000.0, 1000.0, 5.0]))
+    else:
+        c["TS"] = str(rs.choice(["endpoint", "multinomial"]))
+        c["static"] = str(rs.choice(["nsteps", "nsteps", "time"]))
+        c["L"] = int(rs.integers(1, 12))
+        c["lam"] = float(base * rs.uniform(0.5, 6.0))
+    c["refresh"] = float(rs.choice([0.0, 0.0, 0.3, 0.9]))
+    c["n_transitions"] = 3
+    c["seed"] = int(rs.integers(1, 1 << 30))
+    return c
+
+
+def describe(c):
+    keys = ("dtype", "D", "N", "target", "metric", "integrator", "nuts", "TS", "TC", "max_depth", "static", "L", "refresh", "eps_per_chain")
+    return f"case {c['i']}: " + " ".join(f"{k}={c[k].__name__ if k == 'dtype' else c[k]}" for k in keys if k in c)
+
+
+def build(c, rng):
+    D, N = c["D"], c["N"]
+    if c["metric"] == "dense":
+        metric = A.DenseEuclideanMetric(_spd(D, rng))
+    elif c["metric"] == "unit":
+        metric = A.UnitEuclideanMetric((D, N))
+    elif c["metric"] == "diag_shared":
+        metric = A.DiagEuclideanMetric(0.5 + rng.random(D))
+    else:
+        metric = A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+    target = A.DenseGaussian(_spd(D, rng, 3.0)) if c["target"] == "dense" else make_target(c["target"], D, rng)
+    h = A.Hamiltonian(metric, target)
+    lf = {"leapfrog": lambda: A.Leapfrog(c["eps"]), "jittered": lambda: A.JitteredLeapfrog(c["eps"], c["jitter"]),
+          "tempered": lambda: A.TemperedLeapfrog(c["eps"], c["alpha"])}[c["integrator"]]()
+    TS = {"endpoint": A.EndPointTS, "multinomial": A.MultinomialTS, "slice": A.SliceTS}[c["TS"]]
+    if c["nuts"]:
+        TC = {"generalised": A.GeneralisedNoUTurn, "classic": A.ClassicNoUTurn, "strict": A.StrictGeneralisedNoUTurn}[c["TC"]]
+        term = TC(max_depth=c["max_depth"], delta_max=c["delta_max"])
+    else:
+        term = A.FixedNSteps(c["L"]) if c["static"] == "nsteps" else A.FixedIntegrationTime(c["lam"])
+    refreshment = A.PartialMomentumRefreshment(c["refresh"]) if c["refresh"] else A.FullMomentumRefreshment()
+    return h, lf, A.HMCKernel(refreshment, A.Trajectory(TS, lf, term))
+
+
+def refused(c):
+    """FixedIntegrationTime with a VECTOR of step sizes (src/trajectory.jl:241-243 takes one nominal ϵ); a vector of one chain's is that ϵ"""
+    return (not c["nuts"]) and c.get("static") == "time" and c["eps_per_chain"] and c["N"] > 1
+
+
+def advance(e, kernel):
+    """one transition: Engine.transition, or — PartialMomentumRefreshment lives in the sample loop's kernel configuration — a
+    one-iteration sample call (src/sampler.jl:159-248 with n_samples = 1)"""
+    if kernel.refreshment.alpha:
+        e.run(kernel, 1, 0)
+    else:
+        e.transition(kernel)
+
+
+def run_case(c, hip, oracle):
+    rng = np.random.default_rng(c["seed"])
+    dtype, D, N = c["dtype"], c["D"], c["N"]
+    what = describe(c)
+    h, lf, kernel = build(c, rng)
+    th0 = 0.5 * rng.normal(size=(D, N))
+    engines, errors = [], []
+    for lib in (hip, oracle):
+        try:
+            e = A.Engine(h, N, dtype=dtype, rng=c["seed"] & 0xFFFF, lib=lib)
+            engines.append(e)
+            e.set_integrator(lf)
+            e.set_position(th0)
+            e.refresh()          # (partial refreshment mixes with the momentum the point holds: give it one)
+            advance(e, kernel)
+            errors.append(None)
+        except A.AHMCError as ex:
+            errors.append(type(ex))
+    try:
+        # the same configuration is valid on both sides, or refused by both with the same class of error
+        assert errors[0] == errors[1], f"{what}: HIP engine {errors[0]}, oracle {errors[1]}"
+        if errors[0] is not None:
+            return "refused:" + errors[0].__name__
+        g, o = engines
+        rt = RTOL[dtype] * 100
+        for it in range(c["n_transitions"]):
+            if it:
+                for e in (g, o):
+                    advance(e, kernel)
+            sg, so = g.stats(), o.stats()
+            clear = PU.decision_margin(o, reset=False) >= PU.MARGIN_BOUND[np.dtype(dtype)]
+            # Float32 on a trajectory that left the stable region (energy error beyond 20 on either side — on its way to the Δ_max test):
+            # rounding is amplified exponentially along it, WHERE it crosses Δ_max is not a property any margin bounds.  Those chains are
+            # held to "both sides saw the instability"; everywhere else, and in Float64 throughout, the margin rule applies
+            sel = None
+            if dtype == np.float32:
+                wild = np.maximum(np.abs(sg["max_hamiltonian_energy_error"]), np.abs(so["max_hamiltonian_energy_error"])) > 20
+                wild |= ~np.isfinite(sg["max_hamiltonian_energy_error"]) | ~np.isfinite(so["max_hamiltonian_energy_error"])
+                both = (np.abs(sg["max_hamiltonian_energy_error"]) > 5) & (np.abs(so["max_hamiltonian_energy_error"]) > 5)
+                both |= ~np.isfinite(sg["max_hamiltonian_energy_error"]) & ~np.isfinite(so["max_hamiltonian_energy_error"])
+                assert (both | ~wild).all(), (what, "an unstable trajectory on one side only", np.flatnonzero(wild & ~both)[:8])
+                sel = ~wild
+            same = compare_transition_stats(sg, so, dtype, o, what, sel=sel)
+            # (a near-tie in the CHOICE of the candidate leaves every statistic alone and moves θ: the continuous results are held to
+            # the tolerance on the chains none of whose decisions was near a tie)
+            same = same & clear
+            zg, zo = g.phasepoint(), o.phasepoint()
+            tol = 1e-8 if dtype == np.float64 else 2e-2   # (f32: trees of up to 63 single-precision leapfrogs)
+            np.testing.assert_allclose(zg.theta[:, same], zo.theta[:, same], rtol=tol, atol=tol, err_msg=what + " theta")
+            np.testing.assert_allclose(zg.lp.value[same], zo.lp.value[same], rtol=tol * 10, atol=tol * 10 * max(1.0, D / 16), err_msg=what + " lp")
+            if not c["nuts"]:
+                L = c["L"] if c["static"] == "nsteps" else max(1, int(np.floor(c["lam"] / float(np.ravel(c["eps"])[0]))))
+                assert (sg["n_steps"] == L).all(), (what, L, sg["n_steps"][:8])
+            realign(g, o, same)
+        return "ran"
+    finally:
+        for e in engines:
+            e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_configuration(hip, oracle, i):
+    c = draw_case(i)
+    if refused(c):
+        # FixedIntegrationTime needs ONE nominal step size (reference quirk Q6): both sides must refuse the vector
+        assert run_case(c, hip, oracle) == "refused:ArgumentError", describe(c)
+        return
+    assert run_case(c, hip, oracle) == "ran", describe(c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(0, N_CASES, 2))
+def test_random_configuration_bulk_equals_stepwise(hip, i):
+    """the same configurations through ONE `ahmc_sample_from` call of 5 iterations against 5 calls of one: the launch schedule (batched
+    NUTS launches, prefetched normals, the dense engine's epochs) must not move a single bit of any chain"""
+    c = draw_case(i)
+    if refused(c):
+        pytest.skip("refused configuration (covered by test_random_configuration)")
+    rng = np.random.default_rng(c["seed"])
+    h, lf, kernel = build(c, rng)
+    th0 = 0.5 * rng.normal(size=(c["D"], c["N"]))
+    out = []
+    for bulk in (True, False):
+        e = A.Engine(h, c["N"], dtype=c["dtype"], rng=c["seed"] & 0xFFFF, lib=hip)
+        try:
+            e.set_integrator(lf)
+            e.set_position(th0)
+            e.refresh()
+            if bulk:
+                e.run(kernel, 5, 0)
+            else:
+                for _ in range(5):
+                    e.run(kernel, 1, 0)
+            z, st = e.phasepoint(), e.stats()
+            out.append((z.theta.copy(), z.r.copy(), st["n_steps"].copy(), st["hamiltonian_energy"].copy()))
+        finally:
+            e.close()
+    for a, b, name in zip(out[0], out[1], ("theta", "r", "n_steps", "hamiltonian_energy")):
+        np.testing.assert_array_equal(a, b, err_msg=describe(c) + " " + name)
+
+
+def draw_adaptation(i):
+    rs = np.random.default_rng(50_000 + i)
+    c = {"i": i, "dtype": (np.float64, np.float64, np.float32)[rs.integers(3)]}
+    c["D"] = D = int(rs.choice([1, 2, 5, 16, 33, 64, 100, 257, 700]))
+    c["N"] = int(rs.choice([1, 2, 17, 64, 130]))
+    c["metric"] = str(rs.choice(["unit", "diag_chain", "diag_chain"] + (["dense"] if D <= 100 else [])))
+    kinds = ["stepsize", "stan", "naive", "massmatrix"] + (["nutpie", "pooled"] if c["metric"] == "diag_chain" else [])
+    c["kind"] = str(rs.choice(kinds))
+    c["n_adapts"] = int(rs.integers(12, 220))
+    c["buffers"] = (int(rs.integers(1, 90)), int(rs.integers(1, 60)), int(rs.integers(2, 40)))
+    c["delta"] = float(rs.choice([0.65, 0.8, 0.95]))
+    c["seed"] = int(rs.integers(1, 1 << 30))
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(max(24, N_CASES // 4)))
+def test_random_adaptation(hip, oracle, i):
+    """adapt!(…) on IDENTICAL inputs (θ, ∇ℓπ, α drawn at random per iteration — the dual-averaging loop is not contractive, see
+    test_adaptation) for random adaptor kinds, metrics, sizes, Stan window parameters and n_adapts — including windows that do not
+    fit n_adapts (src/adaptation/stan_adaptor.jl:13-50: the 15 % / 75 % / 10 % fallback): ϵ and M⁻¹ agree at every checkpoint and
+    after finalize!"""
+    c = draw_adaptation(i)
+    rng = np.random.default_rng(c["seed"])
+    D, N, dtype, n_adapts = c["D"], c["N"], c["dtype"], c["n_adapts"]
+    metric = {"unit": lambda: A.UnitEuclideanMetric((D, N)), "diag_chain": lambda: A.DiagEuclideanMetric((D, N)),
+              "dense": lambda: A.DenseEuclideanMetric((D,))}[c["metric"]]()
+    h = A.Hamiltonian(metric, A.IsoGaussian(D))
+    lf = A.Leapfrog(np.full(N, 0.1)) if c["metric"] != "dense" else A.Leapfrog(0.1)
+    ssa = A.StepSizeAdaptor(c["delta"], lf)
+    pc = {"nutpie": A.NutpieVar, "pooled": A.PooledVar}.get(c["kind"], A.MassMatrixAdaptor)(metric)
+    ib, tb, ws = c["buffers"]
+    ad = {"stepsize": ssa, "massmatrix": pc, "naive": A.NaiveHMCAdaptor(pc, ssa)}.get(c["kind"], A.StanHMCAdaptor(pc, ssa, ib, tb, ws))
+    what = f"adaptation case {i}: " + " ".join(f"{k}={getattr(v, '__name__', v)}" for k, v in c.items() if k not in ("i", "seed"))
+    engines, errors = [], []
+    for lib in (hip, oracle):
+        try:
+            e = A.Engine(h, N, dtype=dtype, rng=3, lib=lib)
+            engines.append(e)
+            e.set_integrator(lf)
+            e.set_position(np.zeros((D, N)))
+            e.adaptor_init(ad)
+            errors.append(None)
+        except A.AHMCError as ex:
+            errors.append(type(ex))
+    try:
+        assert errors[0] == errors[1], f"{what}: HIP engine {errors[0]}, oracle {errors[1]}"
+        if errors[0] is not None:
+            return
+        g, o = engines
+        rt = 1e-9 if dtype == np.float64 else 2e-3
+        scale = 0.5 + 2 * rng.random((D, 1))
+        checks = {1, 2, n_adapts // 3, n_adapts // 2, n_adapts - 1, n_adapts, n_adapts + 3}
+        for it in range(1, n_adapts + 4):
+            th, gr, al = scale * rng.normal(size=(D, N)), rng.normal(size=(D, N)) / scale, np.clip(c["delta"] + 0.15 * rng.standard_normal(N), 0.0, 1.0)   # (around δ: ϵ neither collapses nor explodes)
+            for e in (g, o):
+                e.adapt(it, n_adapts, theta=th, alpha=al, grad=gr if c["kind"] == "nutpie" else None)
+            if it in checks:
+                np.testing.assert_allclose(g.get_stepsize(), o.get_stepsize(), rtol=rt, atol=1e3 * float(np.finfo(dtype).tiny), err_msg=f"{what}: ϵ at {it}")
+                if c["metric"] != "unit":
+                    Mo = o.get_metric()
+                    np.testing.assert_allclose(g.get_metric(), Mo, rtol=rt * 10, atol=rt * 10 * float(np.abs(Mo).max()), err_msg=f"{what}: M⁻¹ at {it}")
+    finally:
+        for e in engines:
+            e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(1, N_CASES, 4))
+def test_random_configuration_checkpoint_resume(hip, i):
+    """HMCState (src/abstractmcmc.jl:11-27) on random configurations WITH an adaptor running: iterations 1 … 4, `get_state`, 5 … 8 —
+    against a fresh engine that is given the state and runs 5 … 8: bit for bit, whatever kernel, integrator, metric and adaptor"""
+    c = draw_case(i)
+    if refused(c) or c["refresh"]:
+        pytest.skip("refused configuration / partial refreshment carries the momentum, which HMCState does not hold (the reference's neither)")
+    rng = np.random.default_rng(c["seed"])
+    h, lf, kernel = build(c, rng)
+    th0 = 0.5 * rng.normal(size=(c["D"], c["N"]))
+    adapt = c["integrator"] == "leapfrog" and c["metric"] != "dense"
+    if not c["nuts"] and c["static"] == "time" and c["N"] > 1:
+        adapt = False   # (per-chain adapted step sizes + FixedIntegrationTime: refused, Q6)
+    def fresh():
+        e = A.Engine(h, c["N"], dtype=c["dtype"], rng=c["seed"] & 0xFFFF, lib=hip)
+        e.set_integrator(lf)
+        e.set_position(th0)
+        if adapt:
+            pc = A.MassMatrixAdaptor(h.metric)
+            e.adaptor_init(A.StanHMCAdaptor(pc, A.StepSizeAdaptor(0.8, lf), 2, 2, 2) if c["metric"] != "unit" else A.StepSizeAdaptor(0.8, lf))
+        return e
+    a = fresh()
+    try:
+        a.run(kernel, 4, 8 if adapt else 0)
+        st = a.get_state()
+        a.run(kernel, 8, 8 if adapt else 0, i_first=5)
+        b = fresh()
+        try:
+            b.set_state(st)
+            b.run(kernel, 8, 8 if adapt else 0, i_first=5)
+            za, zb = a.phasepoint(), b.phasepoint()
+            np.testing.assert_array_equal(za.theta, zb.theta, err_msg=describe(c))
+            np.testing.assert_array_equal(a.get_stepsize(), b.get_stepsize(), err_msg=describe(c))
+            if c["metric"] != "unit":
+                np.testing.assert_array_equal(a.get_metric(), b.get_metric(), err_msg=describe(c))
+            np.testing.assert_array_equal(a.stats()["n_steps"], b.stats()["n_steps"], err_msg=describe(c))
+        finally:
+            b.close()
+    finally:
+        a.close()
+
+
+def test_the_draw_covers_the_space():
+    """(no GPU work) the generator reaches every value of every axis, and the rare products this file exists for"""
+    cases = [draw_case(i) for i in range(96)]
+    for key, want in (("dtype", 2), ("target", 5), ("metric", 4), ("integrator", 3), ("TS", 3), ("TC", 3), ("refresh", 3)):
+        got = {str(c[key]) for c in cases if key in c}
+        assert len(got) >= want, (key, got)
+    assert sum(c["D"] > 512 for c in cases) >= 8                                               # multi-wave chains
+    assert sum(c["nuts"] and c["TC"] != "generalised" and c["integrator"] != "leapfrog" for c in cases) >= 4
+    assert sum(c["metric"] == "dense" and c["dtype"] == np.float32 for c in cases) >= 2
+    assert sum(c["N"] == 1 for c in cases) >= 4
