@@ -313,6 +313,119 @@ def test_random_configuration_checkpoint_resume(hip, i):
         a.close()
 
 
+def draw_dense(i):
+    rs = np.random.default_rng(90_000 + i)
+    c = {"i": i, "dtype": (np.float64, np.float64, np.float32)[rs.integers(3)]}
+    c["D"] = int(rs.choice([256, 384, 512, 512] if c["dtype"] == np.float64 else [256, 384, 512, 768, 1024]))
+    c["N"] = int(rs.integers(33, 700 if c["D"] <= 512 else 300))
+    c["chunk"] = rs.choice([None, None, "3", "5", "17"])
+    c["TS"] = str(rs.choice(["multinomial", "multinomial", "slice"]))
+    c["TC"] = str(rs.choice(["generalised", "generalised", "classic", "strict"]))
+    c["temper"] = rs.choice([None, None, 1.03, 1.08])
+    # (the column-tile shapes compiled beside the default, AHMC_EPOCH2_SHAPES: Float64 D = 512 both, Float32 D = 512 the 16-chain one)
+    c["nct"] = rs.choice([None, None, "1", "2"] if c["dtype"] == np.float64 else [None, "1"]) if c["D"] == 512 else None
+    c["max_depth"] = int(rs.integers(3, 11))
+    c["rho"] = float(rs.choice([0.5, 0.9]))
+    c["spd"] = bool(rs.integers(2))
+    c["n"] = (int(rs.integers(1, 4)), int(rs.integers(1, 4)))   # adapting iterations, draws
+    c["seed"] = int(rs.integers(1, 1 << 30))
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(max(12, N_CASES // 8)))
+def test_random_dense_epoch(hip, monkeypatch, i):
+    """the chain-complete dense kernels (`k_dense_epoch`, `k_dense_epoch2<T, NW, NCT, WPE, CRIT>`) against the step-synchronous kernels on the
+    HIP engine at random shapes: D (4 … 16 waves per workgroup), a chain count that leaves the last workgroup ragged, epochs cut by random chunk
+    lengths, sampler × criterion × TemperedLeapfrog, the column-tile shape, max_depth, the target's correlation, identity / full M⁻¹ — Float64: the same
+    n_steps on every chain in every transition and the same draws to 1e-9, free-running; Float32 (they add r·v, θ·g, ρ·v in another order): one
+    iteration at a time from the same state, ≥ 99 % of the chains with the same n_steps per transition and those within 2e-3"""
+    import torch
+
+    c = draw_dense(i)
+    rs = np.random.default_rng(c["seed"])
+    D, N, dtype = c["D"], c["N"], c["dtype"]
+    what = "dense case " + " ".join(f"{k}={getattr(v, '__name__', v)}" for k, v in c.items() if k != "seed")
+    idx = np.arange(D)
+    P = np.asfortranarray(np.linalg.inv(c["rho"] ** np.abs(idx[:, None] - idx[None, :])))
+    if c["spd"]:
+        Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+        Minv = (Q * np.linspace(0.6, 2.0, D)) @ Q.T
+        Minv = np.asfortranarray((Minv + Minv.T) / 2)
+    else:
+        Minv = np.eye(D, order="F")
+    th0 = np.asfortranarray(rs.normal(size=(D, N)))
+    eps0 = (0.12 if c["rho"] > 0.7 else 0.3) * (0.7 + 0.6 * rs.random(N))
+    TS = {"multinomial": A.MultinomialTS, "slice": A.SliceTS}[c["TS"]]
+    TC = {"generalised": A.GeneralisedNoUTurn, "classic": A.ClassicNoUTurn, "strict": A.StrictGeneralisedNoUTurn}[c["TC"]]
+    n_adapts, n_draws = c["n"]
+
+    def env(engine):
+        monkeypatch.setenv("AHMC_DENSE_EPOCH", "1" if engine == "epoch" else "0")
+        monkeypatch.setenv("AHMC_DENSE_EPOCH_MIN", "32")
+        for var, val in (("AHMC_DENSE_CHUNK", c["chunk"]), ("AHMC_DENSE_EPOCH_NCT", c["nct"]), ("AHMC_DENSE_EPOCH_V", "2" if c["nct"] else None)):
+            if val:
+                monkeypatch.setenv(var, str(val))
+            else:
+                monkeypatch.delenv(var, raising=False)
+
+    def make(engine):
+        env(engine)
+        lf = A.TemperedLeapfrog(eps0, float(c["temper"])) if c["temper"] else A.Leapfrog(eps0)
+        k = A.HMCKernel(A.Trajectory(TS, lf, TC(max_depth=c["max_depth"], delta_max=1000.0)))
+        g = A.Engine(A.Hamiltonian(A.DenseEuclideanMetric(Minv), A.DenseGaussian(P)), N, dtype=dtype, rng=A.PhiloxRNG(c["seed"] & 0xFFFF), lib=hip)
+        g.set_integrator(lf)
+        g.set_position(th0)
+        g.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+        return g, k
+
+    if dtype == np.float64:
+        # free-running: the whole loop in one call on either engine
+        out = {}
+        for engine in ("step", "epoch"):
+            g, k = make(engine)
+            try:
+                draws = torch.empty((n_draws, N, D), dtype=torch.float64, device="cuda")
+                g.run(k, n_adapts + n_draws, n_adapts, drop_warmup=True, samples_out=draws.data_ptr())
+                g.sync()
+                st, acc = g.stats(), g.accum()
+                out[engine] = (draws.cpu().numpy(), st["n_steps"].copy(), acc["total_n_steps"], g.get_stepsize().copy(), g.theta().copy(), g.info("dense_epoch_launches"))
+            finally:
+                g.close()
+        a, b = out["step"], out["epoch"]
+        assert a[5] == 0, what
+        if b[5] == 0:
+            pytest.skip("no chain-complete kernel for this shape (the engine keeps the step-synchronous kernels): " + what)
+        np.testing.assert_array_equal(a[1], b[1], err_msg=what)
+        assert a[2] == b[2], what
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-9, err_msg=what)
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-9, atol=1e-9, err_msg=what)
+        np.testing.assert_allclose(a[4], b[4], rtol=1e-9, atol=1e-9, err_msg=what)
+        return
+    # Float32: ONE iteration at a time from the step engine's state (free-running, single-precision dual averaging between trees of up to 1 023
+    # single-precision leapfrogs drifts apart without any decision being wrong): per transition at most 1 chain in 100 may take another number
+    # of leapfrogs (a tie in single precision), every other chain ends within 2e-3 and adapts to the same step size
+    (gs, k), (ge, _) = make("step"), make("epoch")
+    try:
+        for it in range(1, n_adapts + n_draws + 1):
+            ge.set_state(gs.get_state())
+            env("step")
+            gs.run(k, it, n_adapts, i_first=it)
+            env("epoch")
+            ge.run(k, it, n_adapts, i_first=it)
+            ns, ne = gs.stats()["n_steps"], ge.stats()["n_steps"]
+            same = ns == ne
+            assert same.mean() >= 0.99 or (~same).sum() <= 2, (what, it, same.mean())
+            np.testing.assert_allclose(ge.theta()[:, same], gs.theta()[:, same], rtol=2e-3, atol=2e-3, err_msg=f"{what} iteration {it}")
+            np.testing.assert_allclose(ge.get_stepsize()[same], gs.get_stepsize()[same], rtol=1e-4, err_msg=f"{what} iteration {it}")
+        assert gs.info("dense_epoch_launches") == 0, what
+        if ge.info("dense_epoch_launches") == 0:
+            pytest.skip("no chain-complete kernel for this shape (the engine keeps the step-synchronous kernels): " + what)
+    finally:
+        gs.close()
+        ge.close()
+
+
 def test_the_draw_covers_the_space():
     """(no GPU work) the generator reaches every value of every axis, and the rare products this file exists for"""
     cases = [draw_case(i) for i in range(96)]
