@@ -426,6 +426,62 @@ def test_random_dense_epoch(hip, monkeypatch, i):
         ge.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(max(12, N_CASES // 8)))
+def test_random_reference_batch_exit(hip, oracle, i):
+    """`ahmc_set_ref_compat` (the reference's matrix-mode early exit, src/integrator.jl:252-258 over all columns) at random
+    sizes, metrics, step counts and directions, with one to three chains that blow up after a random number of steps: `step(lf, h, z, n)` and
+    static EndPointTS transitions on the HIP engine against the oracle's literal form — on and off"""
+    rs = np.random.default_rng(70_000 + i)
+    D, N = int(rs.choice([1, 3, 16, 65, 200, 600])), int(rs.choice([2, 5, 64, 130, 257]))
+    metric = str(rs.choice(["unit", "diag_chain", "diag_shared"]))
+    compat = bool(rs.integers(4))            # three in four with the coupling on
+    n = int(rs.integers(2, 12)) * (1 if rs.integers(2) else -1)
+    bad = rs.choice(N, size=min(N - 1, int(rs.integers(1, 4))), replace=False)
+    what = f"batch exit case {i}: D={D} N={N} metric={metric} compat={compat} n={n} bad={bad.tolist()}"
+    rng = np.random.default_rng(int(rs.integers(1 << 30)))
+    if metric == "unit":
+        m = A.UnitEuclideanMetric((D, N))
+    elif metric == "diag_shared":
+        m = A.DiagEuclideanMetric(0.5 + rng.random(D))
+    else:
+        m = A.DiagEuclideanMetric(np.asfortranarray(0.5 + rng.random((D, N))))
+    h = A.Hamiltonian(m, A.IsoGaussian(D))
+    eps = 0.05 + 0.2 * rng.random(N)
+    # a chain with ϵ = 1e80 … 1e160 leaves the finite numbers after one to three steps (θ ≈ ϵ·r, then ϵ²·…, the energy overflows)
+    eps[bad] = 10.0 ** rng.choice([80, 110, 160], size=bad.size)
+    th, r = rng.normal(size=(D, N)), rng.normal(size=(D, N))
+    ok = np.ones(N, dtype=bool)
+    ok[bad] = False
+    engines = []
+    try:
+        for lib in (hip, oracle):
+            engines.append(A.Engine(h, N, dtype=np.float64, rng=4 + i, lib=lib))
+        g, o = engines
+        for e in (g, o):
+            e.set_integrator(A.Leapfrog(eps))
+            e.set_ref_compat(compat)
+            e.set_position(th, r)
+            e.step(n)
+        zg, zo = g.phasepoint(), o.phasepoint()
+        np.testing.assert_allclose(zg.theta[:, ok], zo.theta[:, ok], rtol=1e-9, atol=1e-9, err_msg=what)
+        np.testing.assert_allclose(zg.r[:, ok], zo.r[:, ok], rtol=1e-9, atol=1e-9, err_msg=what)
+        np.testing.assert_array_equal(np.isfinite(zg.lp.value), np.isfinite(zo.lp.value), err_msg=what)
+        np.testing.assert_array_equal(np.isfinite(zg.lk.value), np.isfinite(zo.lk.value), err_msg=what)
+        kern = A.HMCKernel(A.Trajectory(A.EndPointTS, A.Leapfrog(eps), A.FixedNSteps(abs(n))))
+        for e in (g, o):
+            e.set_position(th)
+        for _ in range(2):
+            for e in (g, o):
+                e.transition(kern)
+            same = compare_transition_stats(g.stats(), o.stats(), np.float64, o, what)
+            np.testing.assert_allclose(g.phasepoint().theta[:, same & ok], o.phasepoint().theta[:, same & ok], rtol=1e-9, atol=1e-9, err_msg=what)
+            realign(g, o, same)
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_the_draw_covers_the_space():
     """(no GPU work) the generator reaches every value of every axis, and the rare products this file exists for"""
     cases = [draw_case(i) for i in range(96)]
