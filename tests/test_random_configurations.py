@@ -482,6 +482,33 @@ def test_random_reference_batch_exit(hip, oracle, i):
             e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(2, N_CASES, 4))
+def test_random_find_good_stepsize(hip, oracle, i):
+    """find_good_stepsize per chain (src/trajectory.jl:768-837) on the random configurations' Hamiltonians and start points, from random initial
+    step sizes: the powers of two and the direction of the search follow from decisions alone — identical unless the oracle had a near-tie"""
+    c = draw_case(i)
+    rng = np.random.default_rng(c["seed"])
+    h, lf, kernel = build(c, rng)
+    th0 = (0.5 if i % 8 < 6 else 3.0) * rng.normal(size=(c["D"], c["N"]))
+    eps_init = float(10.0 ** rng.uniform(-3, 1))
+    res, engines = [], []
+    try:
+        for lib in (hip, oracle):
+            e = A.Engine(h, c["N"], dtype=c["dtype"], rng=c["seed"] & 0xFFFF, lib=lib)
+            engines.append(e)
+            e.set_position(th0)
+            if lib is oracle:
+                PU.reset_margin(e)
+            res.append(e.find_good_stepsize(eps_init))
+        PU.check_equal_or_near_tie(res[0], res[1], PU.decision_margin(engines[1]), c["dtype"], "find_good_stepsize " + describe(c) + f" from {eps_init:g}")
+        # the point survives the search
+        np.testing.assert_array_equal(engines[0].theta(), np.asarray(th0, dtype=c["dtype"]))
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_the_draw_covers_the_space():
     """(no GPU work) the generator reaches every value of every axis, and the rare products this file exists for"""
     cases = [draw_case(i) for i in range(96)]
