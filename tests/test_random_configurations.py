@@ -208,8 +208,10 @@ def draw_adaptation(i):
     c = {"i": i, "dtype": (np.float64, np.float64, np.float32)[rs.integers(3)]}
     c["D"] = D = int(rs.choice([1, 2, 5, 16, 33, 64, 100, 257, 700]))
     c["N"] = int(rs.choice([1, 2, 17, 64, 130]))
-    c["metric"] = str(rs.choice(["unit", "diag_chain", "diag_chain"] + (["dense"] if D <= 100 else [])))
-    kinds = ["stepsize", "stan", "naive", "massmatrix"] + (["nutpie", "pooled"] if c["metric"] == "diag_chain" else [])
+    c["metric"] = str(rs.choice(["unit", "diag_chain", "diag_chain", "diag_shared"] + (["dense"] if D <= 100 else [])))
+    kinds = ["stepsize", "stan", "naive", "massmatrix"] + (["nutpie"] if c["metric"] == "diag_chain" else [])
+    if c["metric"] == "diag_shared":
+        kinds = ["stepsize", "pooled"]
     c["kind"] = str(rs.choice(kinds))
     c["n_adapts"] = int(rs.integers(12, 220))
     c["buffers"] = (int(rs.integers(1, 90)), int(rs.integers(1, 60)), int(rs.integers(2, 40)))
@@ -229,7 +231,7 @@ def test_random_adaptation(hip, oracle, i):
     rng = np.random.default_rng(c["seed"])
     D, N, dtype, n_adapts = c["D"], c["N"], c["dtype"], c["n_adapts"]
     metric = {"unit": lambda: A.UnitEuclideanMetric((D, N)), "diag_chain": lambda: A.DiagEuclideanMetric((D, N)),
-              "dense": lambda: A.DenseEuclideanMetric((D,))}[c["metric"]]()
+              "diag_shared": lambda: A.DiagEuclideanMetric((D,)), "dense": lambda: A.DenseEuclideanMetric((D,))}[c["metric"]]()
     h = A.Hamiltonian(metric, A.IsoGaussian(D))
     lf = A.Leapfrog(np.full(N, 0.1)) if c["metric"] != "dense" else A.Leapfrog(0.1)
     ssa = A.StepSizeAdaptor(c["delta"], lf)
@@ -507,6 +509,53 @@ def test_random_find_good_stepsize(hip, oracle, i):
     finally:
         for e in engines:
             e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(3, N_CASES, 4))
+def test_random_fused_warmup_equals_stepwise(hip, i):
+    """the whole `sample` loop with an adaptor (adapt! inside the kernels, batched launches, windows, restarts, finalize!) in ONE call against
+    transition + adapt! per iteration on the HIP engine — random configuration, random adaptor (kind, estimator, Stan buffers), n_adapts 8 … 70,
+    a run that ends inside the warm-up or some draws after it: bit for bit"""
+    c = draw_case(i)
+    if refused(c) or c["metric"] == "dense" or (not c["nuts"] and c["static"] == "time" and c["N"] > 1):
+        pytest.skip("refused configuration / DenseEuclideanMetric adapts through WelfordCov on its own path (test_dense_covariance_adaptation) / "
+                    "per-chain adapted step sizes + FixedIntegrationTime (Q6)")
+    rng = np.random.default_rng(c["seed"] + 1)
+    h, lf, kernel = build(c, np.random.default_rng(c["seed"]))
+    kinds = ["stepsize", "stan", "naive", "massmatrix"] + (["nutpie"] if c["metric"] == "diag_chain" else [])
+    if c["metric"] == "diag_shared":
+        kinds = ["stepsize", "pooled"]     # (ONE shared M⁻¹: the pooled estimator adapts it, the per-chain ones have nothing to write to)
+    kind = str(rng.choice(kinds))
+    ssa = A.StepSizeAdaptor(float(rng.choice([0.65, 0.8, 0.9])), lf)
+    pc = {"nutpie": A.NutpieVar, "pooled": A.PooledVar}.get(kind, A.MassMatrixAdaptor)(h.metric)
+    buffers = (int(rng.integers(1, 30)), int(rng.integers(1, 20)), int(rng.integers(2, 15)))
+    ad = {"stepsize": ssa, "massmatrix": pc, "naive": A.NaiveHMCAdaptor(pc, ssa)}.get(kind, A.StanHMCAdaptor(pc, ssa, *buffers))
+    n_adapts = int(rng.integers(8, 70))
+    n = max(1, n_adapts + int(rng.integers(-5, 7)))
+    what = describe(c) + f" adaptor={kind} buffers={buffers} n_adapts={n_adapts} n={n}"
+    th0 = 0.5 * rng.normal(size=(c["D"], c["N"]))
+    a = A.Engine(h, c["N"], dtype=c["dtype"], rng=c["seed"] & 0xFFFF, lib=hip)
+    b = A.Engine(h, c["N"], dtype=c["dtype"], rng=c["seed"] & 0xFFFF, lib=hip)
+    try:
+        for e in (a, b):
+            e.set_integrator(lf)
+            e.set_position(th0)
+            e.refresh()
+            e.adaptor_init(ad)
+        a.run(kernel, n, n_adapts)
+        for it in range(1, n + 1):
+            b.run(kernel, it, n_adapts, i_first=it)
+        np.testing.assert_array_equal(a.theta(), b.theta(), err_msg=what)
+        np.testing.assert_array_equal(a.get_stepsize(), b.get_stepsize(), err_msg=what)
+        if c["metric"] != "unit":
+            np.testing.assert_array_equal(a.get_metric(), b.get_metric(), err_msg=what)
+        sa, sb = a.stats(), b.stats()
+        for f in ("n_steps", "acceptance_rate", "hamiltonian_energy", "tree_depth", "is_accept"):
+            np.testing.assert_array_equal(sa[f], sb[f], err_msg=what + " " + f)
+    finally:
+        a.close()
+        b.close()
 
 
 def test_the_draw_covers_the_space():
