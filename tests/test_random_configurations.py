@@ -558,6 +558,45 @@ def test_random_fused_warmup_equals_stepwise(hip, i):
         b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,N,target,dtype", [(3, 100003, "funnel", np.float64), (32, 65537, "funnel", np.float64), (128, 4097, "iso", np.float64),
+                                              (16, 70001, "hier", np.float32), (1, 131071, "iso", np.float64), (200, 1031, "diag", np.float32)])
+def test_awkward_chain_counts_fused_equals_stepwise(hip, D, N, target, dtype):
+    """chain counts that are multiples of nothing (a ragged last wave, a ragged last workgroup, more chains than one 16-bit dispatch-order key
+    distinguishes, 2¹⁷ − 1 chains of one dimension): the whole loop — Stan warm-up inside the kernels, work-sorted launches of several transitions,
+    the prefetched normals, the log-domain redo pass of the funnel's overflowing chains — in ONE call against one iteration per call, bit for bit"""
+    rng = np.random.default_rng(D * 1000 + N)
+    metric = A.DiagEuclideanMetric((D, N))
+    h = A.Hamiltonian(metric, make_target(target, D, rng))
+    lf = A.Leapfrog(np.full(N, 0.2))
+    kernel = A.HMCKernel(A.Trajectory(A.MultinomialTS, lf, A.GeneralisedNoUTurn(max_depth=6)))
+    ad = A.StanHMCAdaptor(A.MassMatrixAdaptor(metric), A.StepSizeAdaptor(0.8, lf), 4, 3, 5)
+    th0 = rng.normal(size=(D, N))
+    n_adapts, n = 22, 34
+    a = A.Engine(h, N, dtype=dtype, rng=5, lib=hip)
+    b = A.Engine(h, N, dtype=dtype, rng=5, lib=hip)
+    try:
+        for e in (a, b):
+            e.set_integrator(lf)
+            e.set_position(th0)
+            e.adaptor_init(ad)
+        a.run(kernel, n, n_adapts)
+        for it in range(1, n + 1):
+            b.run(kernel, it, n_adapts, i_first=it)
+        np.testing.assert_array_equal(a.theta(), b.theta())
+        np.testing.assert_array_equal(a.get_stepsize(), b.get_stepsize())
+        np.testing.assert_array_equal(a.get_metric(), b.get_metric())
+        sa, sb = a.stats(), b.stats()
+        for f in ("n_steps", "acceptance_rate", "hamiltonian_energy", "tree_depth", "numerical_error"):
+            np.testing.assert_array_equal(sa[f], sb[f], err_msg=f)
+        assert sa["n_steps"].max() > 7 and np.isfinite(a.theta()).all()
+        if target == "funnel":
+            assert a.info("nuts_launches") + a.info("nuts_warm_launches") > 0
+    finally:
+        a.close()
+        b.close()
+
+
 def test_the_draw_covers_the_space():
     """(no GPU work) the generator reaches every value of every axis, and the rare products this file exists for"""
     cases = [draw_case(i) for i in range(96)]
