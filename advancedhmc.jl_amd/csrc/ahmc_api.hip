@@ -619,7 +619,8 @@ int nuts_transition(Ctx<T>* c, int max_depth, double delta_max, int criterion, i
     return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
   if (criterion != AHMC_TC_CLASSIC && criterion != AHMC_TC_GENERALISED && criterion != AHMC_TC_STRICT)
     return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
-  if (max_depth < 1 || max_depth > 24) return fail(c, AHMC_ERR_ARGUMENT, "max_depth must be in 1..24");
+  if (max_depth < 1) return fail(c, AHMC_ERR_ARGUMENT, "max_depth must be >= 1");
+  if (max_depth > 24) return fail(c, AHMC_ERR_UNSUPPORTED, "nuts_transition: the fused kernels support max_depth <= 24 (16.7 M leapfrogs per transition)");
   KP<T> p = make_kp(c);
   p.max_depth = max_depth;
   p.delta_max = (T)delta_max;

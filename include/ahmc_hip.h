@@ -225,7 +225,10 @@ void* ahmc_theta_ptr(ahmc_ctx* ctx);
 int32_t ahmc_hmc_transition(ahmc_ctx* ctx, int64_t L, double lambda, int32_t sampler);
 
 /* NUTS: transition(rng, h, HMCKernel(Trajectory{TS}(lf, TC(max_depth, Δ_max))), z) per chain
- * (src/trajectory.jl:677-742, build_tree :626-675), run for all N chains at once.            */
+ * (src/trajectory.jl:677-742, build_tree :626-675), run for all N chains at once.
+ * Domain: max_depth >= 1 (AHMC_ERR_ARGUMENT below; the reference takes any Int and would hand back the start point with 0/0
+ * statistics).  An engine limit, not the reference's: max_depth <= 24 on the fused kernels, <= 17 on the dense / external-target
+ * engine — AHMC_ERR_UNSUPPORTED beyond (the reference's default is 10).                        */
 int32_t ahmc_nuts_transition(ahmc_ctx* ctx, int32_t max_depth, double delta_max,
                              int32_t criterion, int32_t sampler);
 

@@ -1150,6 +1150,7 @@ void accumulate(Ctx<T>* c) {
 
 template <class T>
 int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, T refresh_alpha) {
+  if (int rcb = check_builtin(c, "hmc_transition")) return rcb;
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
   if (sampler != AHMC_TS_ENDPOINT && sampler != AHMC_TS_MULTINOMIAL)
     return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
@@ -1188,13 +1189,25 @@ int hmc_transition(Ctx<T>* c, int64_t L, double lambda, int sampler, T refresh_a
   return AHMC_OK;
 }
 
+// (as the HIP engine's check_builtin: with AHMC_TARGET_EXTERNAL the caller evaluates the log-density — the calls that would evaluate it
+// themselves are refused; whole transitions go through ahmc_ext_*, single leapfrogs through ahmc_lf_pre / ahmc_lf_post)
+template <class T>
+int check_builtin(Ctx<T>* c, const char* what) {
+  if (c->target.kind == AHMC_TARGET_EXTERNAL)
+    return fail(c, AHMC_ERR_STATE, std::string(what) + " needs a built-in target; with AHMC_TARGET_EXTERNAL the caller evaluates the log-density");
+  return AHMC_OK;
+}
+
 template <class T>
 int nuts_transition_all(Ctx<T>* c, int max_depth, double delta_max, int criterion, int sampler, T refresh_alpha) {
+  if (int rcb = check_builtin(c, "nuts_transition")) return rcb;
   if (!c->have_point) return fail(c, AHMC_ERR_STATE, "transition before set_position");
   if (sampler != AHMC_TS_MULTINOMIAL && sampler != AHMC_TS_SLICE)
     return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
   if (criterion < AHMC_TC_CLASSIC || criterion > AHMC_TC_STRICT)
     return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
+  // (the boundary's domain, include/ahmc_hip.h: the reference takes any Int — max_depth <= 0 would return the start point with 0/0 statistics)
+  if (max_depth < 1) return fail(c, AHMC_ERR_ARGUMENT, "max_depth must be >= 1");
   apply_jitter(c);
   NutsCfg<T> cfg;
   cfg.sampler = sampler;
@@ -1887,6 +1900,7 @@ int32_t ahmc_get_phasepoint(ahmc_ctx* ctx, void* theta, void* r, void* lp, void*
 
 int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
   FOR_CTX_MUT(ctx, {
+    if (int rcb = check_builtin(c, "refresh_momentum")) return rcb;
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "refresh before set_position");
     for (int64_t i = 0; i < c->N; ++i) c->store(i, refresh(c, i, c->load(i), (T)alpha));
     return AHMC_OK;
@@ -1895,6 +1909,7 @@ int32_t ahmc_refresh_momentum(ahmc_ctx* ctx, double alpha) {
 
 int32_t ahmc_leapfrog(ahmc_ctx* ctx, int64_t n_steps) {
   FOR_CTX_MUT(ctx, {
+    if (int rcb = check_builtin(c, "leapfrog")) return rcb;
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "leapfrog before set_position");
     c->eps_cur = c->eps_nom;
     bool fwd = n_steps > 0;
@@ -1978,14 +1993,18 @@ int32_t ahmc_ext_begin(ahmc_ctx* ctx, const ahmc_kernel_cfg* cfg, int32_t n_tran
     if (c->target.kind != AHMC_TARGET_EXTERNAL) return fail(c, AHMC_ERR_STATE, "ext_begin: the target is not AHMC_TARGET_EXTERNAL");
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "ext_begin before set_phasepoint");
     if (c->ext.mode != 0) return fail(c, AHMC_ERR_STATE, "ext_begin: a run is already in progress");
+    if (cfg->refresh_alpha < 0 || cfg->refresh_alpha >= 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: PartialMomentumRefreshment needs 0 <= α < 1");
     if (cfg->nuts) {
       if (cfg->sampler != AHMC_TS_MULTINOMIAL && cfg->sampler != AHMC_TS_SLICE) return fail(c, AHMC_ERR_ARGUMENT, "NUTS supports MultinomialTS and SliceTS");
       if (cfg->criterion < AHMC_TC_CLASSIC || cfg->criterion > AHMC_TC_STRICT) return fail(c, AHMC_ERR_ARGUMENT, "unknown termination criterion");
+      if (cfg->max_depth < 1) return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: max_depth must be >= 1");
     } else {
       if (cfg->sampler != AHMC_TS_ENDPOINT && cfg->sampler != AHMC_TS_MULTINOMIAL)
         return fail(c, AHMC_ERR_ARGUMENT, "static HMC supports EndPointTS and MultinomialTS");
       if (cfg->lambda > 0 && !c->eps_scalar && c->N != 1)
         return fail(c, AHMC_ERR_ARGUMENT, "FixedIntegrationTime needs a scalar step size (src/trajectory.jl:241-243)");
+      if (!(cfg->lambda > 0) && cfg->L == 0)   // (a run of no evaluations has nothing to ask the caller: the boundary's domain, as the HIP engine's)
+        return fail(c, AHMC_ERR_ARGUMENT, "ext_begin: static HMC needs at least one leapfrog step");
     }
     c->ext.cfg = *cfg;
     c->ext.n_trans = n_trans;
@@ -2091,6 +2110,7 @@ int32_t ahmc_get_stat(ahmc_ctx* ctx, int32_t field, void* out) {
 
 int32_t ahmc_find_good_stepsize(ahmc_ctx* ctx, double initial_step_size, int32_t max_n_iters) {
   FOR_CTX_MUT(ctx, {
+    if (int rcb = check_builtin(c, "find_good_stepsize")) return rcb;
     if (!c->have_point) return fail(c, AHMC_ERR_STATE, "find_good_stepsize before set_position");
     std::vector<T> out = find_good_stepsize_all(c, (T)initial_step_size, max_n_iters);
     c->eps_nom = out;
