@@ -416,9 +416,17 @@ template <class T>
 __global__ __launch_bounds__(256) void k_ess(const T* __restrict__ draws, int64_t DN, int64_t K, T* __restrict__ out) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= DN) return;
-  double mean = 0;
-  for (int64_t k = 0; k < K; ++k) mean += (double)draws[k * DN + s];
+  double mean = 0, lo = (double)draws[s], hi = lo;
+  for (int64_t k = 0; k < K; ++k) {
+    const double x = (double)draws[k * DN + s];
+    mean += x;
+    lo = x < lo ? x : lo;
+    hi = x > hi ? x : hi;
+  }
   mean /= (double)K;
+  // a series that never moved has no autocorrelation to estimate: K.  (Decided on the values, not on γ₀ > 0: Σx / K of K identical
+  // values can be an ulp off x, and the "variance" of 1e-32 that leaves gave such a series an ESS of ≈ 1 or K by rounding luck.)
+  if (!(hi > lo)) { out[s] = (T)K; return; }
   auto gamma = [&](int64_t t) {
     double g = 0;
     for (int64_t k = 0; k + t < K; ++k) g += ((double)draws[k * DN + s] - mean) * ((double)draws[(k + t) * DN + s] - mean);

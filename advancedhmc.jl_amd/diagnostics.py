@@ -39,7 +39,9 @@ def ess(draws, axis=0):
     P = np.minimum.accumulate(P, axis=0)                   # initial monotone sequence
     tau = -1.0 + 2.0 * P.sum(axis=0)
     tau = np.maximum(tau, 1.0 / n)
-    return n / tau
+    # a series that never moved (every transition rejected) has no autocorrelation to estimate: n_draws, as k_ess and the CPU checker
+    # (round 6: this function returned n² there — found by tests/test_random_configurations.py::test_random_diagnostics)
+    return np.where(x.max(axis=0) == x.min(axis=0), float(n), n / tau)
 
 
 def EBFMI(energies, axis=0):

@@ -2411,9 +2411,15 @@ int32_t ahmc_ess(ahmc_ctx* ctx, const void* draws_v, int64_t K, void* out_v) {
     const int64_t DN = c->D * c->N;
     _Pragma("omp parallel for schedule(static)")
     for (int64_t s2 = 0; s2 < DN; ++s2) {
-      double mean = 0;
-      for (int64_t k = 0; k < K; ++k) mean += (double)draws[k * DN + s2];
+      double mean = 0, lo = (double)draws[s2], hi = lo;
+      for (int64_t k = 0; k < K; ++k) {
+        const double x = (double)draws[k * DN + s2];
+        mean += x;
+        lo = x < lo ? x : lo;
+        hi = x > hi ? x : hi;
+      }
       mean /= (double)K;
+      if (!(hi > lo)) { out[s2] = (T)K; continue; }   // a series that never moved: K (decided on the values, not on a γ₀ of rounding noise)
       auto gamma = [&](int64_t t) {
         double g = 0;
         for (int64_t k = 0; k + t < K; ++k) g += ((double)draws[k * DN + s2] - mean) * ((double)draws[(k + t) * DN + s2] - mean);

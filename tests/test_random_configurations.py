@@ -597,6 +597,66 @@ def test_awkward_chain_counts_fused_equals_stepwise(hip, D, N, target, dtype):
         b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(max(12, N_CASES // 8)))
+def test_random_diagnostics(hip, i):
+    """output side at random sizes: the device-side running sums and reductions of a bulk run — moments, Σ n_steps,
+    divergences, EBFMI (src/diagnosis.jl:1-3), ESS — against numpy on what the SAME chains produce one iteration per call (bulk == stepwise bit for
+    bit, so every chain counts: no "most chains" threshold)"""
+    import torch
+
+    c = draw_case(7 * i + 3)
+    if refused(c) or c["D"] > 300:
+        pytest.skip("refused configuration / kept small: K draws of (D, N) travel to the host")
+    rng = np.random.default_rng(c["seed"])
+    h, lf, kernel = build(c, rng)
+    D, N, dtype = c["D"], c["N"], c["dtype"]
+    th0 = 0.5 * rng.normal(size=(D, N))
+    K = int(rng.integers(8, 40))
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+
+    def fresh():
+        e = A.Engine(h, N, dtype=dtype, rng=c["seed"] & 0xFFFF, lib=hip)
+        e.set_integrator(lf)
+        e.set_position(th0)
+        e.refresh()
+        return e
+
+    a, b = fresh(), fresh()
+    try:
+        draws_d = torch.empty((K, N, D), dtype=tdt, device="cuda")
+        a.run(kernel, K, 0, samples_out=draws_d.data_ptr())
+        a.sync()
+        draws = draws_d.cpu().numpy().astype(np.float64)
+        E, TH, steps, ndiv = [], [], 0, 0
+        for it in range(1, K + 1):
+            b.run(kernel, it, 0, i_first=it)
+            st = b.stats()
+            E.append(st["hamiltonian_energy"].astype(np.float64))
+            TH.append(b.theta().T.astype(np.float64))
+            steps += int(st["n_steps"].sum())
+            ndiv += int(st["numerical_error"].sum())
+        what = describe(c) + f" K={K}"
+        np.testing.assert_array_equal(draws, np.array(TH), err_msg=what)
+        acc, g = a.accum(), a.gather_moments()
+        assert acc["total_n_steps"] == steps and acc["n_divergent"] == ndiv and acc["n_transitions"] == K, what
+        tol = 1e-9 if dtype == np.float64 else 2e-4
+        mean = draws.mean(axis=(0, 1))
+        np.testing.assert_allclose(g["mean"], mean, rtol=tol, atol=tol, err_msg=what)
+        np.testing.assert_allclose(g["var"], (draws ** 2).mean(axis=(0, 1)) - mean ** 2, rtol=tol * 100, atol=tol * 100 * max(1.0, float((draws ** 2).mean())), err_msg=what)
+        assert g["n_draws"] == K * N and g["total_n_steps"] == steps
+        E = np.array(E)
+        ok = np.var(E, axis=0, ddof=1) > 1e-12 * np.maximum(1.0, np.abs(E).max(axis=0)) ** 2     # (a chain whose energy never moved: 0/0)
+        np.testing.assert_allclose(a.ebfmi()[ok], A.EBFMI(E)[ok], rtol=1e-6 if dtype == np.float64 else 5e-2, err_msg=what)
+        got = a.ess(draws_d.data_ptr(), K)
+        want = A.diagnostics.ess(draws_d.cpu().numpy(), axis=0).T
+        fin = np.isfinite(want)
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-6 if dtype == np.float64 else 2e-2, err_msg=what)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_the_draw_covers_the_space():
     """(no GPU work) the generator reaches every value of every axis, and the rare products this file exists for"""
     cases = [draw_case(i) for i in range(96)]
