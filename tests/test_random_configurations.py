@@ -657,6 +657,58 @@ def test_random_diagnostics(hip, i):
         b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(1, N_CASES, 4))
+def test_random_sharding_invariance(hip, i):
+    """multi-GPU by construction: a chain's stream depends on its GLOBAL index alone — the random configurations run as ONE engine of N
+    chains and as two or three engines over contiguous blocks cut at random (`PhiloxRNG(seed, chain_offset=…)`, each with its slice of the step
+    sizes, the metric and the start points, each adapting on its own): warm-up + draws, bit for bit the same chains"""
+    c = draw_case(i)
+    if refused(c) or c["N"] < 3 or c["metric"] == "dense" or (not c["nuts"] and c["static"] == "time"):
+        pytest.skip("refused configuration / fewer than three chains / one shared dense M⁻¹ adapts from ALL chains (pooled: test_v3_state_gather) / Q6")
+    rng = np.random.default_rng(c["seed"])
+    D, N, dtype = c["D"], c["N"], c["dtype"]
+    h, lf, kernel = build(c, rng)
+    th0 = 0.5 * rng.normal(size=(D, N))
+    cuts = sorted(set(int(x) for x in rng.integers(1, N, size=int(rng.integers(1, 3)))))
+    blocks = list(zip([0] + cuts, cuts + [N]))
+    seed = c["seed"] & 0xFFFF
+    n_adapts, n = 6, 10
+    adapt = c["metric"] != "diag_shared"     # (a shared (D,) M⁻¹ is adapted from all chains of an engine: per block it would differ)
+
+    def sub(a, lo, hi):
+        a = np.asarray(a)
+        return a if a.ndim == 0 or a.shape[-1] != N else a[..., lo:hi]
+
+    def engine(lo, hi):
+        m = h.metric
+        if isinstance(m, A.DiagEuclideanMetric) and np.ndim(m.Minv) == 2:
+            m = A.DiagEuclideanMetric(np.asfortranarray(m.Minv[:, lo:hi]))
+        elif isinstance(m, A.UnitEuclideanMetric):
+            m = A.UnitEuclideanMetric((D, hi - lo))
+        hh = A.Hamiltonian(m, h.target)
+        l2 = type(lf)(sub(lf.eps, lo, hi)) if isinstance(lf, A.Leapfrog) else type(lf)(sub(lf.eps, lo, hi), lf.param)
+        k2 = A.HMCKernel(kernel.refreshment, A.Trajectory(kernel.tau.TS, l2, kernel.tau.termination_criterion))
+        e = A.Engine(hh, hi - lo, dtype=dtype, rng=A.PhiloxRNG(seed, chain_offset=lo), lib=hip)
+        e.set_integrator(l2)
+        e.set_position(th0[:, lo:hi])
+        e.refresh()
+        if adapt:
+            e.adaptor_init(A.StanHMCAdaptor(A.MassMatrixAdaptor(m), A.StepSizeAdaptor(0.8, l2), 2, 1, 2) if c["metric"] == "diag_chain" else A.StepSizeAdaptor(0.8, l2))
+        e.run(k2, n, n_adapts if adapt else 0)
+        out = (e.theta().copy(), e.get_stepsize().copy(), e.stats()["n_steps"].copy())
+        e.close()
+        return out
+
+    whole = engine(0, N)
+    for lo, hi in blocks:
+        part = engine(lo, hi)
+        what = describe(c) + f" block {lo}:{hi} of {blocks}"
+        np.testing.assert_array_equal(part[0], whole[0][:, lo:hi], err_msg=what)
+        np.testing.assert_array_equal(part[1], whole[1][lo:hi], err_msg=what)
+        np.testing.assert_array_equal(part[2], whole[2][lo:hi], err_msg=what)
+
+
 def test_the_draw_covers_the_space():
     """(no GPU work) the generator reaches every value of every axis, and the rare products this file exists for"""
     cases = [draw_case(i) for i in range(96)]
