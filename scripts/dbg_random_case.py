@@ -1,9 +1,13 @@
+#!/usr/bin/env python
+"""Replay one case of tests/test_random_configurations.py on the HIP engine and the oracle and print, per transition, the chains whose discrete
+statistics differ together with the oracle's decision margins:   gpurun -- 'python scripts/dbg_random_case.py 476'"""
 import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np
 import conftest, ahmc_amd as A, parity_util as PU
 import test_random_configurations as R
 o = A.CLib(conftest.build_oracle()); hip = A.load_hip_library()
-c = R.draw_case(476)
+c = R.draw_case(int(sys.argv[1]) if len(sys.argv) > 1 else 476)
+print(R.describe(c))
 rng = np.random.default_rng(c["seed"])
 h, lf, kernel = R.build(c, rng)
 th0 = 0.5 * rng.normal(size=(c["D"], c["N"]))
