@@ -5,7 +5,7 @@ Tolerances (north_star: "within a stated fp tolerance"):
            FMA contraction and libm-vs-ocml last-ulp differences in log/exp/sincos).
   Float32: 2e-3 relative on single leapfrog trajectories, plus moment checks.
   Discrete statistics (n_steps, tree_depth, is_accept, numerical_error), both types, since round 6: EXACT on every chain —
-           except a chain one of whose decisions the oracle itself took within 1e-9 (f64) / 1e-3 (f32) RELATIVE of a tie
+           except a chain one of whose decisions the oracle itself took within 1e-9 (f64) / 1e-4 (f32) RELATIVE of a tie
            (tests/parity_util.py: the oracle reports the margin of every U-turn, sampling, divergence and MH comparison).
            Rounds 1–5 accepted "≥ 99.9 % / 97 % / 90 % of the chains agree"; those thresholds are gone.
 """
