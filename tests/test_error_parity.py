@@ -190,5 +190,5 @@ def test_error_statuses_agree_between_the_hip_engine_and_the_oracle(hip, oracle,
         so.update(_run_ext_probes(oracle))
     diff = {k: (sg[k], so[k]) for k in sg if sg[k] != so[k] and not (k in ENGINE_LIMITS and (sg[k], so[k]) == (2, 0))}
     assert not diff, f"probe: (HIP engine, oracle) statuses differ: {diff}"
-    if with_point:
+    if with_point and hip.backend.startswith("hip"):     # (not in a dry run of this file on the oracle)
         assert all(sg[k] == 2 for k in ENGINE_LIMITS), {k: sg[k] for k in ENGINE_LIMITS}
