@@ -24,7 +24,7 @@ import ctypes as C
 import numpy as np
 
 # a chain may differ from the oracle only if one of its decisions had a relative margin below this.  (Measured on the MI355X,
-# profiles/r6_parity_margins.json: the suite's 248 209 Float64 chain-comparisons — every transition kind, geometry, target, the
+# profiles/r6_parity_margins.json: the suite's 254 596 Float64 chain-comparisons — every transition kind, geometry, target, the
 # dense engine, the full-size slices — produced NO decision flip at all, and neither did its 59 496 Float32 ones although 2 % of
 # those had a decision within 1e-4 of a tie: the Float32 bound is 1e-4, ten times tighter than the 1e-3 the review asked for.)
 MARGIN_BOUND = {np.dtype(np.float64): 1e-9, np.dtype(np.float32): 1e-4}

@@ -192,11 +192,26 @@ def compare_transition_stats(sg, so, dtype, o, what="transition", sel=None):
     read AND reset: one comparison per span of transitions); the continuous statistics to tolerance on the agreeing chains."""
     same = ((sg["n_steps"] == so["n_steps"]) & (sg["is_accept"] == so["is_accept"]) & (sg["tree_depth"] == so["tree_depth"])
             & (sg["numerical_error"] == so["numerical_error"]))
-    same = PU.check_flips(same, PU.decision_margin(o), dtype, what, sel=sel, n_steps=so["n_steps"])
+    margin = PU.decision_margin(o)
+    same = PU.check_flips(same, margin, dtype, what, sel=sel, n_steps=so["n_steps"])
     rt = RTOL[dtype] * 100
+    # The continuous statistics are held to the tolerance where they are well defined on both sides (found by the 10 000-configuration hunt of
+    # tests/test_random_configurations.py, `profiles/r6_experiments.md` r6w): (i) a near-tie in the CHOICE of the candidate leaves every discrete
+    # statistic alone and moves ℓπ, H and its error — chains with such a decision are left to the discrete check; (ii) ΔH_max is maxabs(a, b)
+    # (src/trajectory.jl:526): +x against −x of nearly the same size is a tie of its own — compared in magnitude; (iii) on a trajectory that left
+    # the stable region (|ΔH| beyond 20 on its way to Δ_max) the energies amplify rounding: a thousand times the tolerance there.
+    with np.errstate(invalid="ignore"):
+        wild = (np.abs(sg["max_hamiltonian_energy_error"]) > 20) | (np.abs(so["max_hamiltonian_energy_error"]) > 20)
+        wild |= ~np.isfinite(sg["max_hamiltonian_energy_error"]) | ~np.isfinite(so["max_hamiltonian_energy_error"])
+    clear = same & (margin >= PU.bound(dtype))
     for k in ("acceptance_rate", "log_density", "hamiltonian_energy", "hamiltonian_energy_error",
               "max_hamiltonian_energy_error", "step_size"):
-        np.testing.assert_allclose(sg[k][same], so[k][same], rtol=rt, atol=rt, err_msg=k)
+        a, b = (np.abs(sg[k]), np.abs(so[k])) if k == "max_hamiltonian_energy_error" else (sg[k], so[k])
+        calm = clear & ~wild
+        np.testing.assert_allclose(a[calm], b[calm], rtol=rt, atol=rt, err_msg=f"{what}: {k}")
+        rest = clear & wild & np.isfinite(a) & np.isfinite(b)
+        if dtype == np.float64:
+            np.testing.assert_allclose(a[rest], b[rest], rtol=rt * 1000, atol=rt * 1000, err_msg=f"{what}: {k} (unstable trajectories)")
     np.testing.assert_array_equal(sg["numerical_error"][same], so["numerical_error"][same])
     return same
 

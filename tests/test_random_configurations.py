@@ -161,8 +161,11 @@ def run_case(c, hip, oracle):
             e.close()
 
 
+FIRST = int(os.environ.get("AHMC_RANDOM_FIRST", "0"))    # (a hunt continues where the last one stopped)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("i", range(N_CASES))
+@pytest.mark.parametrize("i", range(FIRST, N_CASES))
 def test_random_configuration(hip, oracle, i):
     c = draw_case(i)
     if refused(c):
