@@ -663,7 +663,11 @@ class Engine:
             self._ext_drive()
             return
         if k.refresh_alpha != 0.0:
-            raise capi.UnsupportedError(capi.ERR_UNSUPPORTED, "PartialMomentumRefreshment runs through Engine.sample")
+            # HMCKernel(PartialMomentumRefreshment(α), τ) (src/trajectory.jl:249-254, src/hamiltonian.jl:243-254): the refreshment is part of
+            # the sample loop's kernel configuration at the boundary — ONE iteration of that loop is this transition (the iteration counter,
+            # and with it every variate, continues as for the two calls below; the running accumulators count the draw, as for any kept one)
+            self._call("ahmc_sample_from", C.byref(k), 1, 1, 0, 0, None)
+            return
         if k.nuts:
             self._call("ahmc_nuts_transition", k.max_depth, k.delta_max, k.criterion, k.sampler)
         else:

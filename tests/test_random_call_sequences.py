@@ -38,6 +38,12 @@ def sync_from_oracle(g, o):
 
 
 def make_kernel(rs, lf, D, nuts):
+    k = _make_kernel(rs, lf, D, nuts)
+    alpha = float(rs.choice([0.0, 0.0, 0.3, 0.9]))
+    return A.HMCKernel(A.PartialMomentumRefreshment(alpha), k.tau) if alpha else k
+
+
+def _make_kernel(rs, lf, D, nuts):
     if nuts:
         TS = (A.MultinomialTS, A.SliceTS)[rs.integers(2)]
         TC = (A.GeneralisedNoUTurn, A.GeneralisedNoUTurn, A.ClassicNoUTurn, A.StrictGeneralisedNoUTurn)[rs.integers(4)]

@@ -95,10 +95,10 @@ def refused(c):
 def advance(e, kernel):
     """one transition: Engine.transition, or — PartialMomentumRefreshment lives in the sample loop's kernel configuration — a
     one-iteration sample call (src/sampler.jl:159-248 with n_samples = 1)"""
-    if kernel.refreshment.alpha:
+    if kernel.refreshment.alpha and getattr(e, "_advance_by_run", False):
         e.run(kernel, 1, 0)
     else:
-        e.transition(kernel)
+        e.transition(kernel)      # (Engine.transition hands a partial refreshment to one iteration of the sample loop itself)
 
 
 def run_case(c, hip, oracle):
