@@ -267,6 +267,39 @@ function AdvancedHMC.transition(
     return Transition(z, tstat)
 end
 
+# HMCKernel(PartialMomentumRefreshment(α), τ) (src/trajectory.jl:249-254, src/hamiltonian.jl:243-254), static or dynamic: at the boundary the
+# refreshment is part of the sample loop's kernel configuration (`refresh_alpha` of ahmc_kernel_cfg), so ONE iteration of that loop is this
+# transition — the iteration counter, and with it every variate, continues as for the two methods above (as `Engine.transition` of the
+# Python mirror; HIP == CPU checker on it: tests/test_random_configurations.py, tests/test_random_call_sequences.py)
+function AdvancedHMC.transition(
+    ::Union{AbstractRNG,AbstractVector{<:AbstractRNG}}, h::Hamiltonian,
+    κ::HMCKernel{<:PartialMomentumRefreshment,<:Trajectory{TS,I,TC}}, z::MI355XChains{T},
+) where {TS,I,TC,T}
+    if z.user_density
+        transition_user_density(h, κ, z)
+    else
+        set_integrator!(z, κ.τ.integrator)
+        cfg = Ref(kernel_cfg(κ))
+        check(z.ctx, ccall((:ahmc_sample_from, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{T}),
+                           z.ctx, cfg, 1, 1, 0, false, C_NULL))
+    end
+    dynamic = TC <: AdvancedHMC.DynamicTerminationCriterion
+    tstat = (
+        n_steps=getstat(z, 0, Int32),
+        is_accept=dynamic ? trues(z.N) : getstat(z, 1, Int32) .!= 0,
+        acceptance_rate=getstat(z, 2, T),
+        log_density=getstat(z, 3, T),
+        hamiltonian_energy=getstat(z, 4, T),
+        hamiltonian_energy_error=getstat(z, 5, T),
+        max_hamiltonian_energy_error=getstat(z, 6, T),
+        tree_depth=getstat(z, 7, Int32),
+        numerical_error=getstat(z, 8, Int32) .!= 0,
+        step_size=getstat(z, 9, T),
+        nom_step_size=getstat(z, 10, T),
+    )
+    return Transition(z, tstat)
+end
+
 # --- adapt!(h, κ, adaptor, i, n_adapts, z, α) (src/sampler.jl:72-90) ---------------------------------
 adaptor_code(::NoAdaptation) = ADAPT_NONE
 adaptor_code(::StepSizeAdaptor) = ADAPT_STEPSIZE
