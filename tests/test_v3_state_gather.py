@@ -158,6 +158,19 @@ def test_ebfmi_moments_and_ess_on_the_oracle(oracle, rng):
         x[t] = phi * x[t - 1] + z[t]
     ratio = e.ess(x, K2).mean() / K2
     assert abs(ratio - (1 - phi) / (1 + phi)) < 0.03, ratio
+    # a series that never moved (every transition rejected) has no autocorrelation to estimate: K — whatever the rounding of its own mean
+    # does (Σx / K of K identical values can be an ulp off x; round 6: the estimators decided on γ₀ > 0 and answered ≈ 1, K or K² there)
+    K3 = 23
+    c = np.empty((K3, N, D))
+    vals = np.random.default_rng(2).normal(size=(N, D)) * np.array([1e-3, 1.0, 0.1, 1e6, 1 / 3, 7.7])[np.arange(D) % 6]
+    c[:] = vals
+    c[:, 0, 0] = np.arange(K3)                        # one series that does move
+    got, want = e.ess(c, K3), A.diagnostics.ess(c, axis=0).T
+    still = np.ones((D, N), dtype=bool)
+    still[0, 0] = False
+    assert (got[still] == K3).all() and (want[still] == K3).all()
+    np.testing.assert_allclose(got[0, 0], want[0, 0], rtol=1e-8)
+    assert got[0, 0] < K3 / 4                          # a ramp is as autocorrelated as a series gets
     e.close()
 
 
