@@ -296,3 +296,44 @@ def test_info_ids_agree_between_header_python_mirror_and_oracle(oracle):
     for key in ids:
         assert isinstance(e.info(key), int), key
     e.close()
+
+
+def test_checkpoint_keeps_one_nominal_step_size_one(oracle):
+    """(ABI v6, AHMC_INFO_STEPSIZE_SCALAR) `ahmc_get_stepsize` always fills N values; a checkpoint records whether the context holds ONE nominal
+    step size and restores it as one — a FixedIntegrationTime kernel (which takes nothing else, src/trajectory.jl:241-243) resumes; round 6: it
+    came back as a vector and the resumed run was refused (found by tests/test_random_configurations.py)"""
+    D, N = 4, 6
+    h = A.Hamiltonian(A.DiagEuclideanMetric((D, N)), A.IsoGaussian(D))
+    lf = A.Leapfrog(0.2)
+    k = A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedIntegrationTime(1.0)))
+    th = np.random.default_rng(0).normal(size=(D, N))
+
+    def fresh():
+        e = A.Engine(h, N, rng=3, lib=oracle)
+        e.set_integrator(lf)
+        e.set_position(th)
+        return e
+
+    a = fresh()
+    assert a.info("stepsize_scalar") == 1
+    a.run(k, 3, 0)
+    st = a.get_state()
+    assert st["stepsize_scalar"] and st["stepsize"].shape == (N,)
+    a.run(k, 6, 0, i_first=4)
+    b = fresh()
+    b.set_state(st)
+    assert b.info("stepsize_scalar") == 1
+    b.run(k, 6, 0, i_first=4)
+    np.testing.assert_array_equal(a.theta(), b.theta())
+    # per-chain step sizes stay per-chain (and FixedIntegrationTime refuses them, Q6)
+    a.set_integrator(A.Leapfrog(np.full(N, 0.2)))
+    assert a.info("stepsize_scalar") == 0 and not a.get_state()["stepsize_scalar"]
+    with pytest.raises(A.ArgumentError):
+        a.run(k, 7, 0, i_first=7)
+    # … and so does a scalar one after adaptation has given every chain its own
+    c = fresh()
+    c.adaptor_init(A.StepSizeAdaptor(0.8, lf))
+    c.run(A.HMCKernel(A.Trajectory(A.EndPointTS, lf, A.FixedNSteps(3))), 4, 4)
+    assert c.info("stepsize_scalar") == 0
+    for e in (a, b, c):
+        e.close()
